@@ -1,0 +1,107 @@
+"""ctypes binding of libacimg.so (the C ABI declared in include/acimg.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a symbol is absent this
+module raises, loudly.  Build it with ``__graft_entry__.build()`` (or ``make`` in ``csrc/``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libacimg.so")
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+class ConvDesc(C.Structure):
+    """Mirror of AcimgConvDesc (include/acimg.h)."""
+
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "H", "W", "C", "ldx", "K", "ldy", "OH", "OW", "R", "S", "stride", "pad_t", "pad_l",
+        "ldw", "act")]
+
+    def __repr__(self):
+        return "ConvDesc(" + ", ".join("%s=%d" % (n, getattr(self, n)) for n, _ in self._fields_) + ")"
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_long
+_F = C.c_float
+_D = C.c_double
+_SZ = C.c_size_t
+_DP = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); every symbol include/acimg.h declares
+PROTOTYPES = {
+    "acimg_version": (_I, []),
+    "acimg_last_error": (_I, [C.c_char_p, _SZ]),
+    "acimg_conv2d_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _P, _I, _P, _P, _SZ, _P]),
+    "acimg_conv2d_stats_rows": (_I, [_DP]),
+    "acimg_conv2d_fwd_workspace": (_SZ, [_DP]),
+    "acimg_conv2d_dgrad": (_I, [_DP, _P, _I, _P, _P, _P, _I, _P, _I, _P, _SZ, _P]),
+    "acimg_conv2d_dgrad_workspace": (_SZ, [_DP]),
+    "acimg_conv2d_wgrad": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),
+    "acimg_conv2d_wgrad_workspace": (_SZ, [_DP]),
+    "acimg_deconv_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _SZ, _P]),
+    "acimg_deconv_dgrad": (_I, [_DP, _P, _I, _P, _P, _P, _I, _P, _SZ, _P]),
+    "acimg_deconv_wgrad": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),
+    "acimg_deconv_workspace": (_SZ, [_DP]),
+    "acimg_bn_finalize": (_I, [_P, _I, _I, _I, _D, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P]),
+    "acimg_bn_add_relu": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "acimg_bn_relu_maxpool": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "acimg_bn_relu": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "acimg_bn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "acimg_pad_channels": (_I, [_P, _P, _L, _I, _I, _P]),
+    "acimg_tile_mfcc": (_I, [_P, _P, _I, _I, _I, _P]),
+    "acimg_minmax_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    "acimg_minmax_bwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "acimg_latent_fwd": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
+    "acimg_latent_bwd": (_I, [_P, _P, _P, _P, _I, _F, _P, _I, _I, _P]),
+    "acimg_recon_loss": (_I, [_P, _P, _P, _P, _L, _F, _F, _P]),
+    "acimg_grad_slice": (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _I, _P]),
+    "acimg_loss_finalize": (_I, [_P, _P, _I, _D, _F, _F, _F, _F, _P, _P]),
+    "acimg_zero": (_I, [_P, _SZ, _P]),
+    "acimg_sumsq": (_I, [_P, _L, _P, _P]),
+    "acimg_axpy": (_I, [_F, _P, _P, _L, _P]),
+    "acimg_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
+    "acimg_mfcc_frontend": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "acimg_find_logen": (_I, [_P, _P, _P, _L, _P]),
+}
+
+_lib = None
+
+
+class AcimgError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libacimg.so and bind every prototype; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AcimgError(
+            "libacimg.so not found at %s: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise AcimgError("libacimg.so lacks symbol %s" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    load().acimg_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise AcimgError("%s failed (rc=%d): %s" % (what or "acimg call", rc, last_error()))

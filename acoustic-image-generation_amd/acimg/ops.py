@@ -1,0 +1,322 @@
+"""Host-side op layer: builds *plans* (lists of C-ABI calls on device buffers) for the kernels in
+libacimg.so.  PyTorch is only the allocator / stream provider here; every arithmetic op of the hot
+path is a call through ``acimg._lib`` (no torch math, no CPU fallback).
+
+A :class:`Plan` can run eagerly (tests, one-off calls) or be recorded once and replayed every
+step with fixed buffers, which keeps Python overhead to one ctypes call per kernel launch.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvDesc  # noqa: F401
+
+
+def up4(v):
+    return (int(v) + 3) & ~3
+
+
+class Ptr(object):
+    """A device address = tensor base + offset (in floats); keeps the tensor alive."""
+
+    __slots__ = ("t", "off")
+
+    def __init__(self, t, off=0):
+        self.t = t
+        self.off = int(off)
+
+    def addr(self):
+        return self.t.data_ptr() + 4 * self.off
+
+
+class Workspace(object):
+    """Caller-owned scratch shared by all calls of a plan (the library allocates nothing)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.need = 256
+        self.buf = None
+
+    def require(self, nbytes):
+        self.need = max(self.need, int(nbytes))
+
+    def allocate(self):
+        if self.buf is None or self.buf.numel() < self.need:
+            self.buf = torch.empty(self.need, dtype=torch.uint8, device=self.device)
+        return self
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    @property
+    def nbytes(self):
+        return self.buf.numel()
+
+
+class _WsPtr(object):
+    def __init__(self, ws):
+        self.ws = ws
+
+
+class _WsBytes(object):
+    def __init__(self, ws):
+        self.ws = ws
+
+
+def _resolve(a):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    if isinstance(a, Ptr):
+        return a.addr()
+    if isinstance(a, _WsPtr):
+        return a.ws.ptr
+    if isinstance(a, _WsBytes):
+        return a.ws.nbytes
+    return a
+
+
+def current_stream_handle(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class Plan(object):
+    """Ordered list of C-ABI calls.  eager=True runs each call as it is added."""
+
+    def __init__(self, device=None, eager=False, ws=None):
+        self.device = device
+        self.eager = eager
+        self.ws = ws if ws is not None else Workspace(device)
+        self.calls = []      # (name, fn, raw args, keepalive)
+        self._resolved = None
+
+    def add(self, name, fn, *args):
+        if self.eager:
+            self.ws.allocate()
+            rc = fn(*[_resolve(a) for a in args], current_stream_handle(self.device))
+            _lib.check(rc, name)
+        else:
+            self.calls.append((name, fn, args))
+            self._resolved = None
+
+    def extend(self, other):
+        self.calls.extend(other.calls)
+        self._resolved = None
+
+    def finalize(self):
+        self.ws.allocate()
+        self._resolved = [(name, fn, tuple(_resolve(a) for a in args)) for name, fn, args in self.calls]
+        return self
+
+    def run(self, stream=None):
+        if self._resolved is None:
+            self.finalize()
+        st = stream if stream is not None else current_stream_handle(self.device)
+        for name, fn, args in self._resolved:
+            rc = fn(*args, st)
+            if rc:
+                _lib.check(rc, name)
+
+    def __len__(self):
+        return len(self.calls)
+
+
+# ------------------------------------------------------------------------------------------------
+# geometry helpers (TensorFlow padding rules)
+# ------------------------------------------------------------------------------------------------
+def same_out_pad(size, k, s):
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2
+
+
+def conv_desc(N, H, W, C, K, R, S, stride=1, padding="SAME", ldx=None, ldy=None, ldw=None,
+              act=ACT_NONE):
+    """Descriptor for tf.layers.conv2d / slim conv2d.  padding: 'SAME', 'VALID' or an int p for
+    explicit symmetric padding followed by VALID (slim conv2d_same)."""
+    d = ConvDesc()
+    if padding == "SAME":
+        OH, pt = same_out_pad(H, R, stride)
+        OW, pl = same_out_pad(W, S, stride)
+    elif padding == "VALID":
+        OH, OW, pt, pl = (H - R) // stride + 1, (W - S) // stride + 1, 0, 0
+    else:
+        p = int(padding)
+        OH, OW, pt, pl = (H + 2 * p - R) // stride + 1, (W + 2 * p - S) // stride + 1, p, p
+    d.N, d.H, d.W, d.C = N, H, W, C
+    d.ldx = C if ldx is None else ldx
+    d.K = K
+    d.ldy = up4(K) if ldy is None else ldy
+    d.OH, d.OW, d.R, d.S, d.stride, d.pad_t, d.pad_l = OH, OW, R, S, stride, pt, pl
+    d.ldw = up4(K) if ldw is None else ldw
+    d.act = act
+    return d
+
+
+def deconv_desc(N, H, W, C, K, R, S, stride, ldx=None, ldy=None, ldw=None):
+    """Descriptor for tf.layers.conv2d_transpose VALID with kernel <= stride: out = in*stride."""
+    d = ConvDesc()
+    d.N, d.H, d.W, d.C = N, H, W, C
+    d.ldx = C if ldx is None else ldx
+    d.K = K
+    d.ldy = K if ldy is None else ldy
+    d.OH, d.OW, d.R, d.S, d.stride, d.pad_t, d.pad_l = H * stride, W * stride, R, S, stride, 0, 0
+    d.ldw = C if ldw is None else ldw
+    d.act = ACT_NONE
+    return d
+
+
+# ------------------------------------------------------------------------------------------------
+# op wrappers: each appends one (or a few) C-ABI calls to `plan`
+# ------------------------------------------------------------------------------------------------
+def _L():
+    return _lib.load()
+
+
+def conv2d_stats_rows(d):
+    return _L().acimg_conv2d_stats_rows(C.byref(d))
+
+
+def conv2d_fwd(plan, d, x, w, bias, y, in_scale=None, in_shift=None, in_relu=0, stats=None):
+    L = _L()
+    plan.ws.require(L.acimg_conv2d_fwd_workspace(C.byref(d)))
+    plan.add("conv2d_fwd", L.acimg_conv2d_fwd, C.byref(d), x, w, bias, y, in_scale, in_shift,
+             int(in_relu), stats, _WsPtr(plan.ws), _WsBytes(plan.ws))
+
+
+def conv2d_dgrad(plan, d, gy, ldgy, w, dx, residual=None, ldres=0, mask=None, ldmask=0):
+    L = _L()
+    plan.ws.require(L.acimg_conv2d_dgrad_workspace(C.byref(d)))
+    plan.add("conv2d_dgrad", L.acimg_conv2d_dgrad, C.byref(d), gy, int(ldgy), w, dx, residual,
+             int(ldres), mask, int(ldmask), _WsPtr(plan.ws), _WsBytes(plan.ws))
+
+
+def conv2d_wgrad(plan, d, x, gy, ldgy, dw, db=None):
+    L = _L()
+    plan.ws.require(L.acimg_conv2d_wgrad_workspace(C.byref(d)))
+    plan.add("conv2d_wgrad", L.acimg_conv2d_wgrad, C.byref(d), x, gy, int(ldgy), dw, db,
+             _WsPtr(plan.ws), _WsBytes(plan.ws))
+
+
+def deconv_fwd(plan, d, x, w, bias, y):
+    L = _L()
+    plan.ws.require(L.acimg_deconv_workspace(C.byref(d)))
+    plan.add("deconv_fwd", L.acimg_deconv_fwd, C.byref(d), x, w, bias, y, _WsPtr(plan.ws),
+             _WsBytes(plan.ws))
+
+
+def deconv_dgrad(plan, d, gy, ldgy, w, dx, mask=None, ldmask=0):
+    L = _L()
+    plan.ws.require(L.acimg_deconv_workspace(C.byref(d)))
+    plan.add("deconv_dgrad", L.acimg_deconv_dgrad, C.byref(d), gy, int(ldgy), w, dx, mask,
+             int(ldmask), _WsPtr(plan.ws), _WsBytes(plan.ws))
+
+
+def deconv_wgrad(plan, d, x, gy, ldgy, dw, db=None):
+    L = _L()
+    plan.ws.require(L.acimg_deconv_workspace(C.byref(d)))
+    plan.add("deconv_wgrad", L.acimg_deconv_wgrad, C.byref(d), x, gy, int(ldgy), dw, db,
+             _WsPtr(plan.ws), _WsBytes(plan.ws))
+
+
+def bn_finalize(plan, stats, rows, Cn, ldstats, count, gamma, beta, moving_mean, moving_var, scale,
+                shift, decay=0.997, eps=1e-5, training=True, save_mean=None, save_invstd=None):
+    plan.add("bn_finalize", _L().acimg_bn_finalize, stats, int(rows), int(Cn), int(ldstats),
+             float(count), gamma, beta, moving_mean, moving_var, float(decay), float(eps),
+             int(bool(training)), scale, shift, save_mean, save_invstd)
+
+
+def bn_add_relu(plan, a, sa, ta, b, sb, tb, out, N, OH, OW, Cn, BH, BW, bstride):
+    plan.add("bn_add_relu", _L().acimg_bn_add_relu, a, sa, ta, b, sb, tb, out, N, OH, OW, Cn, BH, BW,
+             bstride)
+
+
+def bn_relu_maxpool(plan, x, scale, shift, out, N, H, W, Cn, OH, OW, pad_t, pad_l):
+    plan.add("bn_relu_maxpool", _L().acimg_bn_relu_maxpool, x, scale, shift, out, N, H, W, Cn, OH, OW,
+             pad_t, pad_l)
+
+
+def bn_relu(plan, x, scale, shift, y, rows, Cn, ldx, ldy):
+    plan.add("bn_relu", _L().acimg_bn_relu, x, scale, shift, y, int(rows), Cn, ldx, ldy)
+
+
+def bn_relu_bwd(plan, x, y, gy, gamma, save_mean, save_invstd, gx, dgamma, dbeta, rows, Cn):
+    plan.add("bn_relu_bwd", _L().acimg_bn_relu_bwd, x, y, gy, gamma, save_mean, save_invstd, gx,
+             dgamma, dbeta, int(rows), Cn)
+
+
+def pad_channels(plan, x, y, pixels, Cn, Cp):
+    plan.add("pad_channels", _L().acimg_pad_channels, x, y, int(pixels), Cn, Cp)
+
+
+def tile_mfcc(plan, mfcc, out, N, HW, Cn):
+    plan.add("tile_mfcc", _L().acimg_tile_mfcc, mfcc, out, N, HW, Cn)
+
+
+def minmax_fwd(plan, x, ldx, out, ldo, mm, N, P, Cn):
+    plan.add("minmax_fwd", _L().acimg_minmax_fwd, x, ldx, out, ldo, mm, N, P, Cn)
+
+
+def minmax_bwd(plan, x, ldx, go, ldgo, mm, gx, ldgx, N, P, Cn, accumulate=False, mask_relu=False):
+    plan.add("minmax_bwd", _L().acimg_minmax_bwd, x, ldx, go, ldgo, mm, gx, ldgx, N, P, Cn,
+             int(accumulate), int(mask_relu))
+
+
+def latent_fwd(plan, heads, eps, z, ldz, sigma, kl, N, Z):
+    plan.add("latent_fwd", _L().acimg_latent_fwd, heads, eps, z, ldz, sigma, kl, N, Z)
+
+
+def latent_bwd(plan, heads, eps, sigma, gz, ldgz, kl_weight, g_heads, N, Z):
+    plan.add("latent_bwd", _L().acimg_latent_bwd, heads, eps, sigma, gz, ldgz, float(kl_weight),
+             g_heads, N, Z)
+
+
+def recon_loss(plan, yhat, target, g_logit, sums, count, w_mse=1.0, w_huber=1.0):
+    plan.add("recon_loss", _L().acimg_recon_loss, yhat, target, g_logit, sums, int(count),
+             float(w_mse), float(w_huber))
+
+
+def grad_slice(plan, src, ldsrc, dst, lddst, mask, ldmask, pixels, Cn, accumulate=False):
+    plan.add("grad_slice", _L().acimg_grad_slice, src, ldsrc, dst, lddst, mask, ldmask, int(pixels),
+             Cn, int(accumulate))
+
+
+def loss_finalize(plan, sums, kl, N, count, latent_w, half_wd, w_mse, w_huber, out):
+    plan.add("loss_finalize", _L().acimg_loss_finalize, sums, kl, N, float(count), float(latent_w),
+             float(half_wd), float(w_mse), float(w_huber), out)
+
+
+def zero(plan, t, nbytes=None):
+    n = nbytes if nbytes is not None else t.numel() * t.element_size()
+    plan.add("zero", _L().acimg_zero, t, int(n))
+
+
+def sumsq(plan, x, n, out):
+    plan.add("sumsq", _L().acimg_sumsq, x, int(n), out)
+
+
+def axpy(plan, a, x, y, n):
+    plan.add("axpy", _L().acimg_axpy, float(a), x, y, int(n))
+
+
+def adam_step(plan, p, g, m, v, n, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    plan.add("adam_step", _L().acimg_adam_step, p, g, m, v, int(n), float(lr_t), float(beta1),
+             float(beta2), float(eps), float(grad_scale))
+
+
+def mfcc_frontend(plan, frames, window, melfb, dctl, out, nframes, normalize=False):
+    plan.add("mfcc_frontend", _L().acimg_mfcc_frontend, frames, window, melfb, dctl, out, int(nframes),
+             int(bool(normalize)))
+
+
+def find_logen(plan, mfcc_img, idct, out, pixels):
+    plan.add("find_logen", _L().acimg_find_logen, mfcc_img, idct, out, int(pixels))
+
+
+def adam_lr_t(lr, step, beta1=0.9, beta2=0.999):
+    """TF-1 Adam effective step size for 1-based step t."""
+    return lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)

@@ -1,0 +1,619 @@
+// HBM-bound elementwise / reduction kernels of the acoustic-image train step (gfx950).
+// Each is a single pass with 16-byte accesses where the layout allows, wave-64 shuffle
+// reductions and fp32 (or fp64 where noted) accumulation.
+#include "common.hpp"
+
+namespace acimg {
+
+// ------------------------------------------------------------------------------------------
+// batch-norm statistics -> scale/shift (+ moving averages)
+// block = 256 threads = 8 row groups x 32 channels
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* stats, int rows, int C, int ld, double count, const float* gamma, const float* beta,
+    float* moving_mean, float* moving_var, float decay, float eps, int training, float* scale,
+    float* shift, float* save_mean, float* save_invstd) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (training && c < C) {
+        for (int r = rg; r < rows; r += 8) {
+            s1 += (double)stats[((long)r * 2 + 0) * ld + c];
+            s2 += (double)stats[((long)r * 2 + 1) * ld + c];
+        }
+    }
+    red[0][rg][cl] = s1;
+    red[1][rg][cl] = s2;
+    __syncthreads();
+    if (rg != 0 || c >= C) return;
+    float mean, var;
+    if (training) {
+        s1 = 0.0;
+        s2 = 0.0;
+        for (int i = 0; i < 8; ++i) {
+            s1 += red[0][i][cl];
+            s2 += red[1][i][cl];
+        }
+        const double m = s1 / count;
+        double v = s2 / count - m * m;
+        if (v < 0.0) v = 0.0;
+        mean = (float)m;
+        var = (float)v;
+        if (moving_mean) {
+            const double unbiased = count > 1.0 ? v * (count / (count - 1.0)) : v;
+            moving_mean[c] = decay * moving_mean[c] + (1.f - decay) * mean;
+            moving_var[c] = decay * moving_var[c] + (1.f - decay) * (float)unbiased;
+        }
+    } else {
+        mean = moving_mean[c];
+        var = moving_var[c];
+    }
+    const float invstd = 1.f / sqrtf(var + eps);
+    const float g = gamma ? gamma[c] : 1.f;
+    const float sc = g * invstd;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - mean * sc;
+    if (save_mean) save_mean[c] = mean;
+    if (save_invstd) save_invstd[c] = invstd;
+}
+
+// out = relu(a*sa+ta + (b*sb+tb | b))
+__global__ __launch_bounds__(256) void bn_add_relu_kernel(const float* a, const float* sa,
+                                                          const float* ta, const float* b,
+                                                          const float* sb, const float* tb,
+                                                          float* out, long total4, int OH, int OW,
+                                                          int C4, int BH, int BW, int bstride) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        const int c4 = (int)(idx % C4);
+        const long pix = idx / C4;
+        const int c = c4 * 4;
+        float4 va = *reinterpret_cast<const float4*>(a + pix * (C4 * 4) + c);
+        const float4 s = *reinterpret_cast<const float4*>(sa + c);
+        const float4 t = *reinterpret_cast<const float4*>(ta + c);
+        long bpix = pix;
+        if (bstride != 1) {
+            const int ow = (int)(pix % OW);
+            const long t2 = pix / OW;
+            const int oh = (int)(t2 % OH);
+            const long n = t2 / OH;
+            bpix = (n * BH + (long)oh * bstride) * BW + (long)ow * bstride;
+        }
+        float4 vb = *reinterpret_cast<const float4*>(b + bpix * (C4 * 4) + c);
+        if (sb) {
+            const float4 s2 = *reinterpret_cast<const float4*>(sb + c);
+            const float4 t2 = *reinterpret_cast<const float4*>(tb + c);
+            vb.x = vb.x * s2.x + t2.x;
+            vb.y = vb.y * s2.y + t2.y;
+            vb.z = vb.z * s2.z + t2.z;
+            vb.w = vb.w * s2.w + t2.w;
+        }
+        float4 o;
+        o.x = fmaxf(va.x * s.x + t.x + vb.x, 0.f);
+        o.y = fmaxf(va.y * s.y + t.y + vb.y, 0.f);
+        o.z = fmaxf(va.z * s.z + t.z + vb.z, 0.f);
+        o.w = fmaxf(va.w * s.w + t.w + vb.w, 0.f);
+        *reinterpret_cast<float4*>(out + pix * (C4 * 4) + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* x, const float* scale,
+                                                              const float* shift, float* out,
+                                                              long total4, int H, int W, int C4,
+                                                              int OH, int OW, int pad_t, int pad_l) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C4) * 4;
+        long t = idx / C4;
+        const int ow = (int)(t % OW);
+        t /= OW;
+        const int oh = (int)(t % OH);
+        const long n = t / OH;
+        const float4 s = *reinterpret_cast<const float4*>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);  // post-ReLU values are >= 0
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ih = oh * 2 - pad_t + r;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int iw = ow * 2 - pad_l + q;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + ((n * H + ih) * W + iw) * (C4 * 4) + c);
+                m.x = fmaxf(m.x, v.x * s.x + sh.x);
+                m.y = fmaxf(m.y, v.y * s.y + sh.y);
+                m.z = fmaxf(m.z, v.z * s.z + sh.z);
+                m.w = fmaxf(m.w, v.w * s.w + sh.w);
+            }
+        }
+        *reinterpret_cast<float4*>(out + idx * 4) = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_kernel(const float* x, const float* scale,
+                                                      const float* shift, float* y, long rows, int C,
+                                                      int ldx, int ldy) {
+    const long total = rows * C;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long r = idx / C;
+        const int c = (int)(idx - r * C);
+        y[r * ldy + c] = fmaxf(x[r * ldx + c] * scale[c] + shift[c], 0.f);
+    }
+}
+
+// one block per channel
+__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* x, const float* y,
+                                                          const float* gy, const float* gamma,
+                                                          const float* mean, const float* invstd,
+                                                          float* gx, float* dgamma, float* dbeta,
+                                                          long rows, int C) {
+    __shared__ float sm[32];
+    const int c = blockIdx.x;
+    const float mu = mean[c], is = invstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (long r = threadIdx.x; r < rows; r += 256) {
+        const float g = y[r * C + c] > 0.f ? gy[r * C + c] : 0.f;
+        s1 += g;
+        s2 += g * (x[r * C + c] - mu) * is;
+    }
+    s1 = block_sum(s1, sm);
+    s2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+        dbeta[c] = s1;
+        dgamma[c] = s2;
+    }
+    const float k = gamma[c] * is;
+    const float inv_n = 1.f / (float)rows;
+    for (long r = threadIdx.x; r < rows; r += 256) {
+        const float g = y[r * C + c] > 0.f ? gy[r * C + c] : 0.f;
+        const float xh = (x[r * C + c] - mu) * is;
+        gx[r * C + c] = k * (g - s1 * inv_n - xh * s2 * inv_n);
+    }
+}
+
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float* x, float* y, long pixels,
+                                                           int C, int Cp) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < pixels * Cp; idx += (long)gridDim.x * 256) {
+        const long p = idx / Cp;
+        const int c = (int)(idx - p * Cp);
+        y[idx] = c < C ? x[p * C + c] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_mfcc_kernel(const float* mfcc, float* out, int HW, int C,
+                                                        long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const long n = idx / ((long)HW * C);
+        out[idx] = mfcc[n * C + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-sample min-max normalisation; one block per sample
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void minmax_fwd_kernel(const float* x, int ldx, float* out, int ldo,
+                                                         float* mm, int P, int C) {
+    __shared__ float sm[32];
+    const int n = blockIdx.x;
+    const float* xs = x + (long)n * P * ldx;
+    float* os = out + (long)n * P * ldo;
+    const int cnt = P * C;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int p = i / C, c = i - p * C;
+        const float v = xs[(long)p * ldx + c];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        sm[wid] = mn;
+        sm[4 + wid] = mx;
+    }
+    __syncthreads();
+    mn = fminf(fminf(sm[0], sm[1]), fminf(sm[2], sm[3]));
+    mx = fmaxf(fmaxf(sm[4], sm[5]), fmaxf(sm[6], sm[7]));
+    const float D = mx - mn;
+    float cmin = 0.f, cmax = 0.f;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int p = i / C, c = i - p * C;
+        const float v = xs[(long)p * ldx + c];
+        cmin += (v == mn) ? 1.f : 0.f;
+        cmax += (v == mx) ? 1.f : 0.f;
+        os[(long)p * ldo + c] = (v - mn) / D;
+    }
+    cmin = block_sum(cmin, sm);
+    cmax = block_sum(cmax, sm);
+    if (threadIdx.x == 0) {
+        mm[n * 4 + 0] = mn;
+        mm[n * 4 + 1] = mx;
+        mm[n * 4 + 2] = cmin;
+        mm[n * 4 + 3] = cmax;
+    }
+}
+
+__global__ __launch_bounds__(256) void minmax_bwd_kernel(const float* x, int ldx, const float* go,
+                                                         int ldgo, const float* mm, float* gx,
+                                                         int ldgx, int P, int C, int accumulate,
+                                                         int mask_relu) {
+    __shared__ float sm[32];
+    const int n = blockIdx.x;
+    const float* xs = x + (long)n * P * ldx;
+    const float* gs = go + (long)n * P * ldgo;
+    float* gxs = gx + (long)n * P * ldgx;
+    const float mn = mm[n * 4 + 0], mx = mm[n * 4 + 1], cmin = mm[n * 4 + 2], cmax = mm[n * 4 + 3];
+    const float D = mx - mn;
+    const int cnt = P * C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int p = i / C, c = i - p * C;
+        const float g = gs[(long)p * ldgo + c];
+        const float o = (xs[(long)p * ldx + c] - mn) / D;
+        s1 += g;
+        s2 += g * o;
+    }
+    s1 = block_sum(s1, sm);
+    s2 = block_sum(s2, sm);
+    const float gmin = -(s1 - s2) / D / cmin;
+    const float gmax = -s2 / D / cmax;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int p = i / C, c = i - p * C;
+        const float v = xs[(long)p * ldx + c];
+        float g = gs[(long)p * ldgo + c] / D;
+        if (v == mn) g += gmin;
+        if (v == mx) g += gmax;
+        if (accumulate) g += gxs[(long)p * ldgx + c];
+        if (mask_relu && !(v > 0.f)) g = 0.f;
+        gxs[(long)p * ldgx + c] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// latent: softplus, reparameterisation, KL ; one block per sample
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_f(float x) {
+    // log(1+exp(x)) evaluated as TF does: max(x,0) + log1p(exp(-|x|))
+    return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+
+__global__ __launch_bounds__(256) void latent_fwd_kernel(const float* heads, const float* eps,
+                                                         float* z, int ldz, float* sigma, float* kl,
+                                                         int Z) {
+    __shared__ float sm[32];
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < Z; j += 256) {
+        const float mu = heads[(long)n * 2 * Z + j];
+        const float sg = softplus_f(heads[(long)n * 2 * Z + Z + j]);
+        sigma[(long)n * Z + j] = sg;
+        z[(long)n * ldz + j] = mu + sg * eps[(long)n * Z + j];
+        acc += mu * mu + sg * sg - logf(1e-8f + sg * sg) - 1.f;
+    }
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) kl[n] = 0.5f * acc;
+}
+
+__global__ __launch_bounds__(256) void latent_bwd_kernel(const float* heads, const float* eps,
+                                                         const float* sigma, const float* gz, int ldgz,
+                                                         float klw, float* gheads, int N, int Z) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * Z) return;
+    const int n = idx / Z, j = idx - n * Z;
+    const float mu = heads[(long)n * 2 * Z + j];
+    const float sraw = heads[(long)n * 2 * Z + Z + j];
+    const float sg = sigma[idx];
+    const float g = gz[(long)n * ldgz + j];
+    const float dmu = g + klw * mu;
+    const float dsg = g * eps[idx] + klw * (sg - sg / (1e-8f + sg * sg));
+    const float dsp = 1.f / (1.f + expf(-sraw));  // d softplus
+    gheads[(long)n * 2 * Z + j] = dmu;
+    gheads[(long)n * 2 * Z + Z + j] = dsg * dsp;
+}
+
+// ------------------------------------------------------------------------------------------
+// reconstruction loss (MSE + Huber delta=1) and gradient w.r.t. pre-sigmoid logits
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void recon_loss_kernel(const float* yhat, const float* target,
+                                                         float* glogit, float* sums, long count,
+                                                         float w_mse, float w_huber) {
+    __shared__ float sm[32];
+    float s_mse = 0.f, s_hub = 0.f;
+    const float inv = 1.f / (float)count;
+    const long n4 = count >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 yh = reinterpret_cast<const float4*>(yhat)[i];
+        const float4 tg = reinterpret_cast<const float4*>(target)[i];
+        float4 g;
+        const float yv[4] = {yh.x, yh.y, yh.z, yh.w};
+        const float tv[4] = {tg.x, tg.y, tg.z, tg.w};
+        float gv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float e = yv[k] - tv[k];
+            const float ae = fabsf(e);
+            const float q = fminf(ae, 1.f);
+            s_mse += e * e;
+            s_hub += 0.5f * q * q + (ae - q);
+            const float dl = (w_mse * 2.f * e + w_huber * fminf(fmaxf(e, -1.f), 1.f)) * inv;
+            gv[k] = dl * yv[k] * (1.f - yv[k]);
+        }
+        g.x = gv[0];
+        g.y = gv[1];
+        g.z = gv[2];
+        g.w = gv[3];
+        if (glogit) reinterpret_cast<float4*>(glogit)[i] = g;
+    }
+    // tail (count not a multiple of 4)
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
+        const float e = yhat[i] - target[i];
+        const float ae = fabsf(e);
+        const float q = fminf(ae, 1.f);
+        s_mse += e * e;
+        s_hub += 0.5f * q * q + (ae - q);
+        if (glogit)
+            glogit[i] = (w_mse * 2.f * e + w_huber * fminf(fmaxf(e, -1.f), 1.f)) * inv * yhat[i] * (1.f - yhat[i]);
+    }
+    s_mse = block_sum(s_mse, sm);
+    s_hub = block_sum(s_hub, sm);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], s_mse);
+        atomicAdd(&sums[1], s_hub);
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* out) {
+    __shared__ float sm[32];
+    float s = 0.f;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        s += x[i] * x[i];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float a, const float* x, float* y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long n,
+                                                   float lr_t, float b1, float b2, float eps, float gs) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 pv = reinterpret_cast<float4*>(p)[i];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i];
+        float4 mv = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pp = &pv.x;
+        const float* gp = &gv.x;
+        float* mp = &mv.x;
+        float* vp = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gg = gp[k] * gs;
+            mp[k] = b1 * mp[k] + (1.f - b1) * gg;
+            vp[k] = b2 * vp[k] + (1.f - b2) * gg * gg;
+            pp[k] -= lr_t * mp[k] / (sqrtf(vp[k]) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pv;
+        reinterpret_cast<float4*>(m)[i] = mv;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gg = g[i] * gs;
+        m[i] = b1 * m[i] + (1.f - b1) * gg;
+        v[i] = b2 * v[i] + (1.f - b2) * gg * gg;
+        p[i] -= lr_t * m[i] / (sqrtf(v[i]) + eps);
+    }
+}
+
+
+// dst[p][c] = [accumulate ? dst : 0] + src[p][c], zeroed where mask[p][c] <= 0 (mask optional)
+__global__ __launch_bounds__(256) void grad_slice_kernel(const float* src, int ldsrc, float* dst, int lddst,
+                                                         const float* mask, int ldmask, long pixels, int C,
+                                                         int accumulate) {
+    const long total = pixels * C;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long p = idx / C;
+        const int c = (int)(idx - p * C);
+        float v = src[p * ldsrc + c];
+        if (accumulate) v += dst[p * lddst + c];
+        if (mask && !(mask[p * ldmask + c] > 0.f)) v = 0.f;
+        dst[p * lddst + c] = v;
+    }
+}
+
+// out = {mse, huber, latent, reg, total}
+__global__ void loss_finalize_kernel(const float* sums, const float* kl, int N, double count, float latent_w,
+                                     float half_wd, float w_mse, float w_huber, float* out) {
+    __shared__ float sm[32];
+    float a = 0.f;
+    if (kl)
+        for (int i = threadIdx.x; i < N; i += blockDim.x) a += kl[i];
+    a = block_sum(a, sm);
+    if (threadIdx.x == 0) {
+        const float mse = (float)((double)sums[0] / count);
+        const float hub = (float)((double)sums[1] / count);
+        const float lat = kl ? latent_w * (a / (float)N) : 0.f;
+        const float reg = half_wd * sums[2];
+        out[0] = mse;
+        out[1] = hub;
+        out[2] = lat;
+        out[3] = reg;
+        out[4] = lat + w_mse * mse + w_huber * hub + reg;
+    }
+}
+
+static inline int ew_grid(long work_items) {
+    long b = (work_items + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace acimg
+
+using namespace acimg;
+
+extern "C" {
+
+int acimg_version(void) { return ACIMG_VERSION; }
+
+int acimg_last_error(char* buf, size_t len) {
+    if (!buf || len == 0) return ACIMG_EINVAL;
+    strncpy(buf, err_buf(), len - 1);
+    buf[len - 1] = 0;
+    return ACIMG_OK;
+}
+
+int acimg_bn_finalize(const float* stats, int rows, int C, int ldstats, double count,
+                      const float* gamma, const float* beta, float* moving_mean,
+                      float* moving_var, float decay, float eps, int training, float* scale,
+                      float* shift, float* save_mean, float* save_invstd, void* stream) {
+    if (C <= 0 || (training && (!stats || rows <= 0 || count <= 0)) || (!training && (!moving_mean || !moving_var)))
+        return fail(ACIMG_EINVAL, "bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, stats,
+                       rows, C, ldstats, count, gamma, beta, moving_mean, moving_var, decay, eps,
+                       training, scale, shift, save_mean, save_invstd);
+    return check_launch("bn_finalize");
+}
+
+int acimg_bn_add_relu(const float* a, const float* sa, const float* ta, const float* b,
+                      const float* sb, const float* tb, float* out, int N, int OH, int OW, int C,
+                      int BH, int BW, int bstride, void* stream) {
+    if (C & 3) return fail(ACIMG_EINVAL, "bn_add_relu: C must be a multiple of 4");
+    const long total4 = (long)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(bn_add_relu_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, a,
+                       sa, ta, b, sb, tb, out, total4, OH, OW, C / 4, BH, BW, bstride);
+    return check_launch("bn_add_relu");
+}
+
+int acimg_bn_relu_maxpool(const float* x, const float* scale, const float* shift, float* out,
+                          int N, int H, int W, int C, int OH, int OW, int pad_t, int pad_l,
+                          void* stream) {
+    if (C & 3) return fail(ACIMG_EINVAL, "bn_relu_maxpool: C must be a multiple of 4");
+    const long total4 = (long)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream,
+                       x, scale, shift, out, total4, H, W, C / 4, OH, OW, pad_t, pad_l);
+    return check_launch("bn_relu_maxpool");
+}
+
+int acimg_bn_relu(const float* x, const float* scale, const float* shift, float* y, long rows,
+                  int C, int ldx, int ldy, void* stream) {
+    hipLaunchKernelGGL(bn_relu_kernel, dim3(ew_grid(rows * C)), dim3(256), 0, (hipStream_t)stream, x,
+                       scale, shift, y, rows, C, ldx, ldy);
+    return check_launch("bn_relu");
+}
+
+int acimg_bn_relu_bwd(const float* x, const float* y, const float* gy, const float* gamma,
+                      const float* save_mean, const float* save_invstd, float* gx, float* dgamma,
+                      float* dbeta, long rows, int C, void* stream) {
+    hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, y, gy, gamma,
+                       save_mean, save_invstd, gx, dgamma, dbeta, rows, C);
+    return check_launch("bn_relu_bwd");
+}
+
+int acimg_pad_channels(const float* x, float* y, long pixels, int C, int Cp, void* stream) {
+    hipLaunchKernelGGL(pad_channels_kernel, dim3(ew_grid(pixels * Cp)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, pixels, C, Cp);
+    return check_launch("pad_channels");
+}
+
+int acimg_tile_mfcc(const float* mfcc, float* out, int N, int HW, int C, void* stream) {
+    const long total = (long)N * HW * C;
+    hipLaunchKernelGGL(tile_mfcc_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, mfcc,
+                       out, HW, C, total);
+    return check_launch("tile_mfcc");
+}
+
+int acimg_minmax_fwd(const float* x, int ldx, float* out, int ldo, float* mm, int N, int P, int C,
+                     void* stream) {
+    hipLaunchKernelGGL(minmax_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo,
+                       mm, P, C);
+    return check_launch("minmax_fwd");
+}
+
+int acimg_minmax_bwd(const float* x, int ldx, const float* go, int ldgo, const float* mm,
+                     float* gx, int ldgx, int N, int P, int C, int accumulate, int mask_relu,
+                     void* stream) {
+    hipLaunchKernelGGL(minmax_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, ldx, go, ldgo,
+                       mm, gx, ldgx, P, C, accumulate, mask_relu);
+    return check_launch("minmax_bwd");
+}
+
+int acimg_latent_fwd(const float* heads, const float* eps, float* z, int ldz, float* sigma,
+                     float* kl, int N, int Z, void* stream) {
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, heads, eps, z, ldz,
+                       sigma, kl, Z);
+    return check_launch("latent_fwd");
+}
+
+int acimg_latent_bwd(const float* heads, const float* eps, const float* sigma, const float* gz,
+                     int ldgz, float kl_weight, float* g_heads, int N, int Z, void* stream) {
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(cdiv((long)N * Z, 256)), dim3(256), 0, (hipStream_t)stream,
+                       heads, eps, sigma, gz, ldgz, kl_weight, g_heads, N, Z);
+    return check_launch("latent_bwd");
+}
+
+int acimg_recon_loss(const float* yhat, const float* target, float* g_logit, float* sums,
+                     long count, float w_mse, float w_huber, void* stream) {
+    if (!aligned16(yhat) || !aligned16(target) || (g_logit && !aligned16(g_logit)))
+        return fail(ACIMG_EINVAL, "recon_loss: buffers must be 16-byte aligned");
+    long blocks = (count / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(recon_loss_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, yhat,
+                       target, g_logit, sums, count, w_mse, w_huber);
+    return check_launch("recon_loss");
+}
+
+int acimg_sumsq(const float* x, long n, float* out, void* stream) {
+    if (!aligned16(x)) return fail(ACIMG_EINVAL, "sumsq: buffer must be 16-byte aligned");
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    return check_launch("sumsq");
+}
+
+int acimg_axpy(float a, const float* x, float* y, long n, void* stream) {
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, x, y, n);
+    return check_launch("axpy");
+}
+
+int acimg_adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta1,
+                    float beta2, float eps, float grad_scale, void* stream) {
+    if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v))
+        return fail(ACIMG_EINVAL, "adam_step: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m,
+                       v, n, lr_t, beta1, beta2, eps, grad_scale);
+    return check_launch("adam_step");
+}
+
+int acimg_grad_slice(const float* src, int ldsrc, float* dst, int lddst, const float* mask, int ldmask,
+                     long pixels, int C, int accumulate, void* stream) {
+    hipLaunchKernelGGL(grad_slice_kernel, dim3(ew_grid(pixels * C)), dim3(256), 0, (hipStream_t)stream, src,
+                       ldsrc, dst, lddst, mask, ldmask, pixels, C, accumulate);
+    return check_launch("grad_slice");
+}
+
+int acimg_loss_finalize(const float* sums, const float* kl, int N, double count, float latent_w,
+                        float half_wd, float w_mse, float w_huber, float* out, void* stream) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, kl, N, count,
+                       latent_w, half_wd, w_mse, w_huber, out);
+    return check_launch("loss_finalize");
+}
+
+int acimg_zero(void* ptr, size_t bytes, void* stream) {
+    hipError_t e = hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(ACIMG_ELAUNCH, "zero: %s", hipGetErrorString(e));
+    return ACIMG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,920 @@
+// fp32 implicit-GEMM convolution kernels for gfx950 (MI355X), exact-f32 MFMA
+// (v_mfma_f32_16x16x4_f32: bit-for-bit an fmaf chain, 64 FLOP/clk/SIMD).
+//
+// One kernel template covers every conv-shaped op of the acoustic-image train step:
+//   forward conv / strided conv / 1x1 / dense        A = im2col(x),  B = W[k][n]      (NN)
+//   data gradient (stride 1)                         A = im2col(gy), B = W^T flipped  (NT)
+//   kernel==stride patch ops (deconv fwd, pool dgrad)A = pixels,     B = W rows, scatter epilogue
+// and a second template does the weight gradient dW = im2col(x)^T * gy (TN, split over pixels).
+//
+// Tiling: 256 threads = 4 waves, block tile BM x BN x BK(=32), wave tile (BM/WGM) x (BN/WGN) made
+// of 16x16 MFMA tiles.  A is staged [row][k] (k contiguous, ds_read_b128 gives 4 k per lane), B is
+// staged [k][n] (NN, ds_read_b32) or [n][k] (NT, ds_read_b128).  The k order inside a 16-deep step
+// is permuted identically for A and B (lane group g owns k = 4g..4g+3), which leaves the sum
+// unchanged.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t.
+#include "igemm.hpp"
+
+namespace acimg {
+
+// ------------------------------------------------------------------------------------------
+// epilogue helpers (shared by the GEMM kernel and the split-K reducer)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ long epi_row_pix(const EpiParams& e, int m) {
+    if (!e.scatter) return m;
+    const int hw = e.AH * e.AW;
+    const int img = m / hw;
+    const int rem = m - img * hw;
+    const int h = rem / e.AW;
+    const int w = rem - h * e.AW;
+    return ((long)img * e.YH + (long)e.sc * h) * e.YW + (long)e.sc * w;
+}
+__device__ __forceinline__ void epi_col(const EpiParams& e, int n, int& cn, int& pixoff) {
+    if (!e.scatter) {
+        cn = n;
+        pixoff = 0;
+    } else {
+        const int t = n / e.Ko;
+        cn = n - t * e.Ko;
+        const int r = t / e.Sq;
+        const int q = t - r * e.Sq;
+        pixoff = r * e.YW + q;
+    }
+}
+__device__ __forceinline__ void epi_store(const EpiParams& e, long opix, int cn, float v) {
+    if (e.bias) v += e.bias[cn];
+    if (e.res) v += e.res[opix * e.ldres + cn];
+    if (e.act == ACIMG_ACT_RELU)
+        v = fmaxf(v, 0.f);
+    else if (e.act == ACIMG_ACT_SIGMOID)
+        v = 1.f / (1.f + expf(-v));
+    if (e.mask && !(e.mask[opix * e.ldmask + cn] > 0.f)) v = 0.f;
+    e.Y[opix * e.ldy + cn] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// main implicit-GEMM kernel
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, bool B_NT>
+__global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
+    constexpr int BK = 32;
+    constexpr int LDA_S = BK + 4;
+    constexpr int LDB_S = B_NT ? (BK + 4) : (BN + 4);
+    constexpr int A_ELEMS = BM * LDA_S;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int KQ = BK / 4;          // float4 per A row
+    constexpr int RPP = 256 / KQ;       // rows per pass (32)
+    constexpr int NA = BM / RPP;        // A float4 per thread
+    constexpr int NBT = (BN + RPP - 1) / RPP;           // B float4 per thread (NT)
+    constexpr int NQ = BN / 4;                          // float4 per B row (NN)
+    constexpr int RPPB = 256 / NQ;                      // B rows per pass (NN)
+    constexpr int NBN = (BK + RPPB - 1) / RPPB;         // B float4 per thread (NN)
+    constexpr int NB = B_NT ? NBT : NBN;
+    static_assert(WGM * WGN == 4, "4 waves");
+    static_assert(BM % RPP == 0, "BM multiple of 32");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + A_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int li = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // ---- K range of this split -----------------------------------------------------------
+    int it_begin = 0, it_end = p.kiters;
+    if (p.splits > 1) {
+        const int per = (p.kiters + p.splits - 1) / p.splits;
+        it_begin = blockIdx.z * per;
+        it_end = min(p.kiters, it_begin + per);
+    }
+
+    // ---- per-thread A row bookkeeping ------------------------------------------------------
+    const int kq = tid % KQ;
+    const int arow0 = tid / KQ;
+    int a_pix[NA], a_ih0[NA], a_iw0[NA];
+    {
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int m = m0 + arow0 + j * RPP;
+            if (m < p.M) {
+                const int img = m / ohw;
+                const int rem = m - img * ohw;
+                const int oh = rem / p.OW;
+                const int ow = rem - oh * p.OW;
+                a_ih0[j] = oh * p.stride - p.pad_t;
+                a_iw0[j] = ow * p.stride - p.pad_l;
+                a_pix[j] = (img * p.H + a_ih0[j]) * p.W + a_iw0[j];
+            } else {
+                a_ih0[j] = -(1 << 28);
+                a_iw0[j] = -(1 << 28);
+                a_pix[j] = 0;
+            }
+        }
+    }
+
+    float4 ra[NA], rb[NB];
+
+    auto load_tiles = [&](int it) {
+        const int seg = it / p.cps;
+        const int chunk = it - seg * p.cps;
+        const int pp = chunk * BK + kq * 4;  // position of this thread's float4 inside the segment
+        const bool validk = pp < p.L;
+        int r, s, c;
+        if (p.rowrun) {
+            r = seg;
+            s = pp / p.C;
+            c = pp - s * p.C;
+        } else {
+            r = seg / p.S;
+            s = seg - r * p.S;
+            c = pp;
+        }
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool affine = p.a_scale != nullptr;
+        if (affine && validk) {
+            sc4 = *reinterpret_cast<const float4*>(p.a_scale + c);
+            sh4 = *reinterpret_cast<const float4*>(p.a_shift + c);
+        }
+        const int rwoff = r * p.W + s;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int ih = a_ih0[j] + r, iw = a_iw0[j] + s;
+            const bool ok = validk && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                v = *reinterpret_cast<const float4*>(p.A + (long)(a_pix[j] + rwoff) * p.lda + c);
+                if (affine) {
+                    v.x = v.x * sc4.x + sh4.x;
+                    v.y = v.y * sc4.y + sh4.y;
+                    v.z = v.z * sc4.z + sh4.z;
+                    v.w = v.w * sc4.w + sh4.w;
+                    if (p.a_relu) {
+                        v.x = fmaxf(v.x, 0.f);
+                        v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f);
+                        v.w = fmaxf(v.w, 0.f);
+                    }
+                }
+            }
+            ra[j] = v;
+        }
+        if constexpr (B_NT) {
+            const int tap = p.rowrun ? (seg * p.S + s) : seg;
+            const int tapb = p.flip ? (p.ntaps - 1 - tap) : tap;
+            const float* bbase = p.B + (long)tapb * p.tap_stride + c;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int nrow = arow0 + j * RPP;
+                const int n = n0 + nrow;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (validk && nrow < BN && n < p.Ngemm)
+                    v = *reinterpret_cast<const float4*>(bbase + (long)n * p.ldb);
+                rb[j] = v;
+            }
+        } else {
+            const int nq = tid % NQ;
+            const int krow0 = tid / NQ;
+            const int n = n0 + nq * 4;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int krow = krow0 + j * RPPB;
+                const int pb = chunk * BK + krow;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (krow < BK && pb < p.L && n < p.Nld)
+                    v = *reinterpret_cast<const float4*>(p.B + ((long)seg * p.L + pb) * p.ldb + n);
+                rb[j] = v;
+            }
+        }
+    };
+
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            *reinterpret_cast<float4*>(&As[(arow0 + j * RPP) * LDA_S + kq * 4]) = ra[j];
+        if constexpr (B_NT) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int nrow = arow0 + j * RPP;
+                if (nrow < BN) *reinterpret_cast<float4*>(&Bs[nrow * LDB_S + kq * 4]) = rb[j];
+            }
+        } else {
+            const int nq = tid % NQ;
+            const int krow0 = tid / NQ;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int krow = krow0 + j * RPPB;
+                if (krow < BK) *reinterpret_cast<float4*>(&Bs[krow * LDB_S + nq * 4]) = rb[j];
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (it_begin < it_end) {
+        load_tiles(it_begin);
+        store_tiles();
+    }
+    __syncthreads();
+
+    for (int it = it_begin; it < it_end; ++it) {
+        const bool more = (it + 1) < it_end;
+        if (more) load_tiles(it + 1);
+
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            float4 a4[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a4[i] = *reinterpret_cast<const float4*>(
+                    &As[(wm * WTM + i * 16 + li) * LDA_S + kk * 16 + 4 * g]);
+            float bf[TN][4];
+            if constexpr (B_NT) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(
+                        &Bs[(wn * WTN + j * 16 + li) * LDB_S + kk * 16 + 4 * g]);
+                    bf[j][0] = b4.x;
+                    bf[j][1] = b4.y;
+                    bf[j][2] = b4.z;
+                    bf[j][3] = b4.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        bf[j][t] = Bs[(kk * 16 + 4 * g + t) * LDB_S + wn * WTN + j * 16 + li];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float av = t == 0 ? a4[i].x : (t == 1 ? a4[i].y : (t == 2 ? a4[i].z : a4[i].w));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[j][t], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    if (p.splits > 1) {
+        float* slab = p.slab + (long)blockIdx.z * p.M * p.slab_ld;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int m = m0 + wm * WTM + i * 16 + g * 4 + rg;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * WTN + j * 16 + li;
+                    if (n < p.Ngemm) slab[(long)m * p.slab_ld + n] = acc[i][j][rg];
+                }
+            }
+        return;
+    }
+
+    const EpiParams& e = p.e;
+    int cn[TN], pixoff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) epi_col(e, n0 + wn * WTN + j * 16 + li, cn[j], pixoff[j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int m = m0 + wm * WTM + i * 16 + g * 4 + rg;
+            if (m >= e.M) continue;
+            const long rp = epi_row_pix(e, m);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + li;
+                if (n < e.Nstore) epi_store(e, rp + pixoff[j], cn[j], acc[i][j][rg]);
+            }
+        }
+
+    if (e.stats) {
+        // column sums / sums of squares of the raw accumulators of this row block.  Rows >= M
+        // were zero-filled on load, so they add nothing.
+        __syncthreads();  // everyone is done with As/Bs
+        float* red = smem;  // [WGM][2][BN]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float v = acc[i][j][rg];
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (g == 0) {
+                const int col = wn * WTN + j * 16 + li;
+                red[(wm * 2 + 0) * BN + col] = s1;
+                red[(wm * 2 + 1) * BN + col] = s2;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * BN; idx += 256) {
+            const int which = idx / BN, col = idx - which * BN;
+            const int n = n0 + col;
+            if (n < e.stats_ld) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGM; ++w) s += red[(w * 2 + which) * BN + col];
+                e.stats[((long)blockIdx.x * 2 + which) * e.stats_ld + n] = s;
+            }
+        }
+    }
+}
+
+// split-K reducer: sums the slabs and runs the epilogue
+__global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float* slab, int splits,
+                                                                  int M, int Ngemm, int slab_ld,
+                                                                  const EpiParams e) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)M * Ngemm;
+    if (idx >= total) return;
+    const int m = (int)(idx / Ngemm);
+    const int n = (int)(idx - (long)m * Ngemm);
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += slab[((long)z * M + m) * slab_ld + n];
+    if (n >= e.Nstore) return;
+    int cn, pixoff;
+    epi_col(e, n, cn, pixoff);
+    epi_store(e, epi_row_pix(e, m) + pixoff, cn, v);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient kernel: dW[kk][n] = sum_m A(m,kk) G[m][n]
+// ------------------------------------------------------------------------------------------
+template <int BMO, int BN>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
+    constexpr int BKR = 16;  // pixels per step
+    constexpr int LDA_S = BMO + 4;
+    constexpr int LDB_S = BN + 4;
+    constexpr int WTM = BMO / 2, WTN = BN / 2;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int AQ = BMO / 4;               // float4 per A row
+    constexpr int ARPP = 256 / AQ;            // A rows per pass
+    constexpr int NA = (BKR + ARPP - 1) / ARPP;
+    constexpr int BQ = BN / 4;
+    constexpr int BRPP = 256 / BQ;
+    constexpr int NB = (BKR + BRPP - 1) / BRPP;
+
+    __shared__ __attribute__((aligned(16))) float As[BKR * LDA_S];
+    __shared__ __attribute__((aligned(16))) float Bs[BKR * LDB_S];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int li = lane & 15, g = lane >> 4;
+    const int kk0 = blockIdx.x * BMO, n0 = blockIdx.y * BN;
+
+    const int m_begin = blockIdx.z * p.rows_per_split;
+    const int m_end = min(p.M, m_begin + p.rows_per_split);
+
+    // this thread's fixed A column (kk -> tap, c)
+    const int aq = tid % AQ;
+    const int arow0 = tid / AQ;
+    const int kk = kk0 + aq * 4;
+    const bool kk_ok = kk < p.KK;
+    int r = 0, s = 0, c = 0;
+    if (kk_ok) {
+        const int tap = kk / p.C;
+        c = kk - tap * p.C;
+        r = tap / p.S;
+        s = tap - r * p.S;
+    }
+    const int bq = tid % BQ;
+    const int brow0 = tid / BQ;
+    const int nb = n0 + bq * 4;
+    const bool nb_ok = nb < p.Nld;
+    const int ohw = p.OH * p.OW;
+
+    float4 ra[NA], rb[NB];
+    auto load_tiles = [&](int mb) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int row = arow0 + j * ARPP;
+            const int m = mb + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < BKR && kk_ok && m < m_end) {
+                const int img = m / ohw;
+                const int rem = m - img * ohw;
+                const int oh = rem / p.OW;
+                const int ow = rem - oh * p.OW;
+                const int ih = oh * p.stride - p.pad_t + r;
+                const int iw = ow * p.stride - p.pad_l + s;
+                if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                    v = *reinterpret_cast<const float4*>(
+                        p.X + ((long)(img * p.H + ih) * p.W + iw) * p.ldx + c);
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int row = brow0 + j * BRPP;
+            const int m = mb + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < BKR && nb_ok && m < m_end)
+                v = *reinterpret_cast<const float4*>(p.G + (long)m * p.ldg + nb);
+            rb[j] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int row = arow0 + j * ARPP;
+            if (row < BKR) *reinterpret_cast<float4*>(&As[row * LDA_S + aq * 4]) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int row = brow0 + j * BRPP;
+            if (row < BKR) *reinterpret_cast<float4*>(&Bs[row * LDB_S + bq * 4]) = rb[j];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (m_begin < m_end) {
+        load_tiles(m_begin);
+        store_tiles();
+    }
+    __syncthreads();
+    for (int mb = m_begin; mb < m_end; mb += BKR) {
+        const bool more = (mb + BKR) < m_end;
+        if (more) load_tiles(mb + BKR);
+        float af[TM][4], bf[TN][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i][t] = As[(4 * g + t) * LDA_S + wm * WTM + i * 16 + li];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j][t] = Bs[(4 * g + t) * LDB_S + wn * WTN + j * 16 + li];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+        __syncthreads();
+        if (more) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    float* out = p.out + (long)blockIdx.z * p.KK * p.ldo;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int row = kk0 + wm * WTM + i * 16 + g * 4 + rg;
+            if (row >= p.KK) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + li;
+                if (n < p.Ngemm) out[(long)row * p.ldo + n] = acc[i][j][rg];
+            }
+        }
+}
+
+// sums `splits` slabs of [rows][ld] (only cols < ncols) into out[rows][ld]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int splits, long rows,
+                                                          int ncols, int ld, float* out) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * ncols) return;
+    const long row = idx / ncols;
+    const int col = (int)(idx - row * ncols);
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += slab[((long)z * rows + row) * ld + col];
+    out[row * ld + col] = v;
+}
+
+// column sums of G[rows][ld] (cols < ncols) -> out[ncols]; one block per 64 columns, 256 threads
+// = 4 row-groups x 64 columns.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* G, long rows, int ncols,
+                                                             int ld, long rows_per_block,
+                                                             float* partial /*[gridDim.y][ncols]*/) {
+    __shared__ float red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    const long rb = (long)blockIdx.y * rows_per_block;
+    const long re = min(rows, rb + rows_per_block);
+    float s = 0.f;
+    if (col < ncols)
+        for (long r = rb + rg; r < re; r += 4) s += G[r * ld + col];
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && col < ncols)
+        partial[(long)blockIdx.y * ncols + col] = red[0][threadIdx.x] + red[1][threadIdx.x] +
+                                                  red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* partial, int parts, int ncols, float* out) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= ncols) return;
+    float s = 0.f;
+    for (int i = 0; i < parts; ++i) s += partial[(long)i * ncols + col];
+    out[col] = s;
+}
+
+// writes bias to the output positions of a kernel<stride transposed conv that no patch covers
+__global__ __launch_bounds__(256) void deconv_gap_fill_kernel(float* y, int ldy, const float* bias,
+                                                              long pixels, int OH, int OW, int K,
+                                                              int R, int S, int stride) {
+    const int k4 = K / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= pixels * k4) return;
+    const long pix = idx / k4;
+    const int c = (int)(idx - pix * k4) * 4;
+    const int ox = (int)(pix % OW);
+    const int oy = (int)((pix / OW) % OH);
+    if ((oy % stride) < R && (ox % stride) < S) return;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b = *reinterpret_cast<const float4*>(bias + c);
+    *reinterpret_cast<float4*>(y + pix * ldy + c) = b;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: configuration choice and launch
+// ------------------------------------------------------------------------------------------
+struct TileCfg {
+    int bm, bn;
+};
+
+static TileCfg pick_cfg(int M, int Ngemm) {
+    if (Ngemm <= 16) return {256, 16};
+    if (Ngemm <= 64) return {128, 64};
+    const long tiles128 = (long)cdiv(M, 128) * cdiv(Ngemm, 128);
+    if (tiles128 < 192) return {64, 64};
+    return {128, 128};
+}
+
+static int pick_splits(int M, int Ngemm, TileCfg c, int kiters) {
+    const long tiles = (long)cdiv(M, c.bm) * cdiv(Ngemm, c.bn);
+    if (tiles >= 192 || kiters < 8) return 1;
+    long s = (512 + tiles - 1) / tiles;
+    if (s > kiters / 4) s = kiters / 4;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+static size_t igemm_ws_bytes(int M, int Ngemm, int kiters) {
+    TileCfg c = pick_cfg(M, Ngemm);
+    int s = pick_splits(M, Ngemm, c, kiters);
+    if (s <= 1) return 0;
+    const int ld = (Ngemm + 3) & ~3;
+    return (size_t)s * M * ld * sizeof(float);
+}
+
+template <int BM, int BN, int WGM, int WGN, bool NT>
+static void launch_cfg(const IgemmParams& p, dim3 grid, hipStream_t st) {
+    constexpr int BK = 32;
+    constexpr int a_elems = BM * (BK + 4);
+    constexpr int b_elems = NT ? BN * (BK + 4) : BK * (BN + 4);
+    constexpr int stat_elems = WGM * 2 * BN;
+    constexpr int elems = (a_elems + b_elems) > stat_elems ? (a_elems + b_elems) : stat_elems;
+    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, NT>), grid, dim3(256),
+                       elems * sizeof(float), st, p);
+}
+
+static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (p.M <= 0 || p.Ngemm <= 0) return fail(ACIMG_EINVAL, "igemm: empty problem");
+    if ((p.C & 3) || (p.lda & 3) || (p.ldb & 3))
+        return fail(ACIMG_EINVAL, "igemm: C=%d lda=%d ldb=%d must be multiples of 4", p.C, p.lda, p.ldb);
+    if (!aligned16(p.A) || !aligned16(p.B)) return fail(ACIMG_EINVAL, "igemm: operands must be 16-byte aligned");
+    const int nseg = p.rowrun ? p.R : p.R * p.S;
+    p.L = p.rowrun ? p.S * p.C : p.C;
+    p.cps = cdiv(p.L, 32);
+    p.kiters = nseg * p.cps;
+    p.ntaps = p.R * p.S;
+    TileCfg c = pick_cfg(p.M, p.Ngemm);
+    p.splits = pick_splits(p.M, p.Ngemm, c, p.kiters);
+    if (p.e.stats) p.splits = 1;
+    p.slab = nullptr;
+    p.slab_ld = (p.Ngemm + 3) & ~3;
+    if (p.splits > 1) {
+        const size_t need = (size_t)p.splits * p.M * p.slab_ld * sizeof(float);
+        if (ws == nullptr || ws_bytes < need)
+            return fail(ACIMG_EWORKSPACE, "igemm: workspace %zu < %zu", ws_bytes, need);
+        p.slab = static_cast<float*>(ws);
+    }
+    dim3 grid(cdiv(p.M, c.bm), cdiv(p.Ngemm, c.bn), p.splits);
+    if (c.bm == 128 && c.bn == 128) {
+        if (nt) launch_cfg<128, 128, 2, 2, true>(p, grid, st);
+        else launch_cfg<128, 128, 2, 2, false>(p, grid, st);
+    } else if (c.bm == 128 && c.bn == 64) {
+        if (nt) launch_cfg<128, 64, 2, 2, true>(p, grid, st);
+        else launch_cfg<128, 64, 2, 2, false>(p, grid, st);
+    } else if (c.bm == 64 && c.bn == 64) {
+        if (nt) launch_cfg<64, 64, 2, 2, true>(p, grid, st);
+        else launch_cfg<64, 64, 2, 2, false>(p, grid, st);
+    } else {
+        if (nt) launch_cfg<256, 16, 4, 1, true>(p, grid, st);
+        else launch_cfg<256, 16, 4, 1, false>(p, grid, st);
+    }
+    int rc = check_launch("igemm");
+    if (rc) return rc;
+    if (p.splits > 1) {
+        const long total = (long)p.M * p.Ngemm;
+        hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
+                           p.slab, p.splits, p.M, p.Ngemm, p.slab_ld, p.e);
+        rc = check_launch("igemm_splitk_reduce");
+    }
+    return rc;
+}
+
+static int pick_wgrad_splits(int M, int KK, int Ngemm, int bmo, int bn) {
+    const long tiles = (long)cdiv(KK, bmo) * cdiv(Ngemm, bn);
+    long s = (768 + tiles - 1) / tiles;
+    const long maxs = (M + 255) / 256;  // at least 256 pixels per split
+    if (s > maxs) s = maxs;
+    if (s > 128) s = 128;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+static void wgrad_tile(int Ngemm, int& bmo, int& bn) {
+    bmo = 128;
+    bn = Ngemm <= 32 ? 32 : (Ngemm <= 64 ? 64 : 128);
+}
+static size_t wgrad_ws_bytes(int M, int KK, int Ngemm, int ldo) {
+    int bmo, bn;
+    wgrad_tile(Ngemm, bmo, bn);
+    const int s = pick_wgrad_splits(M, KK, Ngemm, bmo, bn);
+    return s > 1 ? (size_t)s * KK * ldo * sizeof(float) : 0;
+}
+
+static int launch_wgrad(WgradParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+    if ((p.C & 3) || (p.ldx & 3) || (p.ldg & 3) || (p.ldo & 3))
+        return fail(ACIMG_EINVAL, "wgrad: C=%d ldx=%d ldg=%d ldo=%d must be multiples of 4", p.C, p.ldx, p.ldg, p.ldo);
+    if (!aligned16(p.X) || !aligned16(p.G) || !aligned16(dw))
+        return fail(ACIMG_EINVAL, "wgrad: operands must be 16-byte aligned");
+    int bmo, bn;
+    wgrad_tile(p.Ngemm, bmo, bn);
+    p.splits = pick_wgrad_splits(p.M, p.KK, p.Ngemm, bmo, bn);
+    int rps = cdiv(p.M, p.splits);
+    rps = ((rps + 15) / 16) * 16;
+    p.rows_per_split = rps;
+    p.splits = cdiv(p.M, rps);
+    if (p.splits > 1) {
+        const size_t need = (size_t)p.splits * p.KK * p.ldo * sizeof(float);
+        if (ws == nullptr || ws_bytes < need)
+            return fail(ACIMG_EWORKSPACE, "wgrad: workspace %zu < %zu", ws_bytes, need);
+        p.out = static_cast<float*>(ws);
+    } else {
+        p.out = dw;
+    }
+    dim3 grid(cdiv(p.KK, bmo), cdiv(p.Ngemm, bn), p.splits);
+    if (bn == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, st, p);
+    else if (bn == 64) hipLaunchKernelGGL((wgrad_f32_kernel<128, 64>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_f32_kernel<128, 32>), grid, dim3(256), 0, st, p);
+    int rc = check_launch("wgrad");
+    if (rc) return rc;
+    if (p.splits > 1) {
+        const long total = (long)p.KK * p.Ngemm;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p.out,
+                           p.splits, (long)p.KK, p.Ngemm, p.ldo, dw);
+        rc = check_launch("wgrad_reduce");
+    }
+    return rc;
+}
+
+// column sums; workspace: parts*ncols floats
+static int launch_colsum(const float* G, long rows, int ncols, int ld, float* out, void* ws,
+                         size_t ws_bytes, hipStream_t st) {
+    int parts = (int)((rows + 511) / 512);
+    if (parts > 256) parts = 256;
+    if (parts < 1) parts = 1;
+    const long rpb = (rows + parts - 1) / parts;
+    const size_t need = (size_t)parts * ncols * sizeof(float);
+    if (ws == nullptr || ws_bytes < need) return fail(ACIMG_EWORKSPACE, "colsum: workspace %zu < %zu", ws_bytes, need);
+    float* partial = static_cast<float*>(ws);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(ncols, 64), parts), dim3(256), 0, st, G, rows,
+                       ncols, ld, rpb, partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(ncols, 64)), dim3(64), 0, st, partial, parts, ncols, out);
+    return check_launch("colsum");
+}
+static size_t colsum_ws_bytes(int ncols) { return (size_t)256 * ncols * sizeof(float); }
+
+static int check_desc(const AcimgConvDesc* d, const char* who) {
+    if (!d) return fail(ACIMG_EINVAL, "%s: null descriptor", who);
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->OH <= 0 || d->OW <= 0 ||
+        d->R <= 0 || d->S <= 0 || d->stride <= 0)
+        return fail(ACIMG_EINVAL, "%s: non-positive dimension", who);
+    if ((d->C & 3) || (d->ldx & 3) || (d->ldw & 3) || d->ldx < d->C)
+        return fail(ACIMG_EINVAL, "%s: C=%d ldx=%d ldw=%d must be multiples of 4 (ldx>=C)", who, d->C, d->ldx, d->ldw);
+    if ((long)d->N * d->H * d->W * d->ldx >= (1L << 31) || (long)d->N * d->OH * d->OW * (long)d->ldy >= (1L << 31))
+        return fail(ACIMG_EINVAL, "%s: tensor exceeds 2^31 elements", who);
+    return ACIMG_OK;
+}
+static inline int up4(int v) { return (v + 3) & ~3; }
+
+}  // namespace acimg
+
+using namespace acimg;
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int acimg_conv2d_stats_rows(const AcimgConvDesc* d) {
+    const int M = d->N * d->OH * d->OW;
+    return cdiv(M, pick_cfg(M, d->K).bm);
+}
+
+static int fwd_kiters(const AcimgConvDesc* d) {
+    const bool rowrun = d->S > 1 && d->ldx == d->C;
+    const int L = rowrun ? d->S * d->C : d->C;
+    return (rowrun ? d->R : d->R * d->S) * cdiv(L, 32);
+}
+
+size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d) {
+    return igemm_ws_bytes(d->N * d->OH * d->OW, d->K, fwd_kiters(d));
+}
+
+int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
+                     float* y, const float* in_scale, const float* in_shift, int in_relu,
+                     float* stats, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_desc(d, "conv2d_fwd");
+    if (rc) return rc;
+    if (d->ldw < d->K) return fail(ACIMG_EINVAL, "conv2d_fwd: ldw < K");
+    IgemmParams p{};
+    p.A = x; p.H = d->H; p.W = d->W; p.C = d->C; p.lda = d->ldx;
+    p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride;
+    p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.M = d->N * d->OH * d->OW;
+    p.rowrun = (d->S > 1 && d->ldx == d->C) ? 1 : 0;
+    p.a_scale = in_scale; p.a_shift = in_shift; p.a_relu = in_relu;
+    p.B = w; p.ldb = d->ldw; p.Nld = d->ldw; p.Ngemm = d->K; p.tap_stride = 0; p.flip = 0;
+    p.e.Y = y; p.e.ldy = d->ldy; p.e.M = p.M; p.e.Nstore = d->K; p.e.bias = bias; p.e.act = d->act;
+    p.e.stats = stats; p.e.stats_ld = d->ldw;
+    return launch_igemm(p, false, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t acimg_conv2d_dgrad_workspace(const AcimgConvDesc* d) {
+    const bool patch = d->stride > 1;
+    if (patch) return igemm_ws_bytes(d->N * d->OH * d->OW, d->R * d->S * d->C, cdiv(up4(d->K), 32));
+    const int ca = up4(d->K);
+    // rowrun depends on ldgy, unknown here: per-tap kiters is the larger bound for splits
+    return igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * d->S * cdiv(ca, 32)) +
+           igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * cdiv(d->S * ca, 32));
+}
+
+int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
+                       float* dx, const float* residual, int ldres, const float* mask, int ldmask,
+                       void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_desc(d, "conv2d_dgrad");
+    if (rc) return rc;
+    const int ca = up4(d->K);
+    if (ca > ldgy || ca > d->ldw || (ldgy & 3)) return fail(ACIMG_EINVAL, "conv2d_dgrad: padded K=%d exceeds ldgy=%d/ldw=%d", ca, ldgy, d->ldw);
+    IgemmParams p{};
+    p.A = gy; p.C = ca; p.lda = ldgy;
+    p.B = w; p.ldb = d->ldw;
+    p.e.Y = dx; p.e.ldy = d->ldx; p.e.res = residual; p.e.ldres = ldres; p.e.mask = mask; p.e.ldmask = ldmask;
+    p.e.act = ACIMG_ACT_NONE;
+    if (d->stride == 1) {
+        // dx[h,w,c] = sum_{r',s',k} gy[h-(R-1-pt)+r', w-(S-1-pl)+s', k] * W[R-1-r'][S-1-s'][c][k]
+        p.H = d->OH; p.W = d->OW; p.OH = d->H; p.OW = d->W;
+        p.R = d->R; p.S = d->S; p.stride = 1;
+        p.pad_t = d->R - 1 - d->pad_t; p.pad_l = d->S - 1 - d->pad_l;
+        p.M = d->N * d->H * d->W;
+        p.rowrun = (d->S > 1 && ldgy == ca) ? 1 : 0;
+        p.tap_stride = (long)d->C * d->ldw; p.flip = 1;
+        p.Ngemm = d->C;
+        p.e.M = p.M; p.e.Nstore = d->C;
+    } else {
+        if (d->stride != d->R || d->stride != d->S || d->pad_t || d->pad_l || d->OH * d->stride != d->H ||
+            d->OW * d->stride != d->W)
+            return fail(ACIMG_EINVAL, "conv2d_dgrad: stride>1 needs kernel==stride, no padding, exact tiling");
+        // patch scatter: rows = output pixels, columns = (tap, c)
+        p.H = d->OH; p.W = d->OW; p.OH = d->OH; p.OW = d->OW;
+        p.R = 1; p.S = 1; p.stride = 1; p.pad_t = 0; p.pad_l = 0;
+        p.M = d->N * d->OH * d->OW;
+        p.rowrun = 0; p.tap_stride = 0; p.flip = 0;
+        p.Ngemm = d->R * d->S * d->C;
+        p.e.M = p.M; p.e.Nstore = p.Ngemm;
+        p.e.scatter = 1; p.e.Ko = d->C; p.e.Sq = d->S; p.e.sc = d->stride;
+        p.e.YH = d->H; p.e.YW = d->W; p.e.AH = d->OH; p.e.AW = d->OW;
+    }
+    return launch_igemm(p, true, ws, ws_bytes, (hipStream_t)stream);
+}
+
+size_t acimg_conv2d_wgrad_workspace(const AcimgConvDesc* d) {
+    return wgrad_ws_bytes(d->N * d->OH * d->OW, d->R * d->S * d->C, up4(d->K), d->ldw) + colsum_ws_bytes(up4(d->K));
+}
+
+int acimg_conv2d_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
+                       float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_desc(d, "conv2d_wgrad");
+    if (rc) return rc;
+    const int kp = up4(d->K);
+    if (kp > ldgy || kp > d->ldw) return fail(ACIMG_EINVAL, "conv2d_wgrad: padded K exceeds ldgy/ldw");
+    WgradParams p{};
+    p.X = x; p.H = d->H; p.W = d->W; p.C = d->C; p.ldx = d->ldx;
+    p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.M = d->N * d->OH * d->OW; p.KK = d->R * d->S * d->C;
+    p.G = gy; p.ldg = ldgy; p.Ngemm = kp; p.Nld = kp; p.ldo = d->ldw;
+    rc = launch_wgrad(p, dw, ws, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    if (db) rc = launch_colsum(gy, (long)p.M, d->K, ldgy, db, ws, ws_bytes, (hipStream_t)stream);
+    return rc;
+}
+
+size_t acimg_deconv_workspace(const AcimgConvDesc* d) {
+    size_t a = igemm_ws_bytes(d->N * d->H * d->W, d->R * d->S * d->K, cdiv(d->C, 32));
+    size_t b = igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * d->S * cdiv(up4(d->K), 32));
+    size_t c = wgrad_ws_bytes(d->N * d->H * d->W, d->R * d->S * up4(d->K), d->C, d->ldw) + colsum_ws_bytes(up4(d->K));
+    size_t m = a > b ? a : b;
+    return m > c ? m : c;
+}
+
+int acimg_deconv_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
+                     float* y, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_desc(d, "deconv_fwd");
+    if (rc) return rc;
+    if (d->R > d->stride || d->S > d->stride || d->OH != d->H * d->stride || d->OW != d->W * d->stride)
+        return fail(ACIMG_EINVAL, "deconv_fwd: needs kernel<=stride and OH=H*stride");
+    if (d->ldw < d->C || (d->K & 3)) return fail(ACIMG_EINVAL, "deconv_fwd: ldw<C or K%%4");
+    IgemmParams p{};
+    p.A = x; p.H = d->H; p.W = d->W; p.C = d->C; p.lda = d->ldx; p.OH = d->H; p.OW = d->W;
+    p.R = 1; p.S = 1; p.stride = 1; p.M = d->N * d->H * d->W; p.rowrun = 0;
+    p.B = w; p.ldb = d->ldw; p.tap_stride = 0; p.flip = 0; p.Ngemm = d->R * d->S * d->K;
+    p.e.Y = y; p.e.ldy = d->ldy; p.e.M = p.M; p.e.Nstore = p.Ngemm; p.e.bias = bias; p.e.act = d->act;
+    p.e.scatter = 1; p.e.Ko = d->K; p.e.Sq = d->S; p.e.sc = d->stride;
+    p.e.YH = d->OH; p.e.YW = d->OW; p.e.AH = d->H; p.e.AW = d->W;
+    rc = launch_igemm(p, true, ws, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    if (d->R < d->stride || d->S < d->stride) {
+        const long pixels = (long)d->N * d->OH * d->OW;
+        hipLaunchKernelGGL(deconv_gap_fill_kernel, dim3(cdiv(pixels * (d->K / 4), 256)), dim3(256), 0,
+                           (hipStream_t)stream, y, d->ldy, bias, pixels, d->OH, d->OW, d->K, d->R, d->S, d->stride);
+        rc = check_launch("deconv_gap_fill");
+    }
+    return rc;
+}
+
+int acimg_deconv_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
+                       float* dx, const float* mask, int ldmask, void* ws, size_t ws_bytes,
+                       void* stream) {
+    int rc = check_desc(d, "deconv_dgrad");
+    if (rc) return rc;
+    const int ca = up4(d->K);
+    if (ca > ldgy || (ldgy & 3) || ca != d->K) return fail(ACIMG_EINVAL, "deconv_dgrad: K must be a multiple of 4 and <= ldgy");
+    // dx[n,h,w,c] = sum_{r,s,k} gy[n, h*stride+r, w*stride+s, k] * W[r][s][k][c]  (a strided conv)
+    IgemmParams p{};
+    p.A = gy; p.H = d->OH; p.W = d->OW; p.C = ca; p.lda = ldgy; p.OH = d->H; p.OW = d->W;
+    p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad_t = 0; p.pad_l = 0;
+    p.M = d->N * d->H * d->W;
+    p.rowrun = (d->S > 1 && ldgy == ca) ? 1 : 0;
+    p.B = w; p.ldb = d->ldw; p.Nld = d->ldw; p.Ngemm = d->C;
+    p.e.Y = dx; p.e.ldy = d->ldx; p.e.M = p.M; p.e.Nstore = d->C; p.e.mask = mask; p.e.ldmask = ldmask;
+    return launch_igemm(p, false, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int acimg_deconv_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
+                       float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_desc(d, "deconv_wgrad");
+    if (rc) return rc;
+    const int ca = up4(d->K);
+    if (ca > ldgy || (ldgy & 3) || ca != d->K) return fail(ACIMG_EINVAL, "deconv_wgrad: K must be a multiple of 4 and <= ldgy");
+    // dW[(r,s,k)][c] = sum_{n,h,w} gy[n,h*stride+r,w*stride+s,k] * x[n,h,w,c]
+    WgradParams p{};
+    p.X = gy; p.H = d->OH; p.W = d->OW; p.C = ca; p.ldx = ldgy;
+    p.OH = d->H; p.OW = d->W; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad_t = 0; p.pad_l = 0;
+    p.M = d->N * d->H * d->W; p.KK = d->R * d->S * ca;
+    p.G = x; p.ldg = d->ldx; p.Ngemm = d->C; p.Nld = d->C; p.ldo = d->ldw;
+    rc = launch_wgrad(p, dw, ws, ws_bytes, (hipStream_t)stream);
+    if (rc) return rc;
+    if (db) rc = launch_colsum(gy, (long)d->N * d->OH * d->OW, d->K, ldgy, db, ws, ws_bytes, (hipStream_t)stream);
+    return rc;
+}
+
+}  // extern "C"

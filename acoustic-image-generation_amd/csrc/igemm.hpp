@@ -1,0 +1,76 @@
+// Internal descriptors of the fp32 implicit-GEMM kernels (igemm.hip).
+#pragma once
+#include "common.hpp"
+
+namespace acimg {
+
+// Epilogue: what happens to one accumulator element acc(m, n).
+struct EpiParams {
+    float* Y;
+    int ldy;
+    int M;       // valid rows
+    int Nstore;  // valid columns
+    const float* bias;
+    const float* res;
+    int ldres;
+    const float* mask;
+    int ldmask;
+    int act;
+    // scatter mode (kernel<=stride transposed conv / patch dgrad): row m is a pixel (img,h,w) of
+    // an AH x AW grid, column n = (tap, ko); element lands at pixel (img, sc*h+r, sc*w+q), chan ko
+    int scatter;
+    int Ko, Sq, sc, YH, YW, AH, AW;
+    // per-row-block column statistics of the raw accumulator (batch-norm), [gridDim.x][2][stats_ld]
+    float* stats;
+    int stats_ld;
+};
+
+// C[m][n] = sum_k A(m,k) * B(k,n);  A gathered from an NHWC tensor (im2col on the fly).
+struct IgemmParams {
+    // A operand
+    const float* A;
+    int H, W, C, lda;
+    int OH, OW;
+    int R, S, stride, pad_t, pad_l;
+    int M;
+    int rowrun;  // 1: a K segment is a whole kernel row r (S*C contiguous floats), 0: one tap
+    int L;       // segment length in floats
+    int cps;     // BK-chunks per segment
+    int kiters;  // total K iterations = nseg * cps
+    const float* a_scale;
+    const float* a_shift;
+    int a_relu;
+    // B operand
+    const float* B;
+    int ldb;
+    long tap_stride;  // NT: distance between taps
+    int flip;         // NT: use tap (ntaps-1-tap)
+    int ntaps;
+    int Ngemm;  // number of GEMM columns
+    int Nld;    // NN: valid floats per B row (multiple of 4)
+    // split-K
+    int splits;
+    float* slab;  // [splits][M][slab_ld]
+    int slab_ld;
+    EpiParams e;
+};
+
+// dW[kk][n] = sum_m A(m,kk) * G[m][n]   (kk = (tap, c) gathered as in IgemmParams)
+struct WgradParams {
+    const float* X;
+    int H, W, C, ldx;
+    int OH, OW;
+    int R, S, stride, pad_t, pad_l;
+    int M;      // reduction length N*OH*OW
+    int KK;     // R*S*C rows of dW
+    const float* G;
+    int ldg;
+    int Ngemm;  // columns
+    int Nld;    // valid floats per G row (multiple of 4)
+    int splits;
+    int rows_per_split;  // multiple of BKR
+    float* out;          // slab [splits][KK][ldo] when splits>1 else dW
+    int ldo;
+};
+
+}  // namespace acimg

@@ -1,0 +1,226 @@
+/*
+ * acimg.h — C ABI of libacimg.so: the MI355X (gfx950) kernels behind the acoustic-image
+ * generation train step of IIT-PAVIS/Acoustic-Image-Generation.
+ *
+ * The reference has no FFI layer: every arithmetic op on its hot path is a TensorFlow-1.x op
+ * call inside models/<name>.py and trainer/mfcctrainer.py.  Each entry point
+ * below replaces one family of those op calls and cites the call site(s) it stands in for.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative ACIMG_E* code otherwise; acimg_last_error() holds text;
+ *     nothing is thrown across the boundary;
+ *   - the CALLER owns every buffer (device pointers, 16-byte aligned), including workspace;
+ *     the library allocates nothing and keeps no mutable global state;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*), no host sync;
+ *   - tensors are NHWC float32; a tensor is (ptr, C, ld): C logical channels per pixel and
+ *     ld >= C the pixel stride in floats, so producers can write straight into channel slices
+ *     of a concat buffer (tf.concat never materialises).  Channel counts seen by the GEMM
+ *     kernels are multiples of 4 (the host pads 3->4, 133->136, 145->148, 150->152, 266->268
+ *     with zeros; padded weights rows/cols are zero and provably stay zero under Adam).
+ *   - weights use TensorFlow's own layouts, padded as above:
+ *       conv2d            HWIO  [R][S][Cin_p][Cout_p]
+ *       conv2d_transpose        [R][S][Cout_p][Cin_p]
+ *       dense                   [Kin_p][Nout_p]
+ */
+#ifndef ACIMG_H_
+#define ACIMG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACIMG_VERSION 100
+
+#define ACIMG_OK 0
+#define ACIMG_EINVAL (-1)     /* bad descriptor / shape / alignment */
+#define ACIMG_EWORKSPACE (-2) /* workspace too small */
+#define ACIMG_ELAUNCH (-3)    /* hipLaunch / runtime error */
+
+#define ACIMG_ACT_NONE 0
+#define ACIMG_ACT_RELU 1
+#define ACIMG_ACT_SIGMOID 2
+
+int acimg_version(void);
+/* copies the calling thread's last error text (NUL terminated) into buf */
+int acimg_last_error(char* buf, size_t len);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution family.  One descriptor serves forward / data-gradient / weight-gradient.
+ *   x : [N,H,W,C]   (pixel stride ldx)      y : [N,OH,OW,K] (pixel stride ldy)
+ *   w : HWIO [R][S][C][ldw], ldw >= K
+ * TF 'SAME' asymmetric padding is resolved by the host into pad_t/pad_l;
+ * OH/OW are given explicitly.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct AcimgConvDesc {
+    int32_t N, H, W, C, ldx;
+    int32_t K, ldy, OH, OW;
+    int32_t R, S, stride, pad_t, pad_l;
+    int32_t ldw;
+    int32_t act; /* ACIMG_ACT_* applied by the forward epilogue */
+} AcimgConvDesc;
+
+/* Forward: y = act(conv(x', w) + bias), x' = relu(x*in_scale[c] + in_shift[c]) when in_scale
+ * is given (deferred batch-norm of the producer, zero padding applied AFTER the affine), else x.
+ * stats (optional, [grid_m][2][ldw] floats, grid_m = acimg_conv2d_stats_rows(d)) receives per
+ * row-block partial sums / sums of squares of the raw conv output for batch-norm statistics.
+ * Replaces: tf.layers.conv2d   models/unet_acresnet.py:159-168,173-182,82,89-94
+ *           slim layers.conv2d / resnet_utils.conv2d_same   models/resnet50.py:109-121,205-209 */
+int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
+                     float* y, const float* in_scale, const float* in_shift, int in_relu,
+                     float* stats, void* ws, size_t ws_bytes, void* stream);
+int acimg_conv2d_stats_rows(const AcimgConvDesc* d);
+size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d);
+
+/* Data gradient.  gy is the gradient w.r.t. the conv's PRE-activation output [N,OH,OW,K]
+ * (pixel stride ldgy); dx = relu_mask(conv_T(gy, w) + residual): `residual` (optional, pixel
+ * stride ldres) is another gradient flowing into x (fan-out), `mask` (optional, pixel stride
+ * ldmask) is the saved post-ReLU activation x itself: dx is zeroed where mask <= 0, so dx is
+ * the pre-activation gradient of the producing layer.  Supported geometries: stride 1, and
+ * stride == R == S with zero padding (non-overlapping patches, layer1/pool_2).
+ * Replaces: the Conv2DBackpropInput ops tf.gradients emits for the calls above
+ *           (trainer/mfcctrainer.py:72-79). */
+int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
+                       float* dx, const float* residual, int ldres, const float* mask, int ldmask,
+                       void* ws, size_t ws_bytes, void* stream);
+size_t acimg_conv2d_dgrad_workspace(const AcimgConvDesc* d);
+
+/* Weight + bias gradient: dw[R][S][C][ldw] = sum_pixels x (*) gy, db[k] = sum gy (db optional).
+ * Replaces: Conv2DBackpropFilter / BiasAddGrad (trainer/mfcctrainer.py:72-79). */
+int acimg_conv2d_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
+                       float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
+size_t acimg_conv2d_wgrad_workspace(const AcimgConvDesc* d);
+
+/* Transposed convolution with kernel <= stride, VALID (TF output = in*stride):
+ *   x : [N,H,W,C] low-res input, y : [N,H*stride,W*stride,K], w : [R][S][K][ldw>=C].
+ * Every input pixel writes a disjoint RxS patch; the remaining positions get the bias only.
+ * Replaces: tf.layers.conv2d_transpose  models/unet_acresnet.py:210-217 (call :86). */
+int acimg_deconv_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
+                     float* y, void* ws, size_t ws_bytes, void* stream);
+int acimg_deconv_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
+                       float* dx, const float* mask, int ldmask, void* ws, size_t ws_bytes,
+                       void* stream);
+int acimg_deconv_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
+                       float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
+size_t acimg_deconv_workspace(const AcimgConvDesc* d);
+
+/* ------------------------------------------------------------------------------------------
+ * Batch-norm pieces of the frozen ResNet-50 trunk (slim batch_norm, decay .997, eps 1e-5,
+ * batch statistics while training: models/vision.py:55-56, trainer/mfcctrainer.py:348-349).
+ * ---------------------------------------------------------------------------------------- */
+/* Reduce the per-row-block partials of acimg_conv2d_fwd into scale/shift:
+ *   mean = S1/count, var = S2/count - mean^2 (biased), scale = gamma/sqrt(var+eps),
+ *   shift = beta - mean*scale; if training: moving_mean/var <- decay*old + (1-decay)*new with the
+ *   UNBIASED variance (fused-BN semantics); save_mean/save_invstd optional.
+ * If training == 0 the moving statistics are used instead of the partials. */
+int acimg_bn_finalize(const float* stats, int rows, int C, int ldstats, double count,
+                      const float* gamma, const float* beta, float* moving_mean,
+                      float* moving_var, float decay, float eps, int training, float* scale,
+                      float* shift, float* save_mean, float* save_invstd, void* stream);
+
+/* out = relu(a*sa[c]+ta[c] + shortcut), shortcut = b*sb[c]+tb[c] (sb given) or b (identity),
+ * b read with spatial subsampling `bstride` (resnet_utils.subsample, models/resnet50.py:107).
+ * a,out: [N,OH,OW,C]; b: [N,OH*bstride.. ,C]. Replaces models/resnet50.py:123. */
+int acimg_bn_add_relu(const float* a, const float* sa, const float* ta, const float* b,
+                      const float* sb, const float* tb, float* out, int N, int OH, int OW, int C,
+                      int BH, int BW, int bstride, void* stream);
+
+/* pool1: out = maxpool3x3/s2 'SAME' over relu(x*scale+shift) (models/resnet50.py:207-208). */
+int acimg_bn_relu_maxpool(const float* x, const float* scale, const float* shift, float* out,
+                          int N, int H, int W, int C, int OH, int OW, int pad_t, int pad_l,
+                          void* stream);
+
+/* y = relu(x*scale+shift) materialised (conv_map output feature, models/resnet50.py:208-209) */
+int acimg_bn_relu(const float* x, const float* scale, const float* shift, float* y, long rows,
+                  int C, int ldx, int ldy, void* stream);
+
+/* Backward of y = relu(gamma*(x-mean)*invstd+beta) in batch-statistics mode for a small-C map
+ * (conv_map, C=12): g_x, dgamma, dbeta from g_y. x,gy,y,gx: [rows,C] dense. */
+int acimg_bn_relu_bwd(const float* x, const float* y, const float* gy, const float* gamma,
+                      const float* save_mean, const float* save_invstd, float* gx, float* dgamma,
+                      float* dbeta, long rows, int C, void* stream);
+
+/* [N,H,W,3] -> [N,H,W,4] zero padded (stem input; lets the stem use 16-byte loads) */
+int acimg_pad_channels(const float* x, float* y, long pixels, int C, int Cp, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Generator-side elementwise / reduction ops (models/unet_acresnet.py, trainer/mfcctrainer.py)
+ * ---------------------------------------------------------------------------------------- */
+/* tf.tile of the MFCC vector: out[n,h,w,c] = mfcc[n,c]   (trainer/mfcctrainer.py:38-40) */
+int acimg_tile_mfcc(const float* mfcc, float* out, int N, int HW, int C, void* stream);
+
+/* Per-sample min-max normalisation o = (x-min)/(max-min) over `cnt` = P*C logical elements of
+ * sample n (x pixel stride ldx, out pixel stride ldo, written at out+0: pass an offset pointer to
+ * write into a concat slice).  mm[n] = {min, max, #argmin, #argmax} saved for backward.
+ * Replaces models/unet_acresnet.py:55-58, :70-71. */
+int acimg_minmax_fwd(const float* x, int ldx, float* out, int ldo, float* mm, int N, int P, int C,
+                     void* stream);
+/* Gradient incl. the reduce_min / reduce_max paths with equal tie splitting (App. B.8).
+ * gx = [accumulate? gx : 0] + d/dx; then zeroed where relu_mask (=x itself) <= 0 if mask_relu. */
+int acimg_minmax_bwd(const float* x, int ldx, const float* go, int ldgo, const float* mm,
+                     float* gx, int ldgx, int N, int P, int C, int accumulate, int mask_relu,
+                     void* stream);
+
+/* heads [N,2*Z] = (mean | std_raw) -> sigma = softplus(std_raw), z = mean + sigma*eps,
+ * kl[n] = 0.5*sum(mean^2+sigma^2-log(1e-8+sigma^2)-1).  z has row stride ldz (pads untouched).
+ * Replaces models/unet_acresnet.py:73-78 and trainer/mfcctrainer.py:56-58. */
+int acimg_latent_fwd(const float* heads, const float* eps, float* z, int ldz, float* sigma,
+                     float* kl, int N, int Z, void* stream);
+/* g_heads from gz (row stride ldgz) and the KL term weighted by kl_weight (= latent_loss / N) */
+int acimg_latent_bwd(const float* heads, const float* eps, const float* sigma, const float* gz,
+                     int ldgz, float kl_weight, float* g_heads, int N, int Z, void* stream);
+
+/* Reconstruction loss on yhat = sigmoid output and its gradient w.r.t. the PRE-sigmoid logits:
+ *   sums[0] += sum (yhat-y)^2, sums[1] += sum huber_1(yhat-y)   (caller zeroes sums)
+ *   g_logit = (w_mse*2e + w_huber*clip(e,-1,1)) / count * yhat*(1-yhat)
+ * Replaces tf.losses.mean_squared_error / huber_loss, trainer/mfcctrainer.py:47,50. */
+int acimg_recon_loss(const float* yhat, const float* target, float* g_logit, float* sums,
+                     long count, float w_mse, float w_huber, void* stream);
+
+/* dst[p][c] = (accumulate ? dst : 0) + src[p][c] for c < C, zeroed where mask[p][c] <= 0 (mask
+ * optional): routes the gradient of one channel slice of a tf.concat back to its producer
+ * (models/unet_acresnet2skip.py:82, models/unet_acresnet.py:197-198). */
+int acimg_grad_slice(const float* src, int ldsrc, float* dst, int lddst, const float* mask, int ldmask,
+                     long pixels, int C, int accumulate, void* stream);
+
+/* out[5] = {mse, huber, latent, reg, total}: mse = sums[0]/count, huber = sums[1]/count,
+ * latent = latent_w * mean_n kl[n] (kl may be NULL: auto-encoder mode), reg = half_wd * sums[2],
+ * total = latent + w_mse*mse + w_huber*huber + reg   (trainer/mfcctrainer.py:46-62). */
+int acimg_loss_finalize(const float* sums, const float* kl, int N, double count, float latent_w,
+                        float half_wd, float w_mse, float w_huber, float* out, void* stream);
+
+/* stream-ordered memset to zero (loss accumulators, gradient buffers) */
+int acimg_zero(void* ptr, size_t bytes, void* stream);
+
+/* sum of squares of a flat buffer into *out (+=) — slim l2_regularizer terms
+ * (models/vision.py:54, tf.losses.get_total_loss trainer/mfcctrainer.py:60). */
+int acimg_sumsq(const float* x, long n, float* out, void* stream);
+/* y += a*x */
+int acimg_axpy(float a, const float* x, float* y, long n, void* stream);
+
+/* TF-1 Adam (tf.train.AdamOptimizer, trainer/mfcctrainer.py:72-79):
+ *   m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2; p -= lr_t * m/(sqrt(v)+eps), lr_t precomputed by host. */
+int acimg_adam_step(float* p, const float* g, float* m, float* v, long n, float lr_t, float beta1,
+                    float beta2, float eps, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Audio front end (dataloader/outdoor_data_mfcc.py:796-876): one 1024-sample int32 frame ->
+ * 12 MFCCs: Tukey(.75) window, rFFT-1024 (Nyquist dropped), power, 24 mel filters, floor 1e-3,
+ * log, DCT(12)*sqrt(2/24), lifter(22).  window[1024], melfb[512*24] (row-major [bin][filter]),
+ * dctl[24*12] (DCT*norm*lifter folded) are float64 tables built by the host exactly as the
+ * reference does; the kernel computes in fp64 like NumPy and rounds to float32 at the end (:823).
+ * normalize != 0 also applies the per-vector min-max of _normalize_mfcc (:696-703).
+ * ---------------------------------------------------------------------------------------- */
+int acimg_mfcc_frontend(const int32_t* frames, const double* window, const double* melfb,
+                        const double* dctl, float* out, int nframes, int normalize, void* stream);
+
+/* find_logen energy map (iouenergythreshold.py:294-323): mfcc image [pixels,12] -> [pixels] */
+int acimg_find_logen(const float* mfcc_img, const double* idct /*12x24*/, float* out, long pixels,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACIMG_H_ */

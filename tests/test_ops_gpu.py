@@ -1,0 +1,476 @@
+"""GPU parity of each HIP op (through the C ABI) against a plain PyTorch CPU fp64 statement of the
+same TensorFlow op.  Tolerance: the kernels compute in fp32 (exact-f32 MFMA, fp32 accumulate), so
+results must agree with the fp64 reference to 2e-5 relative to the tensor's max magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+def up4(v):
+    return (v + 3) & ~3
+
+
+def close(got, ref, tol=RTOL, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(ref.abs().max().item(), 1e-12)
+    err = (got - ref).abs().max().item() / scale
+    assert np.isfinite(err) and err <= tol, "%s: rel err %.3e > %.1e" % (what, err, tol)
+
+
+def tf_conv_ref(x, w, stride, pads, bias=None):
+    """x NHWC fp64, w HWIO; pads = (pt, pb, pl, pr)"""
+    xt = x.permute(0, 3, 1, 2)
+    xt = F.pad(xt, (pads[2], pads[3], pads[0], pads[1]))
+    y = F.conv2d(xt, w.permute(3, 2, 0, 1), bias, stride=stride)
+    return y.permute(0, 2, 3, 1)
+
+
+def same_pads(size, k, s):
+    out = -(-size // s)
+    tot = max((out - 1) * s + k - size, 0)
+    return out, tot // 2, tot - tot // 2
+
+
+def rnd(gen, *shape):
+    return torch.randn(*shape, generator=gen, dtype=torch.float64)
+
+
+def dev(t, device):
+    return t.float().contiguous().to(device)
+
+
+def pad_last(t, n):
+    if t.shape[-1] == n:
+        return t
+    out = torch.zeros(*t.shape[:-1], n, dtype=t.dtype)
+    out[..., : t.shape[-1]] = t
+    return out
+
+
+def pad_w(w, cp, kp):
+    """HWIO -> zero padded [R,S,cp,kp]"""
+    R, S, Cc, K = w.shape
+    out = torch.zeros(R, S, cp, kp, dtype=w.dtype)
+    out[:, :, :Cc, :K] = w
+    return out
+
+
+CONV_CASES = [
+    # N, H, W, C, K, R, S, stride, padding
+    (2, 9, 11, 8, 20, 3, 3, 1, "SAME"),
+    (2, 12, 16, 12, 133, 3, 3, 1, "SAME"),
+    (3, 36, 48, 16, 32, 3, 3, 3, "SAME"),
+    (2, 13, 10, 64, 32, 1, 1, 1, "SAME"),
+    (2, 30, 37, 3, 64, 7, 7, 2, 3),
+    (2, 14, 19, 64, 12, 3, 4, 1, "VALID"),
+    (4, 1, 1, 2816, 300, 1, 1, 1, "VALID"),
+    (2, 17, 23, 133, 128, 3, 3, 1, "SAME"),
+    (1, 20, 15, 32, 256, 3, 3, 2, 1),
+    (2, 8, 9, 256, 128, 3, 3, 1, "SAME"),
+]
+
+
+def _conv_geom(H, W, R, S, stride, padding):
+    if padding == "SAME":
+        OH, pt, pb = same_pads(H, R, stride)
+        OW, pl, pr = same_pads(W, S, stride)
+    elif padding == "VALID":
+        OH, OW = (H - R) // stride + 1, (W - S) // stride + 1
+        pt = pb = pl = pr = 0
+    else:
+        p = padding
+        OH, OW = (H + 2 * p - R) // stride + 1, (W + 2 * p - S) // stride + 1
+        pt = pb = pl = pr = p
+    return OH, OW, (pt, pb, pl, pr)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd(device, case):
+    from acimg import ops
+
+    N, H, W, Cc, K, R, S, stride, padding = case
+    g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)))
+    x = rnd(g, N, H, W, Cc)
+    w = rnd(g, R, S, Cc, K) * 0.1
+    b = rnd(g, K)
+    OH, OW, pads = _conv_geom(H, W, R, S, stride, padding)
+    ref = torch.relu(tf_conv_ref(x, w, stride, pads, b))
+    cp, kp = up4(Cc), up4(K)
+    xd = dev(pad_last(x, cp), device)
+    wd = dev(pad_w(w, cp, kp), device)
+    bd = dev(pad_last(b, kp), device)
+    y = torch.full((N, OH, OW, kp), 7.0, device=device)
+    d = ops.conv_desc(N, H, W, cp, K, R, S, stride, padding, act=ops.ACT_RELU)
+    assert (d.OH, d.OW) == (OH, OW)
+    plan = ops.Plan(device, eager=True)
+    ops.conv2d_fwd(plan, d, xd, wd, bd, y)
+    torch.cuda.synchronize()
+    close(y[..., :K], ref, what="conv fwd %s" % (case,))
+    if kp != K:  # pad channels untouched (store guarded by K)
+        assert (y[..., K:] == 7.0).all()
+
+
+def test_conv2d_fwd_affine_stats_slice(device):
+    """deferred BN (scale/shift/relu on load, zero padding after the affine), raw-output statistics,
+    and writing into a channel slice of a wider buffer"""
+    from acimg import ops
+
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Cc, K = 3, 21, 17, 64, 128
+    x = rnd(g, N, H, W, Cc)
+    sc = rnd(g, Cc).abs() + 0.5
+    sh = rnd(g, Cc)
+    w = rnd(g, 3, 3, Cc, K) * 0.05
+    xa = torch.relu(x * sc + sh)
+    ref = tf_conv_ref(xa, w, 1, (1, 1, 1, 1))
+    xd, wd = dev(x, device), dev(w, device)
+    ybuf = torch.zeros(N, H, W, 256, device=device)
+    d = ops.conv_desc(N, H, W, Cc, K, 3, 3, 1, "SAME", ldy=256)
+    rows = ops.conv2d_stats_rows(d)
+    stats = torch.zeros(rows, 2, K, device=device)
+    plan = ops.Plan(device, eager=True)
+    ops.conv2d_fwd(plan, d, xd, wd, None, ops.Ptr(ybuf, 128), dev(sc, device), dev(sh, device), 1, stats)
+    torch.cuda.synchronize()
+    close(ybuf[..., 128:], ref, what="affine conv")
+    assert (ybuf[..., :128] == 0).all()
+    flat = ref.reshape(-1, K)
+    close(stats[:, 0].sum(0), flat.sum(0), tol=1e-4, what="stats sum")
+    close(stats[:, 1].sum(0), (flat * flat).sum(0), tol=1e-4, what="stats sumsq")
+    # bn_finalize on those partials
+    gamma, beta = rnd(g, K).abs() + 0.5, rnd(g, K)
+    mm, mv = rnd(g, K), rnd(g, K).abs()
+    mmd, mvd = dev(mm, device), dev(mv, device)
+    scale = torch.empty(K, device=device)
+    shift = torch.empty(K, device=device)
+    smean = torch.empty(K, device=device)
+    sinv = torch.empty(K, device=device)
+    cnt = flat.shape[0]
+    ops.bn_finalize(plan, stats, rows, K, K, cnt, dev(gamma, device), dev(beta, device), mmd, mvd, scale,
+                    shift, 0.997, 1e-5, True, smean, sinv)
+    torch.cuda.synchronize()
+    mean = flat.mean(0)
+    var = flat.var(0, unbiased=False)
+    rs = gamma / torch.sqrt(var + 1e-5)
+    close(scale, rs, tol=1e-4, what="bn scale")
+    close(shift, beta - mean * rs, tol=1e-4, what="bn shift")
+    close(mmd, 0.997 * mm + 0.003 * mean, tol=1e-5, what="moving mean")
+    close(mvd, 0.997 * mv + 0.003 * flat.var(0, unbiased=True), tol=1e-5, what="moving var")
+    close(smean, mean, tol=1e-4, what="save mean")
+    # inference mode uses the moving statistics
+    ops.bn_finalize(plan, None, 0, K, K, 0, dev(gamma, device), dev(beta, device), mmd, mvd, scale, shift,
+                    0.997, 1e-5, False)
+    torch.cuda.synchronize()
+    rs2 = gamma / torch.sqrt(mvd.cpu().double() + 1e-5)
+    close(scale, rs2, tol=1e-5, what="bn scale (eval)")
+
+
+DGRAD_CASES = [
+    (2, 9, 11, 8, 20, 3, 3, 1, "SAME"),
+    (2, 12, 16, 12, 133, 3, 3, 1, "SAME"),
+    (2, 12, 16, 133, 128, 3, 3, 1, "SAME"),
+    (2, 7, 6, 64, 12, 3, 3, 1, "SAME"),
+    (3, 1, 1, 152, 2304, 1, 1, 1, "VALID"),
+    (2, 36, 48, 16, 32, 3, 3, 3, "SAME"),
+    (2, 18, 24, 256, 128, 3, 3, 1, "SAME"),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_conv2d_dgrad_wgrad(device, case):
+    from acimg import ops
+
+    N, H, W, Cc, K, R, S, stride, padding = case
+    g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)) + 1)
+    x = rnd(g, N, H, W, Cc).requires_grad_(True)
+    w = (rnd(g, R, S, Cc, K) * 0.1).requires_grad_(True)
+    b = rnd(g, K).requires_grad_(True)
+    OH, OW, pads = _conv_geom(H, W, R, S, stride, padding)
+    y = tf_conv_ref(x, w, stride, pads, b)
+    gy = rnd(g, N, OH, OW, K)
+    y.backward(gy)
+    res = rnd(g, N, H, W, Cc)
+    maskt = rnd(g, N, H, W, Cc)
+    ref_dx = (x.grad + res) * (maskt > 0)
+    cp, kp = up4(Cc), up4(K)
+    d = ops.conv_desc(N, H, W, cp, K, R, S, stride, padding)
+    wd = dev(pad_w(w.detach(), cp, kp), device)
+    gyd = dev(pad_last(gy, kp), device)
+    dx = torch.full((N, H, W, cp), 3.0, device=device)
+    plan = ops.Plan(device, eager=True)
+    ops.conv2d_dgrad(plan, d, gyd, kp, wd, dx, dev(pad_last(res, cp), device), cp,
+                     dev(pad_last(maskt, cp), device), cp)
+    torch.cuda.synchronize()
+    close(dx[..., :Cc], ref_dx, what="dgrad %s" % (case,))
+    # weight / bias gradient
+    dw = torch.full((R, S, cp, kp), 9.0, device=device)
+    db = torch.zeros(kp, device=device)
+    ops.conv2d_wgrad(plan, d, dev(pad_last(x.detach(), cp), device), gyd, kp, dw, db)
+    torch.cuda.synchronize()
+    close(dw[:, :, :Cc, :K], w.grad, what="wgrad %s" % (case,))
+    close(db[:K], b.grad, what="bgrad %s" % (case,))
+    if cp != Cc:
+        assert (dw[:, :, Cc:, :] == 0).all()
+    if kp != K:
+        assert (dw[:, :, :, K:] == 0).all()
+
+
+def test_dgrad_slice_input(device):
+    """gy given as a channel slice of a wider gradient buffer (tf.concat backward)"""
+    from acimg import ops
+
+    g = torch.Generator().manual_seed(11)
+    N, H, W, Cc, K = 2, 10, 12, 32, 128
+    x = rnd(g, N, H, W, Cc).requires_grad_(True)
+    w = (rnd(g, 3, 3, Cc, K) * 0.1).requires_grad_(True)
+    y = tf_conv_ref(x, w, 1, (1, 1, 1, 1))
+    gywide = rnd(g, N, H, W, 256)
+    y.backward(gywide[..., 128:])
+    d = ops.conv_desc(N, H, W, Cc, K, 3, 3, 1, "SAME")
+    gyd = dev(gywide, device)
+    dx = torch.empty(N, H, W, Cc, device=device)
+    plan = ops.Plan(device, eager=True)
+    ops.conv2d_dgrad(plan, d, ops.Ptr(gyd, 128), 256, dev(w.detach(), device), dx)
+    dw = torch.empty(3, 3, Cc, K, device=device)
+    ops.conv2d_wgrad(plan, d, dev(x.detach(), device), ops.Ptr(gyd, 128), 256, dw, None)
+    torch.cuda.synchronize()
+    close(dx, x.grad, what="dgrad slice")
+    close(dw, w.grad, what="wgrad slice")
+
+
+@pytest.mark.parametrize("case", [(2, 12, 16, 128, 128, 2, 3), (3, 5, 4, 32, 64, 2, 2), (2, 6, 7, 64, 32, 3, 3)])
+def test_deconv(device, case):
+    from acimg import ops
+
+    N, H, W, Cc, K, R, s = case
+    g = torch.Generator().manual_seed(77)
+    x = rnd(g, N, H, W, Cc).requires_grad_(True)
+    w = (rnd(g, R, R, K, Cc) * 0.1).requires_grad_(True)  # TF layout [kh, kw, out, in]
+    b = rnd(g, K).requires_grad_(True)
+    y = F.conv_transpose2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, stride=s,
+                           output_padding=s - R).permute(0, 2, 3, 1)
+    assert y.shape[1] == H * s and y.shape[2] == W * s
+    gy = rnd(g, *y.shape)
+    y.backward(gy)
+    d = ops.deconv_desc(N, H, W, Cc, K, R, R, s, ldy=2 * K)
+    ybuf = torch.zeros(N, H * s, W * s, 2 * K, device=device)
+    plan = ops.Plan(device, eager=True)
+    wd = dev(w.detach(), device)
+    ops.deconv_fwd(plan, d, dev(x.detach(), device), wd, dev(b.detach(), device), ybuf)
+    torch.cuda.synchronize()
+    close(ybuf[..., :K], y, what="deconv fwd")
+    assert (ybuf[..., K:] == 0).all()
+    gywide = torch.zeros(N, H * s, W * s, 2 * K, dtype=torch.float64)
+    gywide[..., :K] = gy
+    gyd = dev(gywide, device)
+    maskt = rnd(g, N, H, W, Cc)
+    dx = torch.empty(N, H, W, Cc, device=device)
+    ops.deconv_dgrad(plan, d, gyd, 2 * K, wd, dx, dev(maskt, device), Cc)
+    dw = torch.empty(R, R, K, Cc, device=device)
+    db = torch.empty(K, device=device)
+    ops.deconv_wgrad(plan, d, dev(x.detach(), device), gyd, 2 * K, dw, db)
+    torch.cuda.synchronize()
+    close(dx, x.grad * (maskt > 0), what="deconv dgrad")
+    close(dw, w.grad, what="deconv wgrad")
+    close(db, b.grad, what="deconv bgrad")
+
+
+def test_trunk_elementwise(device):
+    from acimg import ops
+
+    g = torch.Generator().manual_seed(3)
+    plan = ops.Plan(device, eager=True)
+    # bn_add_relu with identity / subsampled / projected shortcut
+    N, OH, OW, Cc = 2, 7, 9, 64
+    a, sa, ta = rnd(g, N, OH, OW, Cc), rnd(g, Cc), rnd(g, Cc)
+    b1 = rnd(g, N, OH, OW, Cc)
+    out = torch.empty(N, OH, OW, Cc, device=device)
+    ops.bn_add_relu(plan, dev(a, device), dev(sa, device), dev(ta, device), dev(b1, device), None, None, out,
+                    N, OH, OW, Cc, OH, OW, 1)
+    close(out, torch.relu(a * sa + ta + b1), what="bn_add_relu id")
+    b2 = rnd(g, N, 2 * OH - 1, 2 * OW, Cc)
+    ops.bn_add_relu(plan, dev(a, device), dev(sa, device), dev(ta, device), dev(b2, device), None, None, out,
+                    N, OH, OW, Cc, 2 * OH - 1, 2 * OW, 2)
+    close(out, torch.relu(a * sa + ta + b2[:, ::2, ::2]), what="bn_add_relu subsample")
+    sb, tb = rnd(g, Cc), rnd(g, Cc)
+    ops.bn_add_relu(plan, dev(a, device), dev(sa, device), dev(ta, device), dev(b1, device), dev(sb, device),
+                    dev(tb, device), out, N, OH, OW, Cc, OH, OW, 1)
+    close(out, torch.relu(a * sa + ta + b1 * sb + tb), what="bn_add_relu proj")
+    # pool1: 3x3 s2 SAME on relu(bn(x)), odd sizes (H: pad 0/1, W: pad 1/1)
+    N, H, W, Cc = 2, 112, 149, 8
+    x, sc, sh = rnd(g, N, H, W, Cc), rnd(g, Cc), rnd(g, Cc)
+    OH, pt, pb = same_pads(H, 3, 2)
+    OW, pl, pr = same_pads(W, 3, 2)
+    xa = torch.relu(x * sc + sh).permute(0, 3, 1, 2)
+    ref = F.max_pool2d(F.pad(xa, (pl, pr, pt, pb), value=-1e30), 3, 2).permute(0, 2, 3, 1)
+    out = torch.empty(N, OH, OW, Cc, device=device)
+    ops.bn_relu_maxpool(plan, dev(x, device), dev(sc, device), dev(sh, device), out, N, H, W, Cc, OH, OW, pt, pl)
+    close(out, ref, what="maxpool")
+    # pad channels
+    x3 = rnd(g, 5, 3)
+    y4 = torch.empty(5, 4, device=device)
+    ops.pad_channels(plan, dev(x3, device), y4, 5, 3, 4)
+    close(y4[:, :3], x3, what="pad")
+    assert (y4[:, 3] == 0).all()
+    # bn_relu + its backward in batch-statistics mode
+    rows, Cc = 384, 12
+    x = rnd(g, rows, Cc).requires_grad_(True)
+    gamma = (rnd(g, Cc).abs() + 0.5).requires_grad_(True)
+    beta = rnd(g, Cc).requires_grad_(True)
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    y = torch.relu((x - mean) * invstd * gamma + beta)
+    gy = rnd(g, rows, Cc)
+    y.backward(gy)
+    scale = (gamma * invstd).detach()
+    shift = (beta - mean * gamma * invstd).detach()
+    yd = torch.empty(rows, Cc, device=device)
+    ops.bn_relu(plan, dev(x.detach(), device), dev(scale, device), dev(shift, device), yd, rows, Cc, Cc, Cc)
+    close(yd, y, what="bn_relu")
+    gx = torch.empty(rows, Cc, device=device)
+    dg = torch.empty(Cc, device=device)
+    dbt = torch.empty(Cc, device=device)
+    ops.bn_relu_bwd(plan, dev(x.detach(), device), yd, dev(gy, device), dev(gamma.detach(), device),
+                    dev(mean.detach(), device), dev(invstd.detach(), device), gx, dg, dbt, rows, Cc)
+    torch.cuda.synchronize()
+    close(gx, x.grad, tol=1e-4, what="bn bwd gx")
+    close(dg, gamma.grad, tol=1e-4, what="bn bwd dgamma")
+    close(dbt, beta.grad, tol=1e-4, what="bn bwd dbeta")
+
+
+def test_generator_elementwise(device):
+    from acimg import ops
+
+    g = torch.Generator().manual_seed(4)
+    plan = ops.Plan(device, eager=True)
+    # tile
+    N = 3
+    mf = rnd(g, N, 12)
+    out = torch.empty(N, 36, 48, 12, device=device)
+    ops.tile_mfcc(plan, dev(mf, device), out, N, 36 * 48, 12)
+    close(out, mf.view(N, 1, 1, 12).expand(N, 36, 48, 12), tol=0, what="tile")
+    # min-max with ties at the minimum (post-ReLU zeros) written into a concat slice
+    P, Cc, ld, ldo = 12 * 16, 133, 136, 148
+    x = torch.relu(rnd(g, N, P, Cc)).requires_grad_(True)
+    mn = x.amin(dim=(1, 2), keepdim=True)
+    a = x - mn
+    o = a / a.amax(dim=(1, 2), keepdim=True)
+    go = rnd(g, N, P, Cc)
+    o.backward(go)
+    xd = dev(pad_last(x.detach(), ld), device)
+    cat = torch.zeros(N, P, ldo, device=device)
+    mm = torch.empty(N, 4, device=device)
+    ops.minmax_fwd(plan, xd, ld, cat, ldo, mm, N, P, Cc)
+    close(cat[..., :Cc], o, what="minmax fwd")
+    assert (cat[..., Cc:] == 0).all()
+    gow = torch.zeros(N, P, ldo, dtype=torch.float64)
+    gow[..., :Cc] = go
+    gx = torch.zeros(N, P, ld, device=device)
+    ops.minmax_bwd(plan, xd, ld, dev(gow, device), ldo, mm, gx, ld, N, P, Cc, False, True)
+    torch.cuda.synchronize()
+    close(gx[..., :Cc], x.grad * (x.detach() > 0), tol=1e-4, what="minmax bwd (relu masked)")
+    # no mask + accumulate, strictly positive input (single min, single max)
+    x2 = (rnd(g, N, 7, 12).abs() + 0.1).requires_grad_(True)
+    a2 = x2 - x2.amin(dim=(1, 2), keepdim=True)
+    o2 = a2 / a2.amax(dim=(1, 2), keepdim=True)
+    go2 = rnd(g, N, 7, 12)
+    o2.backward(go2)
+    base = rnd(g, N, 7, 12)
+    o2d = torch.empty(N, 7, 12, device=device)
+    ops.minmax_fwd(plan, dev(x2.detach(), device), 12, o2d, 12, mm, N, 7, 12)
+    gx2 = dev(base, device)
+    ops.minmax_bwd(plan, dev(x2.detach(), device), 12, dev(go2, device), 12, mm, gx2, 12, N, 7, 12, True, False)
+    torch.cuda.synchronize()
+    close(o2d, o2, what="minmax fwd 2")
+    close(gx2, x2.grad + base, tol=1e-4, what="minmax bwd accumulate")
+    # latent
+    Z = 150
+    heads = rnd(g, N, 2 * Z).requires_grad_(True)
+    eps = rnd(g, N, Z)
+    mu, sg = heads[:, :Z], F.softplus(heads[:, Z:])
+    z = mu + sg * eps
+    kl = 0.5 * (mu ** 2 + sg ** 2 - torch.log(1e-8 + sg ** 2) - 1).sum(1)
+    gz = rnd(g, N, Z)
+    klw = 1e-3
+    ((z * gz).sum() + klw * kl.sum()).backward()
+    hd, ed = dev(heads.detach(), device), dev(eps, device)
+    zd = torch.zeros(N, 152, device=device)
+    sd = torch.empty(N, Z, device=device)
+    kld = torch.empty(N, device=device)
+    ops.latent_fwd(plan, hd, ed, zd, 152, sd, kld, N, Z)
+    close(zd[:, :Z], z, what="z")
+    close(kld, kl, what="kl")
+    gh = torch.empty(N, 2 * Z, device=device)
+    ops.latent_bwd(plan, hd, ed, sd, dev(pad_last(gz, 152), device), 152, klw, gh, N, Z)
+    torch.cuda.synchronize()
+    close(gh, heads.grad, what="latent bwd")
+    # reconstruction loss
+    cnt = N * 36 * 48 * 12
+    logit = rnd(g, cnt).requires_grad_(True)
+    tgt = torch.rand(cnt, generator=g, dtype=torch.float64) * 4 - 1.5  # exercises |e| > 1
+    yh = torch.sigmoid(logit)
+    e = yh - tgt
+    q = e.abs().clamp(max=1.0)
+    mse, hub = (e * e).mean(), (0.5 * q * q + (e.abs() - q)).mean()
+    (mse + hub).backward()
+    sums = torch.zeros(4, device=device)
+    gl = torch.empty(cnt, device=device)
+    ops.recon_loss(plan, dev(yh.detach(), device), dev(tgt, device), gl, sums, cnt, 1.0, 1.0)
+    outv = torch.empty(5, device=device)
+    ops.sumsq(plan, dev(tgt, device), cnt, ops.Ptr(sums, 2))
+    ops.loss_finalize(plan, sums, kld, N, cnt, 1e-6, 2.5e-4, 1.0, 1.0, outv)
+    torch.cuda.synchronize()
+    close(gl, logit.grad, what="recon grad")
+    reg = 2.5e-4 * (tgt * tgt).sum()
+    lat = 1e-6 * kl.detach().mean()
+    close(outv, torch.stack([mse.detach(), hub.detach(), lat, reg, lat + mse.detach() + hub.detach() + reg]),
+          what="loss scalars")
+    # grad_slice
+    src = rnd(g, 20, 24)
+    dst0 = rnd(g, 20, 8)
+    msk = rnd(g, 20, 8)
+    dstd = dev(dst0, device)
+    ops.grad_slice(plan, ops.Ptr(dev(src, device), 5), 24, dstd, 8, dev(msk, device), 8, 20, 7, True)
+    torch.cuda.synchronize()
+    ref = dst0.clone()
+    ref[:, :7] = (src[:, 5:12] + dst0[:, :7]) * (msk[:, :7] > 0)
+    close(dstd, ref, what="grad_slice")
+    # adam (TF-1 form) + axpy + zero
+    n = 1003
+    p, gr, m, v = rnd(g, n), rnd(g, n), rnd(g, n) * 0.1, rnd(g, n).abs() * 0.01
+    lr_t = ops.adam_lr_t(1e-3, 3)
+    m2 = 0.9 * m + 0.1 * gr
+    v2 = 0.999 * v + 0.001 * gr * gr
+    p2 = p - lr_t * m2 / (torch.sqrt(v2) + 1e-8)
+    pd, md, vd = dev(p, device), dev(m, device), dev(v, device)
+    ops.adam_step(plan, pd, dev(gr, device), md, vd, n, lr_t)
+    torch.cuda.synchronize()
+    close(pd, p2, what="adam p")
+    close(md, m2, what="adam m")
+    close(vd, v2, what="adam v")
+    yv = dev(p, device)
+    ops.axpy(plan, 0.5, dev(gr, device), yv, n)
+    close(yv, p + 0.5 * gr, what="axpy")
+    ops.zero(plan, yv)
+    torch.cuda.synchronize()
+    assert (yv == 0).all()
+
+
+def test_error_reporting(device):
+    """bad descriptors come back as error codes with text, never as a crash"""
+    from acimg import _lib, ops
+
+    d = ops.conv_desc(1, 4, 4, 6, 8, 3, 3)  # C not a multiple of 4
+    x = torch.zeros(1, 4, 4, 6, device=device)
+    w = torch.zeros(3, 3, 6, 8, device=device)
+    y = torch.zeros(1, 4, 4, 8, device=device)
+    with pytest.raises(_lib.AcimgError) as ei:
+        ops.conv2d_fwd(ops.Plan(device, eager=True), d, x, w, None, y)
+    assert "multiples of 4" in str(ei.value)
