@@ -1,0 +1,153 @@
+"""CPU tests of the oracle: pinned against the reference's own NumPy outputs (tests/golden/, made by
+tests/golden/make_frontend_golden.py) and the known answers recorded in SURVEY.md App. D; plus
+checks of each TensorFlow semantic the network restatement relies on."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend, resnet50, tfsem, trainer, unet_acresnet
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "frontend_golden.npz"))
+
+
+def test_mfcc_matches_reference_golden():
+    got = frontend.mfcc(GOLD["frames"])
+    assert got.dtype == np.float32 and got.shape == (14, 12)
+    np.testing.assert_allclose(got, GOLD["mfcc"], rtol=1e-6, atol=1e-6)
+
+
+def test_mfcc_known_answers_survey_appendix_d():
+    got = frontend.mfcc(GOLD["frames"][:12])
+    row0 = [-9.510008, -1.000083, -3.269133, 3.592514, 0.124461, -3.20517, -0.679309, 2.78446, -4.455116,
+            -3.4477, 0.066911, -5.548341]
+    np.testing.assert_allclose(got[0], row0, rtol=0, atol=2e-5)
+    assert abs(float(got.sum()) - (-262.86496)) < 1e-3
+    assert abs(float(np.abs(got).max()) - 9.510008) < 1e-5
+
+
+def test_mel_filters_match_reference():
+    f = frontend.createfilters()
+    np.testing.assert_array_equal(f, GOLD["filters"])
+    colsum = [5.5, 6, 7, 7.5, 8, 9.5, 10, 10.5, 12, 13.5, 14.5, 15.5, 17, 19, 21, 23, 25, 27.5, 30, 33, 36.5, 40,
+              43.5, 48]
+    np.testing.assert_allclose(f.sum(0), colsum, atol=1e-9)
+
+
+def test_lowpass_and_silence_mfcc_match_reference():
+    lp = frontend.butter_lowpass_filter(GOLD["frames"][:12].astype(np.float64))
+    np.testing.assert_allclose(lp, GOLD["lowpassed"], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(frontend.mfcc(GOLD["lowpassed"]), GOLD["mfcc_lowpassed"], rtol=1e-6, atol=1e-6)
+
+
+def test_find_logen_matches_reference():
+    np.testing.assert_allclose(frontend.find_logen(GOLD["img64"]).reshape(36, 48), GOLD["logen64"], rtol=1e-12)
+    np.testing.assert_allclose(frontend.find_logen(GOLD["img32"]).reshape(36, 48), GOLD["logen32"], rtol=1e-6)
+
+
+def test_normalize_mfcc_range():
+    v = frontend.normalize_mfcc(GOLD["mfcc"])
+    assert v.dtype == np.float32
+    np.testing.assert_array_equal(v.min(1), 0)
+    np.testing.assert_array_equal(v.max(1), 1)
+
+
+# ---- TF semantics ----------------------------------------------------------------------------------
+def test_same_padding_is_asymmetric_with_stride():
+    assert tfsem.same_pads(224, 3, 2) == (112, 0, 1)
+    assert tfsem.same_pads(298, 3, 2) == (149, 0, 1)
+    assert tfsem.same_pads(36, 3, 3) == (12, 0, 0)
+    assert tfsem.same_pads(112, 3, 2) == (56, 0, 1)   # pool1 rows
+    assert tfsem.same_pads(149, 3, 2) == (75, 1, 1)   # pool1 cols
+    x = torch.arange(25.0).reshape(1, 5, 5, 1)
+    w = torch.ones(3, 3, 1, 1)
+    y = tfsem.conv2d(x, w, None, 2, "SAME")
+    assert y.shape == (1, 3, 3, 1)
+    assert float(y[0, 0, 0, 0]) == 0 + 1 + 5 + 6  # pad 1 before
+
+
+def test_conv2d_transpose_valid_size_and_bias_only_gaps():
+    x = torch.ones(1, 12, 16, 4)
+    w = torch.ones(2, 2, 3, 4)
+    b = torch.tensor([0.5, 1.5, 2.5])
+    y = tfsem.conv2d_transpose_valid(x, w, b, 3)
+    assert y.shape == (1, 36, 48, 3)
+    np.testing.assert_allclose(y[0, 0, 0].numpy(), [4.5, 5.5, 6.5])
+    np.testing.assert_allclose(y[0, 2, 0].numpy(), [0.5, 1.5, 2.5])   # row 2 of each cell: bias only
+    np.testing.assert_allclose(y[0, 35, 47].numpy(), [0.5, 1.5, 2.5])
+
+
+def test_batch_norm_moving_variance_is_unbiased():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4, 3, 3, 2, generator=g, dtype=torch.float64)
+    y, mm, mv, mean, var = tfsem.batch_norm(x, torch.ones(2, dtype=torch.float64), torch.zeros(2, dtype=torch.float64),
+                                            torch.zeros(2, dtype=torch.float64), torch.ones(2, dtype=torch.float64), True)
+    flat = x.reshape(-1, 2)
+    np.testing.assert_allclose(mv.numpy(), 0.997 + 0.003 * flat.var(0, unbiased=True).numpy(), rtol=1e-12)
+    np.testing.assert_allclose(y.reshape(-1, 2).var(0, unbiased=False).numpy(), 1.0, rtol=1e-4)
+
+
+def test_adam_is_tf1_form():
+    p, g = torch.tensor([1.0]), torch.tensor([0.5])
+    p2, m, v = tfsem.adam_tf1(p, g, torch.zeros(1), torch.zeros(1), 1, 0.1)
+    lr_t = 0.1 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    exp = 1.0 - lr_t * 0.05 / (np.sqrt(0.00025) + 1e-8)
+    assert abs(float(p2) - exp) < 1e-6
+
+
+def test_minmax_gradient_splits_ties():
+    x = torch.tensor([[0.0, 0.0, 1.0, 2.0, 2.0]], dtype=torch.float64, requires_grad=True)
+    o = tfsem.minmax_norm(x, (1,))
+    o.backward(torch.tensor([[1.0, 2.0, 3.0, 4.0, 5.0]], dtype=torch.float64))
+    s1, s2, D = 15.0, (3 * 0.5 + 4 + 5), 2.0
+    gmin, gmax = -(s1 - s2) / D / 2, -s2 / D / 2
+    exp = np.array([1 / D + gmin, 2 / D + gmin, 3 / D, 4 / D + gmax, 5 / D + gmax])
+    np.testing.assert_allclose(x.grad.numpy()[0], exp, rtol=1e-12)
+
+
+def test_losses_reductions():
+    y = torch.tensor([[0.0, 0.5], [2.0, -3.0]])
+    t = torch.zeros(2, 2)
+    assert abs(float(tfsem.mse_loss(t, y)) - (0.25 + 4 + 9) / 4) < 1e-7
+    hub = (0.5 * 0.25 + (2 - 0.5) + (3 - 0.5)) / 4
+    assert abs(float(tfsem.huber_loss(t, y)) - hub) < 1e-7
+
+
+# ---- network restatement ---------------------------------------------------------------------------
+def test_parameter_inventory():
+    n_gen = sum(int(np.prod(s)) for s in unet_acresnet.param_shapes(1).values())
+    assert n_gen == 10558532                      # 10.56 M
+    heads = 2 * (12 * 16 * 145 * 150 + 150)
+    assert heads == 8352300                       # 8.35 M in the mean/std heads
+    shapes = resnet50.param_shapes()
+    assert len([k for k in shapes if k.endswith("/weights")]) == 54   # 53 trunk convs + conv_map
+    assert shapes["resnet_v1_50/conv_map/weights"] == (3, 4, 2048, 12)
+    assert resnet50.train_var_names()[0] == "resnet_v1_50/conv_map/weights"
+    assert "UNetAcRes/layer4/conv_1/kernel" in unet_acresnet.param_shapes(2)
+    assert unet_acresnet.param_shapes(2)["UNetAcRes/layer4/conv_1/kernel"] == (3, 3, 266, 128)
+    assert unet_acresnet.param_shapes(0)["UNetAcRes/layer6/conv_1/kernel"] == (3, 3, 128, 128)
+
+
+@pytest.mark.parametrize("num_skip,embedding", [(1, False), (2, False), (0, True)])
+def test_oracle_step_shapes_and_learning(num_skip, embedding):
+    o = trainer.Oracle(num_skip=num_skip, embedding=embedding, randomize=True, learning_rate=1e-3)
+    ac, mf, vid, eps = trainer.synthetic_batch(2)
+    ep = {}
+    r0 = o.train_step(ac, mf, vid, eps, end_points=ep, keep_grads=True)
+    assert r0["output"].shape == (2, 36, 48, 12)
+    assert ep["resnet_v1_50/conv1"].shape == (2, 112, 149, 64) and ep["resnet_v1_50/pool1"].shape == (2, 56, 75, 64)
+    assert ep["resnet_v1_50/block1/unit_3/bottleneck_v1"].shape == (2, 56, 75, 256)
+    assert ep["resnet_v1_50/block2/unit_4/bottleneck_v1"].shape == (2, 28, 38, 512)
+    assert ep["resnet_v1_50/block3/unit_6/bottleneck_v1"].shape == (2, 14, 19, 1024)
+    assert ep["resnet_v1_50/block4/unit_3/bottleneck_v1"].shape == (2, 14, 19, 2048)
+    assert ep["resnet_v1_50/conv_map"].shape == (2, 12, 16, 12)
+    assert ep["features"].shape == (2, 12, 16, 145)
+    assert all(torch.isfinite(g).all() for g in r0["grads"].values())
+    assert float(r0["grads"]["resnet_v1_50/conv_map/weights"].abs().max()) > 0
+    assert (r0["latent"] == 0) == embedding
+    for _ in range(3):
+        r = o.train_step(ac, mf, vid, eps)
+    assert r["mse"] < r0["mse"]
+    e = o.eval_step(ac, mf, vid, eps)
+    assert abs(np.mean([e["mse%d" % i] for i in range(4)]) - e["mse"]) < 1e-6
