@@ -38,7 +38,7 @@ PROTOTYPES = {
     "acimg_conv2d_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _P, _I, _P, _P, _SZ, _P]),
     "acimg_conv2d_stats_rows": (_I, [_DP]),
     "acimg_conv2d_fwd_workspace": (_SZ, [_DP]),
-    "acimg_conv2d_dgrad": (_I, [_DP, _P, _I, _P, _P, _P, _I, _P, _I, _P, _SZ, _P]),
+    "acimg_conv2d_dgrad": (_I, [_DP, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _SZ, _P]),
     "acimg_conv2d_dgrad_workspace": (_SZ, [_DP]),
     "acimg_conv2d_wgrad": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),
     "acimg_conv2d_wgrad_workspace": (_SZ, [_DP]),
@@ -60,6 +60,8 @@ PROTOTYPES = {
     "acimg_recon_loss": (_I, [_P, _P, _P, _P, _L, _F, _F, _P]),
     "acimg_grad_slice": (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _I, _P]),
     "acimg_loss_finalize": (_I, [_P, _P, _I, _D, _F, _F, _F, _F, _P, _P]),
+    "acimg_randn": (_I, [_P, _L, C.c_uint64, C.c_uint64, _P]),
+    "acimg_sqerr_channels": (_I, [_P, _P, _L, _I, _P, _P]),
     "acimg_zero": (_I, [_P, _SZ, _P]),
     "acimg_sumsq": (_I, [_P, _L, _P, _P]),
     "acimg_axpy": (_I, [_F, _P, _P, _L, _P]),

@@ -31,6 +31,19 @@ class Ptr(object):
         return self.t.data_ptr() + 4 * self.off
 
 
+class LazyPtr(object):
+    """Device address known only once the session's flat buffers exist (resolved at Plan.finalize)."""
+
+    __slots__ = ("fn", "off")
+
+    def __init__(self, fn, off=0):
+        self.fn = fn
+        self.off = int(off)
+
+    def addr(self):
+        return self.fn().data_ptr() + 4 * self.off
+
+
 class Workspace(object):
     """Caller-owned scratch shared by all calls of a plan (the library allocates nothing)."""
 
@@ -38,6 +51,7 @@ class Workspace(object):
         self.device = device
         self.need = 256
         self.buf = None
+        self.version = 0
 
     def require(self, nbytes):
         self.need = max(self.need, int(nbytes))
@@ -45,6 +59,7 @@ class Workspace(object):
     def allocate(self):
         if self.buf is None or self.buf.numel() < self.need:
             self.buf = torch.empty(self.need, dtype=torch.uint8, device=self.device)
+            self.version += 1   # plans resolved against the old buffer must re-resolve
         return self
 
     @property
@@ -71,7 +86,7 @@ def _resolve(a):
         return None
     if isinstance(a, torch.Tensor):
         return a.data_ptr()
-    if isinstance(a, Ptr):
+    if isinstance(a, (Ptr, LazyPtr)):
         return a.addr()
     if isinstance(a, _WsPtr):
         return a.ws.ptr
@@ -91,8 +106,17 @@ class Plan(object):
         self.device = device
         self.eager = eager
         self.ws = ws if ws is not None else Workspace(device)
-        self.calls = []      # (name, fn, raw args, keepalive)
+        self.calls = []      # (name, fn, raw args); args None => host hook
         self._resolved = None
+        self._ws_version = -1
+
+    def add_hook(self, pyfn):
+        """a host callback run in order between kernel launches (e.g. fire a gradient all-reduce)"""
+        if self.eager:
+            pyfn()
+        else:
+            self.calls.append(("hook", pyfn, None))
+            self._resolved = None
 
     def add(self, name, fn, *args):
         if self.eager:
@@ -109,14 +133,19 @@ class Plan(object):
 
     def finalize(self):
         self.ws.allocate()
-        self._resolved = [(name, fn, tuple(_resolve(a) for a in args)) for name, fn, args in self.calls]
+        self._ws_version = self.ws.version
+        self._resolved = [(name, fn, None if args is None else tuple(_resolve(a) for a in args))
+                          for name, fn, args in self.calls]
         return self
 
     def run(self, stream=None):
-        if self._resolved is None:
+        if self._resolved is None or self._ws_version != self.ws.version:
             self.finalize()
         st = stream if stream is not None else current_stream_handle(self.device)
         for name, fn, args in self._resolved:
+            if args is None:
+                fn()
+                continue
             rc = fn(*args, st)
             if rc:
                 _lib.check(rc, name)
@@ -188,10 +217,10 @@ def conv2d_fwd(plan, d, x, w, bias, y, in_scale=None, in_shift=None, in_relu=0, 
              int(in_relu), stats, _WsPtr(plan.ws), _WsBytes(plan.ws))
 
 
-def conv2d_dgrad(plan, d, gy, ldgy, w, dx, residual=None, ldres=0, mask=None, ldmask=0):
+def conv2d_dgrad(plan, d, gy, ldgy, w, dx, residual=None, ldres=0, mask=None, ldmask=0, lddx=0):
     L = _L()
     plan.ws.require(L.acimg_conv2d_dgrad_workspace(C.byref(d)))
-    plan.add("conv2d_dgrad", L.acimg_conv2d_dgrad, C.byref(d), gy, int(ldgy), w, dx, residual,
+    plan.add("conv2d_dgrad", L.acimg_conv2d_dgrad, C.byref(d), gy, int(ldgy), w, dx, int(lddx), residual,
              int(ldres), mask, int(ldmask), _WsPtr(plan.ws), _WsBytes(plan.ws))
 
 
@@ -293,6 +322,14 @@ def loss_finalize(plan, sums, kl, N, count, latent_w, half_wd, w_mse, w_huber, o
 def zero(plan, t, nbytes=None):
     n = nbytes if nbytes is not None else t.numel() * t.element_size()
     plan.add("zero", _L().acimg_zero, t, int(n))
+
+
+def randn(plan, out, n, seed, offset=0):
+    plan.add("randn", _L().acimg_randn, out, int(n), int(seed), int(offset))
+
+
+def sqerr_channels(plan, a, b, pixels, Cn, out):
+    plan.add("sqerr_channels", _L().acimg_sqerr_channels, a, b, int(pixels), int(Cn), out)
 
 
 def sumsq(plan, x, n, out):

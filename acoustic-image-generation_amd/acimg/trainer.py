@@ -1,0 +1,352 @@
+"""`Trainer`: the acoustic-image train / eval loop, MI355X-native (`TrainerMask` of the reference).
+
+Mirrors trainer/mfcctrainer.py: ctor (:16-26), `_build_functions` (:28-82: tile the MFCC vector,
+build image encoder + generator, MSE + Huber + latent_loss*mean(KL) + slim regularisers, Adam on
+UNetAcRes/* + resnet_v1_50/conv_map/* with the BN moving-average updates), `train` (:249-398 epoch
+loop, validation, best / every-10-epochs checkpoints, model.txt), `_evaluate` (:411-442),
+`_retrieve_batch` (:444-467), `test` (:476-536 with the four per-3-channel MSEs), `_save_checkpoint`,
+`_restore_model`, `_init_model`.  The body of the hot loop (:343-349, one session.run of
+[lossmse, loss, summary_op, train_op]) is `train_step`.
+
+One step = ONE recorded plan of C-ABI kernel launches on fixed device buffers:
+  zero loss sums -> tile -> trunk forward (BN batch statistics, moving averages advance) ->
+  generator forward -> reconstruction loss (+ its gradient) -> L2 regulariser -> loss scalars ->
+  generator backward -> conv_map backward -> [bucketed RCCL all-reduce, overlapped] -> Adam (1 launch).
+The eight TensorBoard image summaries the reference evaluates every step (:278-297,343-344) are not
+part of the step; scalars are returned as a dict.
+"""
+import os
+from collections import OrderedDict
+from datetime import datetime
+
+import torch
+
+from . import _lib, dp, ops
+from .flags import FLAGS
+from .session import Session
+from .unet_acresnet import Z
+
+_FRAMES_PER_SECOND = 12
+
+
+class _Graph(object):
+    """Buffers + plans for one batch size (the reference's graph has a dynamic batch dimension)."""
+    pass
+
+
+class Trainer(object):
+
+    def __init__(self, modelac, modelimages, display_freq=1,
+                 learning_rate=0.0001, num_classes=14, num_epochs=1, nr_frames=12, temporal_pooling=False,
+                 session=None):
+        self.modelac = modelac
+        self.modelimages = modelimages
+        self.display_freq = display_freq
+        self.learning_rate = learning_rate
+        self.num_classes = num_classes
+        self.num_epochs = num_epochs
+        self.nr_frames = nr_frames
+        self.temporal_pooling = temporal_pooling
+        self.session = session
+        self.global_step = 0
+        self.graphs = {}
+        self.comm = None
+        self.noise_seed = 1237
+        self.log = print
+
+    # ------------------------------------------------------------------------------------------------
+    # graph construction
+    # ------------------------------------------------------------------------------------------------
+    def _build_functions(self, data=None, batch_size=None):
+        """Builds the step for `batch_size` (default: data.batch_size or FLAGS.batch_size)."""
+        if batch_size is None:
+            batch_size = getattr(data, "batch_size", None) or FLAGS.batch_size
+        if self.session is None:
+            self.session = Session()
+        g = self._build_graph(int(batch_size), self.modelimages, self.modelac)
+        self.session.finalize()
+        self.acoustic, self.mfcc, self.video = g.acoustic, g.mfcc, g.video
+        self.mfccmap = g.mfccmap
+        self.primary = g
+        return g
+
+    def _build_graph(self, N, modelimages, modelac):
+        sess = self.session
+        z = sess.zeros
+        g = _Graph()
+        g.N = N
+        g.modelimages, g.modelac = modelimages, modelac
+        g.acoustic = z(N, 36, 48, 12)
+        g.mfcc = z(N, 12)
+        g.video = z(N, 224, 298, 3)
+        g.eps = z(N, Z)
+        # self.mfccmap = tile(mfcc) -> [-1,36,48,12]   (trainer/mfcctrainer.py:38-40)
+        g.mfccmap = z(N, 36, 48, 12)
+        modelimages._build_model(g.video, session=sess)
+        modelac._build_model(g.mfccmap, modelimages.output, session=sess, eps=g.eps)
+        g.sums = z(4)          # [sum e^2, sum huber, sum w^2, -]
+        g.chan = z(16)         # per-channel squared error (test)
+        g.losses = z(8)        # mse, huber, latent, reg, total
+        g.g_logit = z(N, 36, 48, 12)
+        count = N * 36 * 48 * 12
+        w_mse, w_hub = float(bool(FLAGS.MSE)), float(bool(FLAGS.huber_loss))
+        ae = modelac.embedding
+        kl = None if ae else modelac.kl
+
+        def head(plan):
+            ops.zero(plan, g.sums)
+            ops.tile_mfcc(plan, g.mfcc, g.mfccmap, N, 36 * 48, 12)
+
+        # ---- training step ----
+        p = sess.new_plan()
+        head(p)
+        p.extend(modelimages.plan_train)
+        p.extend(modelac.plan_fwd)
+        ops.recon_loss(p, modelac.output, g.acoustic, g.g_logit, g.sums, count, w_mse, w_hub)
+        modelimages.record_regularizer(p, ops.Ptr(g.sums, 2))
+        from .vision import WEIGHT_DECAY
+        ops.loss_finalize(p, g.sums, kl, N, count, FLAGS.latent_loss, 0.5 * WEIGHT_DECAY, w_mse, w_hub, g.losses)
+        # gradient buckets: the flat buffer is laid out in backward-completion order; a host hook after
+        # the last kernel of each bucket fires its all-reduce on the side stream (no-op on one GPU)
+        s = modelac.scope
+        cm = modelimages.scope + "/conv_map"
+        self.bucket_boundaries = [cm + "/BatchNorm/beta", s + "/layer6/conv_1/bias", s + "/dense/bias",
+                                  s + "/heads/bias"]
+        ready = {"layer6/conv_1": 1, "dense": 2, "heads": 3, "layer1/conv_1": 4}
+
+        def on_ready(name, p=p):
+            if name in ready:
+                p.add_hook(lambda i=ready[name]: self.comm is not None and self.comm.bucket_ready(i))
+
+        modelac.record_backward(p, g.g_logit, modelimages.g_output, FLAGS.latent_loss / N if not ae else 0.0,
+                                on_ready=on_ready)
+        modelimages.record_backward(p)
+        p.add_hook(lambda: self.comm is not None and self.comm.bucket_ready(0))
+        g.plan_train = p
+        # ---- evaluation step (is_training = 0: moving statistics; MSE only, :411-442) ----
+        e = sess.new_plan()
+        head(e)
+        e.extend(modelimages.plan_eval)
+        e.extend(modelac.plan_fwd)
+        ops.recon_loss(e, modelac.output, g.acoustic, None, g.sums, count, 1.0, 1.0)
+        ops.zero(e, g.chan)
+        ops.sqerr_channels(e, modelac.output, g.acoustic, N * 36 * 48, 12, g.chan)
+        ops.loss_finalize(e, g.sums, None, N, count, 0.0, 0.0, 1.0, 0.0, g.losses)
+        g.plan_eval = e
+        g.count = count
+        self.graphs[N] = g
+        return g
+
+    def _graph_for(self, N):
+        if N in self.graphs:
+            return self.graphs[N]
+        # a different batch size (last partial batch): same variables, new buffers + plans
+        mi = type(self.modelimages)(input_shape=[224, 298, 3], num_classes=None)
+        ma = type(self.modelac)(input_shape=[36, 48, 12], embedding=self.modelac.embedding,
+                                num_skip=self.modelac.num_skip)
+        mi._register = lambda store: None
+        ma_heads = self.modelac.heads
+
+        def _reuse(store, ma=ma):
+            ma.heads = ma_heads
+        ma._register = _reuse
+        return self._build_graph(N, mi, ma)
+
+    def enable_data_parallel(self, group=None):
+        """All-reduce the flat gradient across ranks (torch.distributed must be initialised): five
+        contiguous buckets, each fired from its hook in the recorded backward plan."""
+        store = self.session.store
+        self.buckets = dp.make_buckets(store.train_ranges(), self.bucket_boundaries)
+        assert len(self.buckets) == 5, self.buckets
+        self.comm = dp.GradComm(store.grad, self.buckets, group)
+        return self.comm
+
+    # ------------------------------------------------------------------------------------------------
+    # the step
+    # ------------------------------------------------------------------------------------------------
+    def _feed(self, g, batch, eps):
+        acoustic, mfcc, video = batch[0], batch[1], batch[2]
+        g.acoustic.copy_(acoustic.reshape(g.N, 36, 48, 12), non_blocking=True)
+        g.mfcc.copy_(mfcc.reshape(g.N, 12), non_blocking=True)
+        g.video.copy_(video.reshape(g.N, 224, 298, 3), non_blocking=True)
+        if eps is not None:
+            g.eps.copy_(eps.reshape(g.N, Z), non_blocking=True)
+        else:
+            ops.randn(ops.Plan(self.session.device, eager=True, ws=self.session.ws), g.eps, g.N * Z,
+                      self.noise_seed, self.global_step * 4096)
+
+    def train_step(self, batch=None, eps=None, sync=True):
+        """One optimisation step (the body of the reference's hot loop, trainer/mfcctrainer.py:343-349).
+        batch: (acoustic [N,36,48,12], mfcc [N,12], video [N,224,298,3], ...) or None to reuse the
+        tensors already resident in the graph's input buffers.  Returns {mse, huber, latent, reg, loss}
+        (python floats; sync=False returns the device tensor instead and does not block)."""
+        g = self.primary if batch is None else self._graph_for(int(batch[1].reshape(-1, 12).shape[0]))
+        if batch is not None:
+            self._feed(g, batch, eps)
+        elif eps is not None:
+            g.eps.copy_(eps.reshape(g.N, Z), non_blocking=True)
+        g.plan_train.run()      # hooks inside fire the bucketed all-reduce when data-parallel
+        store = self.session.store
+        scale = 1.0
+        if self.comm is not None and self.comm.enabled:
+            self.comm.wait()
+            scale = self.comm.grad_scale
+        self.global_step += 1
+        lr_t = ops.adam_lr_t(self.learning_rate, self.global_step)
+        st = ops.current_stream_handle(self.session.device)
+        rc = _lib.load().acimg_adam_step(store.flat["train"].data_ptr(), store.grad.data_ptr(),
+                                         store.adam_m.data_ptr(), store.adam_v.data_ptr(),
+                                         store.train_numel(), lr_t, 0.9, 0.999, 1e-8, scale, st)
+        _lib.check(rc, "adam_step")
+        if not sync:
+            return g.losses
+        return self._scalars(g)
+
+    def _scalars(self, g):
+        v = g.losses[:5].tolist()
+        return OrderedDict(mse=v[0], huber=v[1], latent=v[2], reg=v[3], loss=v[4])
+
+    def eval_step(self, batch=None, eps=None):
+        """forward in inference mode (BN moving statistics); returns mse + the four per-3-channel MSEs"""
+        g = self.primary if batch is None else self._graph_for(int(batch[1].reshape(-1, 12).shape[0]))
+        if batch is not None:
+            self._feed(g, batch, eps)
+        elif eps is not None:
+            g.eps.copy_(eps.reshape(g.N, Z), non_blocking=True)
+        g.plan_eval.run()
+        mse = float(g.losses[0])
+        ch = g.chan[:12].tolist()
+        res = OrderedDict(mse=mse)
+        per = g.N * 36 * 48 * 3
+        for i in range(4):
+            res["mse%d" % i] = sum(ch[3 * i:3 * i + 3]) / per
+        return res
+
+    # ------------------------------------------------------------------------------------------------
+    # reference protocol: loops, checkpoints
+    # ------------------------------------------------------------------------------------------------
+    def _retrieve_batch(self, next_batch):
+        if FLAGS.model == 'UNet':
+            mfcc = next_batch[1].reshape(-1, 12)
+            images = next_batch[2].reshape(-1, 224, 298, 3)
+            acoustic = next_batch[0].reshape(-1, 36, 48, 12)
+            labels = next_batch[3].reshape(mfcc.shape[0], -1).argmax(1)
+            scenario = next_batch[4].reshape(mfcc.shape[0], -1).argmax(1)
+        else:
+            raise ValueError('Unknown model type')
+        return acoustic, mfcc, images, labels, scenario
+
+    def _init_model(self, session):
+        """random init, then optional partial restores (trainer/mfcctrainer.py:163-234)"""
+        self.modelimages.initialize()
+        self.modelac.initialize()
+        if FLAGS.init_checkpoint is not None:
+            self.modelac.init_model(session, FLAGS.init_checkpoint)
+        elif FLAGS.acoustic_init_checkpoint is not None or FLAGS.visual_init_checkpoint is not None:
+            if FLAGS.acoustic_init_checkpoint is not None:
+                self.modelac.init_model(session, FLAGS.acoustic_init_checkpoint)
+            if FLAGS.visual_init_checkpoint is not None:
+                self.modelimages.init_model(session, FLAGS.visual_init_checkpoint)
+        elif FLAGS.restore_checkpoint is not None:
+            self._restore_model(session)
+
+    def _restore_model(self, session):
+        """model variables only: Adam slots and global_step start afresh (:236-247)"""
+        from .vision import load_state_file
+        state = load_state_file(FLAGS.restore_checkpoint)
+        session.store.load_state(state, strict=False)
+
+    def _save_checkpoint(self, session, epoch):
+        checkpoint_dir = '{}/{}'.format(FLAGS.checkpoint_dir, FLAGS.exp_name)
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        model_name = 'epoch_{}.ckpt'.format(epoch)
+        self.log('{}: {} - Saving model to {}/{}'.format(datetime.now(), FLAGS.exp_name, checkpoint_dir, model_name))
+        store = session.store
+        torch.save({"model": store.state_dict(), "adam_m": store.slot_dict("m"), "adam_v": store.slot_dict("v"),
+                    "global_step": self.global_step}, '{}/{}'.format(checkpoint_dir, model_name))
+        self._saved = getattr(self, "_saved", []) + ['{}/{}'.format(checkpoint_dir, model_name)]
+        while len(self._saved) > 11:   # Saver(max_to_keep=11), :81
+            old = self._saved.pop(0)
+            if os.path.exists(old) and old not in self._saved:
+                os.remove(old)
+
+    def train(self, train_data=None, valid_data=None):
+        assert train_data is not None
+        assert valid_data is not None
+        if not self.graphs:
+            self._build_functions(train_data)
+        session = self.session
+        self._init_model(session)
+        if FLAGS.checkpoint_dir is not None:
+            self._save_checkpoint(session, 'random')
+        start_epoch = int(self.global_step)
+        best_epoch, best_loss = -1, 10000
+        for epoch in range(start_epoch, start_epoch + self.num_epochs):
+            step = 0
+            for next_batch in train_data.data:
+                acoustic, mfcc, images, _, _ = self._retrieve_batch(next_batch)
+                r = self.train_step((acoustic, mfcc, images))
+                if step % self.display_freq == 0:
+                    self.log('{}: {} - Iteration: [{:3}]\t Training_mse_Loss: {:6f}\t Training_Loss: {:6f}'.format(
+                        datetime.now(), FLAGS.exp_name, step, r["mse"], r["loss"]))
+                step += 1
+            total_loss = self._evaluate(session, 'validation', valid_data)
+            self.log('{}: {} - Epoch: {}\t Validation_mse_Loss: {:6f}'.format(datetime.now(), FLAGS.exp_name, epoch,
+                                                                              total_loss))
+            if FLAGS.checkpoint_dir is not None:
+                if epoch % 10 == 0:
+                    self._save_checkpoint(session, epoch)
+                if total_loss <= best_loss:
+                    best_epoch, best_loss = epoch, total_loss
+                    self._save_checkpoint(session, epoch)
+                    with open('{}/{}'.format(FLAGS.checkpoint_dir, FLAGS.exp_name) + "/model.txt", "w") as outfile:
+                        outfile.write('{}: {}\nBest Epoch: {}\nValidation_mse_Loss: {:6f}\n'.format(
+                            datetime.now(), FLAGS.exp_name, best_epoch, best_loss))
+            elif total_loss <= best_loss:
+                best_epoch, best_loss = epoch, total_loss
+        self.log('{}: {} - Best Epoch: {}\t Validation_mse_Loss: {:6f}'.format(datetime.now(), FLAGS.exp_name,
+                                                                            best_epoch, best_loss))
+        return best_loss
+
+    def _valid(self, session, data):
+        return self._evaluate(session, 'validation', data)
+
+    def _evaluate(self, session, mod, data):
+        """size-weighted mean of the per-batch MSE (trainer/mfcctrainer.py:411-442)"""
+        loss_sum, data_set_size = 0.0, 0
+        for next_batch in data.data:
+            acoustic, mfcc, images, labels, _ = self._retrieve_batch(next_batch)
+            r = self.eval_step((acoustic, mfcc, images))
+            n = labels.shape[0]
+            data_set_size += n
+            loss_sum += r["mse"] * n
+        return loss_sum / data_set_size
+
+    def test(self, test_data=None):
+        assert test_data is not None
+        if not self.graphs:
+            self._build_functions(test_data)
+        session = self.session
+        self.modelimages.initialize()
+        self.modelac.initialize()
+        if FLAGS.restore_checkpoint is not None:
+            self._restore_model(session)
+        sums = [0.0] * 5
+        data_set_size = 0
+        for next_batch in test_data.data:
+            acoustic, mfcc, images, labels, _ = self._retrieve_batch(next_batch)
+            r = self.eval_step((acoustic, mfcc, images))
+            n = labels.shape[0]
+            data_set_size += n
+            for i, k in enumerate(("mse", "mse0", "mse1", "mse2", "mse3")):
+                sums[i] += r[k] * n
+        test_loss, l0, l1, l2, l3 = [s / data_set_size for s in sums]
+        line = '{} - Testing_Loss: {:6f}\t  Testing_Loss0: {:6f}\t Testing_Loss1: {:6f}\t Testing_Loss2: {:6f}\t ' \
+               'Testing_Loss3: {:6f}'.format(datetime.now(), test_loss, l0, l1, l2, l3)
+        if FLAGS.restore_checkpoint is not None:
+            name_folder = str.join('/', FLAGS.restore_checkpoint.split('/')[:-1])
+            tag = FLAGS.restore_checkpoint.split('/')[-1].split('.')[0].split('_')[-1]
+            with open('{}'.format(name_folder) + "/test_accuracy_{}.txt".format(tag), "w") as outfile:
+                outfile.write(line)
+        self.log(line)
+        return test_loss

@@ -1,0 +1,275 @@
+"""`ResNet50Model`: the modified ResNet-v1-50 image encoder, MI355X-native.
+
+Mirrors the reference's model protocol (models/vision.py:8-71): `scope`, `init_model(session,
+checkpoint_file)`, `_build_model(visual_images)` which sets `output`, `network`, `train_vars`
+(conv_map only) and `train_vars2` (the frozen trunk).  Architecture: models/resnet50.py:75-125
+(bottleneck), :205-209 (7x7/2 stem, 3x3/2 pool, conv_map 3x4 VALID 2048->12 + BN + ReLU), :261-266
+(block strides 1,2,2,1 placed in each block's last unit).
+
+MI355X design: every conv is one implicit-GEMM launch that writes the RAW conv output once and
+leaves per-row-block (sum, sum^2) partials; `bn_finalize` turns them into per-channel scale/shift
+(and advances the moving averages); the *consumer* conv applies scale/shift/ReLU while staging its
+A tile, so normalised activations are never written to HBM.  Only the unit outputs
+(relu(bn(conv3) + shortcut)) are materialised.  Activations live in six reusable arenas (about
+0.8 GB at batch 32), so consecutive layers hit the 256 MiB Infinity Cache instead of streaming
+6.5 GB of distinct tensors.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from .params import Var, up4
+from .session import get_default_session
+
+BLOCKS = (("block1", 64, 3, 1), ("block2", 128, 4, 2), ("block3", 256, 6, 2), ("block4", 512, 3, 1))
+WEIGHT_DECAY = 5e-4   # resnet_arg_scope(weight_decay=5e-4), models/vision.py:54
+BN_DECAY = 0.997
+BN_EPS = 1e-5
+
+
+class ResNet50Model(object):
+
+    def __init__(self, input_shape=None, num_classes=None):
+        self.scope = 'resnet_v1_50'
+        self.num_classes = num_classes
+        self.height = input_shape[0]
+        self.width = input_shape[1]
+        self.channels = input_shape[2]
+        if num_classes is not None:
+            raise NotImplementedError("the logits layer is not on the acoustic-image path (num_classes=None)")
+        self.session = None
+        self.output = None
+        self.network = None
+
+    # ---- variable inventory (TF names) --------------------------------------------------------------
+    def _units(self):
+        depth_in = 64
+        for name, base, n, stride in BLOCKS:
+            for u in range(n):
+                s = stride if u == n - 1 else 1
+                yield ("%s/%s/unit_%d/bottleneck_v1" % (self.scope, name, u + 1), depth_in, base * 4, base, s)
+                depth_in = base * 4
+
+    def _conv_layers(self):
+        yield (self.scope + "/conv1", 7, 7, 3, 64)
+        for scope, din, d, db, s in self._units():
+            if din != d:
+                yield (scope + "/shortcut", 1, 1, din, d)
+            yield (scope + "/conv1", 1, 1, din, db)
+            yield (scope + "/conv2", 3, 3, db, db)
+            yield (scope + "/conv3", 1, 1, db, d)
+        yield (self.scope + "/conv_map", 3, 4, 2048, 12)
+
+    def _register(self, store):
+        cm = self.scope + "/conv_map"
+        # trainable first (conv_map/* is in the optimiser's var_list, trainer/mfcctrainer.py:64)
+        store.add(Var(cm + "/weights", (3, 4, 2048, 12), "conv", "train"))
+        store.add(Var(cm + "/BatchNorm/gamma", (12,), "vec", "train"))
+        store.add(Var(cm + "/BatchNorm/beta", (12,), "vec", "train"))
+        store.add(Var(cm + "/BatchNorm/moving_mean", (12,), "vec", "state"))
+        store.add(Var(cm + "/BatchNorm/moving_variance", (12,), "vec", "state"))
+        for scope, kh, kw, cin, cout in self._conv_layers():
+            if scope == cm:
+                continue
+            store.add(Var(scope + "/weights", (kh, kw, cin, cout), "conv", "trunkw"))
+            for sfx in ("gamma", "beta", "moving_mean", "moving_variance"):
+                store.add(Var(scope + "/BatchNorm/" + sfx, (cout,), "vec", "state"))
+
+    # ---- reference protocol ------------------------------------------------------------------------
+    def init_model(self, session, checkpoint_file):
+        """Initialise from a TF-named state dict, everything except logits / conv_map
+        (models/vision.py:20-42).  checkpoint_file: path to .npz / torch file, or a dict."""
+        state = load_state_file(checkpoint_file)
+        store = (session or self.session).store
+        return store.load_state(state, strict=False,
+                                only=lambda n: n.startswith(self.scope + "/") and "/logits" not in n and "/conv_map" not in n)
+
+    def initialize(self, seed=1238):
+        """slim defaults: variance_scaling_initializer conv kernels, gamma 1, beta 0, moving 0/1"""
+        g = torch.Generator().manual_seed(seed)
+        state = OrderedDict()
+        for scope, kh, kw, cin, cout in self._conv_layers():
+            fan_in = kh * kw * cin
+            t = torch.randn(kh, kw, cin, cout, generator=g, dtype=torch.float64).clamp_(-2, 2)
+            state[scope + "/weights"] = (t * np.sqrt(1.3 * 2.0 / fan_in)).float()
+            state[scope + "/BatchNorm/gamma"] = torch.ones(cout)
+            state[scope + "/BatchNorm/beta"] = torch.zeros(cout)
+            state[scope + "/BatchNorm/moving_mean"] = torch.zeros(cout)
+            state[scope + "/BatchNorm/moving_variance"] = torch.ones(cout)
+        self.session.store.load_state(state, strict=False, only=lambda n: n.startswith(self.scope + "/"))
+
+    def _build_model(self, visual_images, session=None):
+        """visual_images: device buffer [N,224,298,3] float32 (the feed target).  Records the forward
+        plans (training / inference BN mode) and the conv_map backward plan."""
+        sess = session or get_default_session()
+        self.session = sess
+        self._register(sess.store)
+        N = visual_images.shape[0]
+        assert tuple(visual_images.shape[1:]) == (self.height, self.width, self.channels)
+        self.N = N
+        self._alloc(sess, visual_images)
+        self.plan_train = sess.new_plan()
+        self.plan_eval = sess.new_plan()
+        self._record_forward(self.plan_train, True)
+        self._record_forward(self.plan_eval, False)
+        self.network = OrderedDict(input=visual_images, is_training=None, keep_prob=None)
+        self.network[self.scope + "/conv_map"] = self.output
+        cm = self.scope + "/conv_map"
+        self.train_vars = [cm + "/weights", cm + "/BatchNorm/gamma", cm + "/BatchNorm/beta"]
+        self.train_vars2 = [n for n, v in sess.store.vars.items()
+                            if v.group == "trunkw" or (v.group == "state" and n.endswith(("gamma", "beta")))]
+
+    # ---- buffers -------------------------------------------------------------------------------------
+    def _alloc(self, sess, images):
+        N, H, W = self.N, self.height, self.width
+        z = sess.zeros
+        self.images = images
+        self.xpad = z(N, H, W, 4)
+        oh1, ow1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        self.stem_hw = (oh1, ow1)
+        self.raw0 = z(N, oh1, ow1, 64)
+        ph, _ = ops.same_out_pad(oh1, 3, 2)
+        pw, _ = ops.same_out_pad(ow1, 3, 2)
+        self.pool_hw = (ph, pw)
+        # arena sizes over all units
+        h, w = ph, pw
+        mx_io = N * h * w * 64
+        mx_r1 = mx_r2 = mx_r3 = 0
+        nch = 64
+        for scope, din, d, db, s in self._units():
+            oh, _ = ops.same_out_pad(h, 1, s)
+            ow, _ = ops.same_out_pad(w, 1, s)
+            mx_r1 = max(mx_r1, N * h * w * db)
+            mx_r2 = max(mx_r2, N * oh * ow * db)
+            mx_r3 = max(mx_r3, N * oh * ow * d)
+            mx_io = max(mx_io, N * h * w * din, N * oh * ow * d)
+            h, w = oh, ow
+            nch += (d if din != d else 0) + 2 * db + d
+        self.final_hw = (h, w)
+        self.arena_a = z(mx_io)
+        self.arena_b = z(mx_io)
+        self.arena_r1 = z(mx_r1)
+        self.arena_r2 = z(mx_r2)
+        self.arena_r3 = z(mx_r3)
+        self.arena_sc = z(mx_r3)
+        self.xfinal = z(N, h, w, 2048)          # block4 output, kept for the conv_map weight gradient
+        self.affine = z(2 * (nch + 64 + 16))    # scale/shift of every BN layer
+        self._aff_off = 0
+        fh, fw = h - 3 + 1, w - 4 + 1
+        self.feat_hw = (fh, fw)
+        self.raw_cm = z(N, fh, fw, 12)
+        self.output = z(N, fh, fw, 12)
+        self.save_mean = z(16)
+        self.save_invstd = z(16)
+        self.g_output = z(N, fh, fw, 12)        # filled by the generator's backward (min-max bwd)
+        self.g_raw_cm = z(N, fh, fw, 12)
+        self.stats = None
+        self._stats_need = 0
+
+    def _new_affine(self, c):
+        sc = self.affine[self._aff_off:self._aff_off + c]
+        sh = self.affine[self._aff_off + c:self._aff_off + 2 * c]
+        self._aff_off += 2 * c
+        assert self._aff_off <= self.affine.numel()
+        return sc, sh
+
+    # ---- plan recording ------------------------------------------------------------------------------
+    def _conv_bn(self, plan, scope, x, hw, cin, kh, kw, cout, stride, padding, out, in_aff, training,
+                 save=False):
+        """raw conv + BN statistics -> (scale, shift) of this layer; returns (OH, OW, scale, shift)"""
+        st = self.session.store
+        P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
+        d = ops.conv_desc(self.N, hw[0], hw[1], cin, cout, kh, kw, stride, padding, ldx=cin, ldy=up4(cout),
+                          ldw=up4(cout))
+        rows = ops.conv2d_stats_rows(d)
+        self._stats_need = max(self._stats_need, rows * 2 * up4(cout))
+        stats = ops.LazyPtr(lambda: self.stats)
+        isc, ish = (in_aff if in_aff is not None else (None, None))
+        ops.conv2d_fwd(plan, d, x, P(scope + "/weights"), None, out, isc, ish, 1,
+                       stats if training else None)
+        if not hasattr(self, "_aff_cache"):
+            self._aff_cache = {}
+        if scope not in self._aff_cache:
+            self._aff_cache[scope] = self._new_affine(up4(cout))
+        sc, sh = self._aff_cache[scope]
+        b = scope + "/BatchNorm/"
+        ops.bn_finalize(plan, stats if training else None, rows if training else 0, cout, up4(cout),
+                        self.N * d.OH * d.OW if training else 0, P(b + "gamma"), P(b + "beta"),
+                        P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, BN_DECAY, BN_EPS, training,
+                        self.save_mean if save else None, self.save_invstd if save else None)
+        return d.OH, d.OW, sc, sh
+
+    def _record_forward(self, plan, training):
+        N = self.N
+        H, W = self.height, self.width
+        ops.pad_channels(plan, self.images, self.xpad, N * H * W, 3, 4)
+        oh, ow, sc, sh = self._conv_bn(plan, self.scope + "/conv1", self.xpad, (H, W), 4, 7, 7, 64, 2, 3,
+                                       self.raw0, None, training)
+        ph, pw = self.pool_hw
+        _, pt = ops.same_out_pad(oh, 3, 2)
+        _, pl = ops.same_out_pad(ow, 3, 2)
+        cur, nxt = self.arena_a, self.arena_b
+        ops.bn_relu_maxpool(plan, self.raw0, sc, sh, cur, N, oh, ow, 64, ph, pw, pt, pl)
+        h, w = ph, pw
+        units = list(self._units())
+        for i, (scope, din, d, db, s) in enumerate(units):
+            last = i == len(units) - 1
+            oh1, ow1, s1, t1 = self._conv_bn(plan, scope + "/conv1", cur, (h, w), din, 1, 1, db, 1, "SAME",
+                                             self.arena_r1, None, training)
+            oh2, ow2, s2, t2 = self._conv_bn(plan, scope + "/conv2", self.arena_r1, (h, w), db, 3, 3, db, s,
+                                             "SAME" if s == 1 else 1, self.arena_r2, (s1, t1), training)
+            oh3, ow3, s3, t3 = self._conv_bn(plan, scope + "/conv3", self.arena_r2, (oh2, ow2), db, 1, 1, d, 1,
+                                             "SAME", self.arena_r3, (s2, t2), training)
+            out = self.xfinal if last else nxt
+            if din != d:
+                _, _, ssc, tsc = self._conv_bn(plan, scope + "/shortcut", cur, (h, w), din, 1, 1, d, s, "SAME",
+                                               self.arena_sc, None, training)
+                ops.bn_add_relu(plan, self.arena_r3, s3, t3, self.arena_sc, ssc, tsc, out, N, oh3, ow3, d,
+                                oh3, ow3, 1)
+            else:
+                ops.bn_add_relu(plan, self.arena_r3, s3, t3, cur, None, None, out, N, oh3, ow3, d, h, w, s)
+            h, w = oh3, ow3
+            if not last:
+                cur, nxt = nxt, cur
+        fh, fw = self.feat_hw
+        _, _, scm, tcm = self._conv_bn(plan, self.scope + "/conv_map", self.xfinal, (h, w), 2048, 3, 4, 12, 1,
+                                       "VALID", self.raw_cm, None, training, save=True)
+        ops.bn_relu(plan, self.raw_cm, scm, tcm, self.output, N * fh * fw, 12, 12, 12)
+        if self.stats is None or self.stats.numel() < self._stats_need:
+            self.stats = self.session.zeros(self._stats_need)
+
+    def record_backward(self, plan):
+        """conv_map backward: g(output) -> BN/ReLU backward -> weight gradient (+ L2 term).  The trunk
+        below conv_map receives no gradient (it is not in var_list, trainer/mfcctrainer.py:64)."""
+        st = self.session.store
+        cm = self.scope + "/conv_map"
+        P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
+        G = lambda n: ops.LazyPtr(lambda n=n: st.g(n))  # noqa: E731
+        N = self.N
+        fh, fw = self.feat_hw
+        h, w = self.final_hw
+        ops.bn_relu_bwd(plan, self.raw_cm, self.output, self.g_output, P(cm + "/BatchNorm/gamma"),
+                        self.save_mean, self.save_invstd, self.g_raw_cm, G(cm + "/BatchNorm/gamma"),
+                        G(cm + "/BatchNorm/beta"), N * fh * fw, 12)
+        d = ops.conv_desc(N, h, w, 2048, 12, 3, 4, 1, "VALID", ldx=2048, ldy=12, ldw=12)
+        ops.conv2d_wgrad(plan, d, self.xfinal, self.g_raw_cm, 12, G(cm + "/weights"), None)
+        ops.axpy(plan, WEIGHT_DECAY, P(cm + "/weights"), G(cm + "/weights"), 3 * 4 * 2048 * 12)
+
+    def record_regularizer(self, plan, accum):
+        """adds sum(w^2) over every conv kernel of the scope into accum[0] (slim l2_regularizer terms
+        collected by tf.losses.get_total_loss, trainer/mfcctrainer.py:60)"""
+        st = self.session.store
+        ops.sumsq(plan, ops.LazyPtr(lambda: st.flat["trunkw"]), st._sizes["trunkw"], accum)
+        ops.sumsq(plan, ops.LazyPtr(lambda: st.p(self.scope + "/conv_map/weights")), 3 * 4 * 2048 * 12, accum)
+
+
+def load_state_file(f):
+    """{TF variable name: array}: a dict, an .npz, or a torch-saved dict (possibly under 'model')."""
+    if isinstance(f, dict):
+        return f.get("model", f)
+    if str(f).endswith(".npz"):
+        return dict(np.load(f))
+    obj = torch.load(f, map_location="cpu", weights_only=False)
+    return obj.get("model", obj) if isinstance(obj, dict) else obj

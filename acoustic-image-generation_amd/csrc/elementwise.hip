@@ -450,6 +450,74 @@ __global__ void loss_finalize_kernel(const float* sums, const float* kl, int N, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// standard normal samples, Philox4x32-10 counter RNG + Box-Muller (stands where the reference
+// calls tf.random_normal, models/unet_acresnet.py:77): 4 samples per counter, stateless.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
+                                             uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* out, long n, uint64_t seed, uint64_t offset) {
+    const long quads = (n + 3) >> 2;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
+        const uint64_t ctr = (uint64_t)q + offset;
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x9E3779B9u, c3 = 0xBB67AE85u;
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c0, c1, c2, c3, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const float u0 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u1 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u3 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+        float s0, cs0, s1, cs1;
+        sincospif(2.f * u1, &s0, &cs0);
+        sincospif(2.f * u3, &s1, &cs1);
+        const float v[4] = {r0 * cs0, r0 * s0, r1 * cs1, r1 * s1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (q * 4 + k < n) out[q * 4 + k] = v[k];
+    }
+}
+
+
+// per-channel sum of squared errors: out[c] += sum_p (a[p][c]-b[p][c])^2  (C <= 64)
+__global__ __launch_bounds__(256) void sqerr_channels_kernel(const float* a, const float* b, long pixels, int C,
+                                                             float* out) {
+    __shared__ float acc[64];
+    if (threadIdx.x < 64) acc[threadIdx.x] = 0.f;
+    __syncthreads();
+    const long total = pixels * C;
+    // each thread keeps a fixed channel: stride of the loop is a multiple of C
+    const long stride = ((long)gridDim.x * 256 / C) * C;
+    const long start = (long)blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    int c = -1;
+    if (start < stride) {
+        c = (int)(start % C);
+        for (long i = start; i < total; i += stride) {
+            const float e = a[i] - b[i];
+            s += e * e;
+        }
+    }
+    if (c >= 0) atomicAdd(&acc[c], s);
+    __syncthreads();
+    if (threadIdx.x < C) atomicAdd(&out[threadIdx.x], acc[threadIdx.x]);
+}
+
 static inline int ew_grid(long work_items) {
     long b = (work_items + 255) / 256;
     if (b > 4096) b = 4096;
@@ -614,6 +682,23 @@ int acimg_zero(void* ptr, size_t bytes, void* stream) {
     hipError_t e = hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ACIMG_ELAUNCH, "zero: %s", hipGetErrorString(e));
     return ACIMG_OK;
+}
+
+int acimg_randn(float* out, long n, uint64_t seed, uint64_t offset, void* stream) {
+    if (n <= 0) return fail(ACIMG_EINVAL, "randn: n must be positive");
+    hipLaunchKernelGGL(randn_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, out, n,
+                       seed, offset);
+    return check_launch("randn");
+}
+
+int acimg_sqerr_channels(const float* a, const float* b, long pixels, int C, float* out, void* stream) {
+    if (C <= 0 || C > 64) return fail(ACIMG_EINVAL, "sqerr_channels: C must be in 1..64");
+    long blocks = (pixels * C + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    if (blocks * 256 < C) blocks = (C + 255) / 256;
+    hipLaunchKernelGGL(sqerr_channels_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a, b, pixels,
+                       C, out);
+    return check_launch("sqerr_channels");
 }
 
 }  // extern "C"

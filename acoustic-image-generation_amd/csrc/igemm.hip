@@ -789,8 +789,8 @@ size_t acimg_conv2d_dgrad_workspace(const AcimgConvDesc* d) {
 }
 
 int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
-                       float* dx, const float* residual, int ldres, const float* mask, int ldmask,
-                       void* ws, size_t ws_bytes, void* stream) {
+                       float* dx, int lddx, const float* residual, int ldres, const float* mask,
+                       int ldmask, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_desc(d, "conv2d_dgrad");
     if (rc) return rc;
     const int ca = up4(d->K);
@@ -798,7 +798,9 @@ int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
     IgemmParams p{};
     p.A = gy; p.C = ca; p.lda = ldgy;
     p.B = w; p.ldb = d->ldw;
-    p.e.Y = dx; p.e.ldy = d->ldx; p.e.res = residual; p.e.ldres = ldres; p.e.mask = mask; p.e.ldmask = ldmask;
+    if (lddx <= 0) lddx = d->ldx;
+    if (lddx < d->C) return fail(ACIMG_EINVAL, "conv2d_dgrad: lddx < C");
+    p.e.Y = dx; p.e.ldy = lddx; p.e.res = residual; p.e.ldres = ldres; p.e.mask = mask; p.e.ldmask = ldmask;
     p.e.act = ACIMG_ACT_NONE;
     if (d->stride == 1) {
         // dx[h,w,c] = sum_{r',s',k} gy[h-(R-1-pt)+r', w-(S-1-pl)+s', k] * W[R-1-r'][S-1-s'][c][k]

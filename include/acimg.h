@@ -78,13 +78,14 @@ size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d);
  * (pixel stride ldgy); dx = relu_mask(conv_T(gy, w) + residual): `residual` (optional, pixel
  * stride ldres) is another gradient flowing into x (fan-out), `mask` (optional, pixel stride
  * ldmask) is the saved post-ReLU activation x itself: dx is zeroed where mask <= 0, so dx is
- * the pre-activation gradient of the producing layer.  Supported geometries: stride 1, and
+ * the pre-activation gradient of the producing layer.  dx has pixel stride lddx (0 = d->ldx: the
+ * gradient of a concat-slice input usually lives in its own, narrower buffer).  Supported geometries: stride 1, and
  * stride == R == S with zero padding (non-overlapping patches, layer1/pool_2).
  * Replaces: the Conv2DBackpropInput ops tf.gradients emits for the calls above
  *           (trainer/mfcctrainer.py:72-79). */
 int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
-                       float* dx, const float* residual, int ldres, const float* mask, int ldmask,
-                       void* ws, size_t ws_bytes, void* stream);
+                       float* dx, int lddx, const float* residual, int ldres, const float* mask,
+                       int ldmask, void* ws, size_t ws_bytes, void* stream);
 size_t acimg_conv2d_dgrad_workspace(const AcimgConvDesc* d);
 
 /* Weight + bias gradient: dw[R][S][C][ldw] = sum_pixels x (*) gy, db[k] = sum gy (db optional).
@@ -191,8 +192,16 @@ int acimg_grad_slice(const float* src, int ldsrc, float* dst, int lddst, const f
 int acimg_loss_finalize(const float* sums, const float* kl, int N, double count, float latent_w,
                         float half_wd, float w_mse, float w_huber, float* out, void* stream);
 
+/* out[i] ~ N(0,1), i < n: Philox4x32-10 keyed by `seed`, counter = offset + i/4, Box-Muller.
+ * Stands where the reference samples tf.random_normal (models/unet_acresnet.py:77). */
+int acimg_randn(float* out, long n, uint64_t seed, uint64_t offset, void* stream);
+
 /* stream-ordered memset to zero (loss accumulators, gradient buffers) */
 int acimg_zero(void* ptr, size_t bytes, void* stream);
+
+/* out[c] += sum over pixels of (a-b)^2 for channel c (dense [pixels][C], C<=64; caller zeroes out):
+ * the per-3-channel test MSEs of trainer/mfcctrainer.py:105-117 are sums of 3 of these / count. */
+int acimg_sqerr_channels(const float* a, const float* b, long pixels, int C, float* out, void* stream);
 
 /* sum of squares of a flat buffer into *out (+=) — slim l2_regularizer terms
  * (models/vision.py:54, tf.losses.get_total_loss trainer/mfcctrainer.py:60). */
