@@ -37,6 +37,7 @@ PROTOTYPES = {
     "acimg_last_error": (_I, [C.c_char_p, _SZ]),
     "acimg_conv2d_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _P, _I, _P, _P, _SZ, _P]),
     "acimg_conv2d_stats_rows": (_I, [_DP]),
+    "acimg_conv2d_fwd_tiling": (_I, [_DP, C.POINTER(C.c_int)]),
     "acimg_conv2d_fwd_workspace": (_SZ, [_DP]),
     "acimg_conv2d_dgrad": (_I, [_DP, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _SZ, _P]),
     "acimg_conv2d_dgrad_workspace": (_SZ, [_DP]),

@@ -150,6 +150,29 @@ class Plan(object):
             if rc:
                 _lib.check(rc, name)
 
+    def run_probed(self, indices, out, stream=None):
+        """run(), bracketing the calls whose index is in `indices` with events on the launch stream;
+        appends (index, start_event, end_event) to `out` (bench.py's live per-kernel timing)."""
+        if self._resolved is None or self._ws_version != self.ws.version:
+            self.finalize()
+        st = stream if stream is not None else current_stream_handle(self.device)
+        ts = torch.cuda.current_stream(self.device)
+        for i, (name, fn, args) in enumerate(self._resolved):
+            if args is None:
+                fn()
+                continue
+            if i in indices:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(ts)
+                rc = fn(*args, st)
+                e1.record(ts)
+                out.append((i, e0, e1))
+            else:
+                rc = fn(*args, st)
+            if rc:
+                _lib.check(rc, name)
+
     def __len__(self):
         return len(self.calls)
 
@@ -208,6 +231,13 @@ def _L():
 
 def conv2d_stats_rows(d):
     return _L().acimg_conv2d_stats_rows(C.byref(d))
+
+
+def conv2d_fwd_tiling(d):
+    """(BM, BN, splits) the forward kernel launch for `d` uses"""
+    out = (C.c_int * 3)()
+    _lib.check(_L().acimg_conv2d_fwd_tiling(C.byref(d), out), "conv2d_fwd_tiling")
+    return out[0], out[1], out[2]
 
 
 def conv2d_fwd(plan, d, x, w, bias, y, in_scale=None, in_shift=None, in_relu=0, stats=None):

@@ -169,13 +169,20 @@ class Trainer(object):
         g.acoustic.copy_(acoustic.reshape(g.N, 36, 48, 12), non_blocking=True)
         g.mfcc.copy_(mfcc.reshape(g.N, 12), non_blocking=True)
         g.video.copy_(video.reshape(g.N, 224, 298, 3), non_blocking=True)
+        self._noise(g, eps)
+
+    def _noise(self, g, eps):
+        """eps given: copy it in (parity tests); else sample N(0,1) on the device, a fresh Philox
+        counter range every step (the reference's tf.random_normal, models/unet_acresnet.py:77)"""
         if eps is not None:
             g.eps.copy_(eps.reshape(g.N, Z), non_blocking=True)
         else:
-            ops.randn(ops.Plan(self.session.device, eager=True, ws=self.session.ws), g.eps, g.N * Z,
-                      self.noise_seed, self.global_step * 4096)
+            self._noise_calls = getattr(self, "_noise_calls", 0) + 1
+            rc = _lib.load().acimg_randn(g.eps.data_ptr(), g.N * Z, self.noise_seed, self._noise_calls * 65536,
+                                         ops.current_stream_handle(self.session.device))
+            _lib.check(rc, "randn")
 
-    def train_step(self, batch=None, eps=None, sync=True):
+    def train_step(self, batch=None, eps=None, sync=True, probe=None):
         """One optimisation step (the body of the reference's hot loop, trainer/mfcctrainer.py:343-349).
         batch: (acoustic [N,36,48,12], mfcc [N,12], video [N,224,298,3], ...) or None to reuse the
         tensors already resident in the graph's input buffers.  Returns {mse, huber, latent, reg, loss}
@@ -183,9 +190,12 @@ class Trainer(object):
         g = self.primary if batch is None else self._graph_for(int(batch[1].reshape(-1, 12).shape[0]))
         if batch is not None:
             self._feed(g, batch, eps)
-        elif eps is not None:
-            g.eps.copy_(eps.reshape(g.N, Z), non_blocking=True)
-        g.plan_train.run()      # hooks inside fire the bucketed all-reduce when data-parallel
+        else:
+            self._noise(g, eps)
+        if probe is None:
+            g.plan_train.run()      # hooks inside fire the bucketed all-reduce when data-parallel
+        else:
+            g.plan_train.run_probed(probe[0], probe[1])
         store = self.session.store
         scale = 1.0
         if self.comm is not None and self.comm.enabled:
@@ -211,8 +221,8 @@ class Trainer(object):
         g = self.primary if batch is None else self._graph_for(int(batch[1].reshape(-1, 12).shape[0]))
         if batch is not None:
             self._feed(g, batch, eps)
-        elif eps is not None:
-            g.eps.copy_(eps.reshape(g.N, Z), non_blocking=True)
+        else:
+            self._noise(g, eps)
         g.plan_eval.run()
         mse = float(g.losses[0])
         ch = g.chan[:12].tolist()

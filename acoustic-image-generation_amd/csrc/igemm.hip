@@ -756,6 +756,16 @@ static int fwd_kiters(const AcimgConvDesc* d) {
     return (rowrun ? d->R : d->R * d->S) * cdiv(L, 32);
 }
 
+int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
+    if (!d || !out) return fail(ACIMG_EINVAL, "conv2d_fwd_tiling: null argument");
+    const int M = d->N * d->OH * d->OW;
+    TileCfg c = pick_cfg(M, d->K);
+    out[0] = c.bm;
+    out[1] = c.bn;
+    out[2] = pick_splits(M, d->K, c, fwd_kiters(d));
+    return ACIMG_OK;
+}
+
 size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d) {
     return igemm_ws_bytes(d->N * d->OH * d->OW, d->K, fwd_kiters(d));
 }

@@ -72,6 +72,8 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
                      float* y, const float* in_scale, const float* in_shift, int in_relu,
                      float* stats, void* ws, size_t ws_bytes, void* stream);
 int acimg_conv2d_stats_rows(const AcimgConvDesc* d);
+/* out[3] = {BM, BN, split-K factor} the forward launch will use (profiling / roofline bookkeeping) */
+int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out);
 size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d);
 
 /* Data gradient.  gy is the gradient w.r.t. the conv's PRE-activation output [N,OH,OW,K]

@@ -81,6 +81,7 @@ def forward(p, inputs, resnetfeature, eps, num_skip=1, embedding=False, end_poin
     conv1 = _c(p, "layer1/conv_2", c)
     pool1 = _c(p, "layer1/pool_2", conv1, stride=3)  # 3x3 s3 'same' on 36x48: no padding
     c = _c(p, "layer2/conv_1", pool1)
+    ep["layer2/conv_1"] = c
     conv2_0 = _c(p, "layer2/conv_2", c)
     ep.update(conv1=conv1, pool1=pool1, conv2_0=conv2_0)
     conv2 = tfsem.minmax_norm(conv2_0, (1, 2, 3))
@@ -104,16 +105,20 @@ def forward(p, inputs, resnetfeature, eps, num_skip=1, embedding=False, end_poin
     if num_skip == 2:
         net = torch.cat((net, conv2_0), dim=-1)
     c = _c(p, "layer4/conv_1", net)
+    ep["layer4/conv_1"] = c
     conv4 = _c(p, "layer4/conv_2", c)
     c = _c(p, "layer5/conv_1", conv4)
+    ep["layer5/conv_1"] = c
     conv5 = _c(p, "layer5/conv_2", c)
     up = tfsem.conv2d_transpose_valid(conv5, p[SCOPE + "/upsample_1/kernel"], p[SCOPE + "/upsample_1/bias"], 3)
     ep.update(conv4=conv4, conv5=conv5, upsample_1=up)
     if num_skip >= 1:
         up = torch.cat((up, conv1), dim=-1)
     c = _c(p, "layer6/conv_1", up)
+    ep["layer6/conv_1"] = c
     conv6 = _c(p, "layer6/conv_2", c)
     c = _c(p, "layer7/conv_1", conv6)
+    ep["layer7/conv_1"] = c
     conv7 = _c(p, "layer7/conv_2", c)
     out = _c(p, "final", conv7, act=torch.sigmoid)
     ep.update(conv6=conv6, conv7=conv7, output=out)
