@@ -80,12 +80,16 @@ def test_train_step_matches_oracle(device, num_skip, embedding):
         if step == 0:
             assert rel_err(g.modelac.network["features"], ep["features"]) < TOL, "145-ch feature map"
             grads = sess.store.grad_dict()
-            worst = ("", 0.0)
+            worst, worst_max = ("", 0.0), ("", 0.0)
             for k, gr in ref["grads"].items():
-                e = rel_err(grads[k], gr)
+                e = l2_err(grads[k], gr)
                 if e > worst[1]:
                     worst = (k, e)
-            assert worst[1] < 2e-3, "gradient %s rel err %.3e" % worst
+                e = rel_err(grads[k], gr)
+                if e > worst_max[1]:
+                    worst_max = (k, e)
+            assert worst[1] < TOL, "gradient %s rel L2 err %.3e" % worst
+            assert worst_max[1] < 3e-2, "gradient %s max-norm err %.3e" % worst_max
     # weights, Adam slots and BN moving statistics after 3 steps
     sd = sess.store.state_dict()
     worst = ("", 0.0)
