@@ -4,9 +4,10 @@ batch-norm moving statistics, and the evaluation pass.
 
 Tolerance (BASELINE.json north_star): outputs and losses within 1e-3 relative (max-norm, relative to
 the tensor's max magnitude).  Both sides compute in fp32 (the HIP path on exact-f32 MFMA), observed
-error ~1e-5.  Gradients are compared in relative L2 norm at 1e-3 plus a loose 3e-2 max-norm bound: a
-ReLU pre-activation within fp32 rounding of zero (observed: one element of 49k in `conv4`, 2.3e-7 vs
-0.0) legitimately takes the other subgradient and perturbs a handful of weight-gradient entries.
+error ~1e-5.  Gradients are held to the same 1e-3 (max-norm and L2) on an input whose ReLU masks agree
+exactly with the oracle's: a pre-activation within fp32 rounding of zero (observed with seed 99: one
+element of 49k in `conv4`, 2.3e-7 vs 0.0) legitimately takes the other subgradient, so the test counts
+mask flips, bounds their damage loosely, and demands strict parity on a flip-free seed.
 """
 import numpy as np
 import pytest
@@ -53,18 +54,37 @@ def build(device, num_skip, embedding, batch, lr=1e-3):
     return tr, orc, sess
 
 
-@pytest.mark.parametrize("num_skip,embedding", [(1, False), (2, False), (0, True)])
-def test_train_step_matches_oracle(device, num_skip, embedding):
+MASK_PAIRS = [("c11", "layer1/conv_1"), ("conv1", "conv1"), ("pool1", "pool1"), ("c21", "layer2/conv_1"),
+              ("conv2_0", "conv2_0"), ("dns", "dense"), ("net", "conv2d"), ("c41", "layer4/conv_1"), ("conv4", "conv4"),
+              ("c51", "layer5/conv_1"), ("conv5", "conv5"), ("c61", "layer6/conv_1"), ("conv6", "conv6"),
+              ("c71", "layer7/conv_1"), ("conv7", "conv7")]
+
+
+def relu_mask_flips(ma, ep):
+    """number of post-ReLU activations that are zero on one side and positive on the other (a
+    pre-activation within fp32 rounding of zero); every activation is also checked to 1e-3"""
+    flips = 0
+    for attr, key in MASK_PAIRS:
+        a = getattr(ma, attr)
+        t = a.t.cpu().reshape(a.N, a.H, a.W, -1)[..., a.off:a.off + a.C]
+        r = ep[key].detach()
+        assert rel_err(t, r) < TOL, "activation " + key
+        flips += int(((t > 0) != (r > 0)).sum())
+    return flips
+
+
+def run_case(device, num_skip, embedding, seed):
+    """returns True when the case ran with zero ReLU-mask flips and passed the strict gradient checks"""
     from oracle import trainer as otr
 
     B = 2
     tr, orc, sess = build(device, num_skip, embedding, B)
-    ac, mf, vid, eps = otr.synthetic_batch(B, seed=99)
+    ac, mf, vid, eps = otr.synthetic_batch(B, seed=seed)
     # state-dict round trip through the padded internal layouts is lossless
     sd = sess.store.state_dict()
     for k, v in orc.state_dict().items():
         assert torch.equal(sd[k], v.detach()), k
-
+    strict = True
     for step in range(3):
         ep = {}
         ref = orc.train_step(ac, mf, vid, eps, end_points=ep, keep_grads=True)
@@ -79,17 +99,23 @@ def test_train_step_matches_oracle(device, num_skip, embedding):
             assert rel_err(g.modelac.std, ref["std"]) < TOL, "std"
         if step == 0:
             assert rel_err(g.modelac.network["features"], ep["features"]) < TOL, "145-ch feature map"
+            flips = relu_mask_flips(g.modelac, ep)
+            strict = flips == 0
             grads = sess.store.grad_dict()
-            worst, worst_max = ("", 0.0), ("", 0.0)
+            worst, worst_l2 = ("", 0.0), ("", 0.0)
             for k, gr in ref["grads"].items():
-                e = l2_err(grads[k], gr)
+                e = rel_err(grads[k], gr)
                 if e > worst[1]:
                     worst = (k, e)
-                e = rel_err(grads[k], gr)
-                if e > worst_max[1]:
-                    worst_max = (k, e)
-            assert worst[1] < TOL, "gradient %s rel L2 err %.3e" % worst
-            assert worst_max[1] < 3e-2, "gradient %s max-norm err %.3e" % worst_max
+                e = l2_err(grads[k], gr)
+                if e > worst_l2[1]:
+                    worst_l2 = (k, e)
+            if strict:
+                assert worst[1] < TOL, "gradient %s max-norm err %.3e" % worst
+                assert worst_l2[1] < TOL, "gradient %s L2 err %.3e" % worst_l2
+            else:  # one subgradient differs: the damage must stay small and local
+                assert worst_l2[1] < 2e-2, "gradient %s L2 err %.3e with %d mask flips" % (worst_l2 + (flips,))
+                return False
     # weights, Adam slots and BN moving statistics after 3 steps
     sd = sess.store.state_dict()
     worst = ("", 0.0)
@@ -107,6 +133,17 @@ def test_train_step_matches_oracle(device, num_skip, embedding):
     for k in ("mse", "mse0", "mse1", "mse2", "mse3"):
         assert abs(gote[k] - refe[k]) <= TOL * refe[k], (k, gote[k], refe[k])
     assert rel_err(tr.primary.modelac.output, refe["output"]) < TOL
+    return True
+
+
+@pytest.mark.parametrize("num_skip,embedding", [(1, False), (2, False), (0, True)])
+def test_train_step_matches_oracle(device, num_skip, embedding):
+    """strict parity must hold on an input whose ReLU masks agree exactly with the oracle's (tries up to
+    three seeds; a seed with a flipped mask still has to stay within the loose bound)"""
+    for seed in (99, 100, 101):
+        if run_case(device, num_skip, embedding, seed):
+            return
+    pytest.fail("no seed without ReLU-mask flips among 3")
 
 
 def test_partial_batch_and_device_noise(device):
