@@ -80,7 +80,7 @@ def init_params(seed=1238, dtype=torch.float32, randomize_bn=False):
     return p
 
 
-def _conv_bn(p, scope, x, stride, training, relu, updates, padding=None):
+def _conv_bn(p, scope, x, stride, training, relu, updates, padding=None, mask=None):
     w = p[scope + "/weights"]
     if padding == "VALID":
         y = tfsem.conv2d(x, w, None, stride, "VALID")
@@ -94,10 +94,12 @@ def _conv_bn(p, scope, x, stride, training, relu, updates, padding=None):
     if training:
         updates[b + "moving_mean"] = mm
         updates[b + "moving_variance"] = mv
+    if relu and mask is not None:
+        return y * mask.to(y.dtype)   # ReLU pattern of the implementation under test (see unet_acresnet._relu)
     return torch.relu(y) if relu else y
 
 
-def forward(p, images, training, end_points=None):
+def forward(p, images, training, end_points=None, feat_mask=None):
     """images [N,224,298,3] -> features [N,12,16,12]; returns (features, moving-stat updates).
     Gradients flow only from conv_map on (the trunk is not in var_list, mfcctrainer.py:64): the trunk
     runs under no_grad."""
@@ -118,7 +120,7 @@ def forward(p, images, training, end_points=None):
             r = _conv_bn(p, scope + "/conv3", r, 1, training, False, updates)
             net = torch.relu(shortcut + r)
             ep[scope] = net
-    net = _conv_bn(p, SCOPE + "/conv_map", net, 1, training, True, updates, padding="VALID")
+    net = _conv_bn(p, SCOPE + "/conv_map", net, 1, training, True, updates, padding="VALID", mask=feat_mask)
     ep[SCOPE + "/conv_map"] = net
     return net, updates
 

@@ -49,12 +49,13 @@ class Oracle(object):
         d.update(self.gen)
         return d
 
-    def forward(self, video, mfcc, eps, training, end_points=None):
+    def forward(self, video, mfcc, eps, training, end_points=None, relu_masks=None):
         n = mfcc.shape[0]
         mfccmap = mfcc.reshape(n, 1, 1, 12).expand(n, 36, 48, 12).contiguous()
-        feat, updates = resnet50.forward(self.res, video, training, end_points)
+        rm = relu_masks or {}
+        feat, updates = resnet50.forward(self.res, video, training, end_points, feat_mask=rm.get("conv_map"))
         mean, std, out = unet_acresnet.forward(self.gen, mfccmap, feat, eps, self.num_skip,
-                                               self.embedding, end_points)
+                                               self.embedding, end_points, relu_masks=relu_masks)
         return mean, std, out, updates
 
     def losses(self, acoustic, mean, std, out):
@@ -73,14 +74,16 @@ class Oracle(object):
             total = total + lat
         return OrderedDict(mse=mse, huber=hub, latent=lat, reg=reg, loss=total)
 
-    def train_step(self, acoustic, mfcc, video, eps, end_points=None, keep_grads=False):
-        """one optimisation step; returns dict of python floats (+ tensors when asked)"""
+    def train_step(self, acoustic, mfcc, video, eps, end_points=None, keep_grads=False, relu_masks=None):
+        """one optimisation step; returns dict of python floats (+ tensors when asked).
+        relu_masks: {layer: bool tensor} ReLU on/off patterns taken from the implementation under test
+        (parity tests only; see unet_acresnet._relu)."""
         leaves = []
         for k in self.train_names:
             t = self._get(k).detach().clone().requires_grad_(True)
             self._set(k, t)
             leaves.append(t)
-        mean, std, out, updates = self.forward(video, mfcc, eps, True, end_points)
+        mean, std, out, updates = self.forward(video, mfcc, eps, True, end_points, relu_masks)
         L = self.losses(acoustic, mean, std, out)
         grads = torch.autograd.grad(L["loss"], leaves, allow_unused=True)
         self.step += 1

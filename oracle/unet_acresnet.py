@@ -67,14 +67,39 @@ def init_params(seed=1239, num_skip=1, embedding=False, dtype=torch.float32, bia
     return p
 
 
-def _c(p, name, x, stride=1, padding="SAME", act=torch.relu):
+_MASKS = None  # see forward(relu_masks=...)
+
+
+def _relu(name, y):
+    """ReLU; with a mask override the on/off pattern comes from the implementation under test, so that
+    both sides differentiate the SAME piecewise-linear function (a pre-activation within fp32 rounding
+    of zero otherwise picks a different, equally valid, subgradient).  Values are unaffected beyond
+    that rounding."""
+    if _MASKS is not None and name in _MASKS:
+        return y * _MASKS[name].to(y.dtype)
+    return torch.relu(y)
+
+
+def _c(p, name, x, stride=1, padding="SAME", act="relu"):
     y = tfsem.conv2d(x, p["%s/%s/kernel" % (SCOPE, name)], p["%s/%s/bias" % (SCOPE, name)], stride, padding)
+    if act == "relu":
+        return _relu(name, y)
     return act(y) if act is not None else y
 
 
-def forward(p, inputs, resnetfeature, eps, num_skip=1, embedding=False, end_points=None):
+def forward(p, inputs, resnetfeature, eps, num_skip=1, embedding=False, end_points=None, relu_masks=None):
     """inputs: tiled MFCC map [N,36,48,12]; resnetfeature [N,12,16,12]; eps [N,150] stands in for
-    tf.random_normal (:77).  Returns (mean, std, output) or (z, None, output) when embedding."""
+    tf.random_normal (:77).  Returns (mean, std, output) or (z, None, output) when embedding.
+    relu_masks: optional {layer name: bool tensor} ReLU on/off patterns (see _relu)."""
+    global _MASKS
+    _MASKS = relu_masks
+    try:
+        return _forward(p, inputs, resnetfeature, eps, num_skip, embedding, end_points)
+    finally:
+        _MASKS = None
+
+
+def _forward(p, inputs, resnetfeature, eps, num_skip, embedding, end_points):
     ep = end_points if end_points is not None else {}
     c = _c(p, "layer1/conv_1", inputs)
     ep["layer1/conv_1"] = c
@@ -98,7 +123,7 @@ def forward(p, inputs, resnetfeature, eps, num_skip=1, embedding=False, end_poin
         std = F.softplus(_c(p, "std", conv2, padding="VALID", act=None)).reshape(n, Z)
         z = mean + std * eps
     ep["z"] = z
-    net = torch.relu(z @ p[SCOPE + "/dense/kernel"] + p[SCOPE + "/dense/bias"]).reshape(n, 12, 16, 12)
+    net = _relu("dense", (z @ p[SCOPE + "/dense/kernel"] + p[SCOPE + "/dense/bias"]).reshape(n, 12, 16, 12))
     ep["dense"] = net
     net = _c(p, "conv2d", net)
     ep["conv2d"] = net

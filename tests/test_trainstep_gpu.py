@@ -4,10 +4,11 @@ batch-norm moving statistics, and the evaluation pass.
 
 Tolerance (BASELINE.json north_star): outputs and losses within 1e-3 relative (max-norm, relative to
 the tensor's max magnitude).  Both sides compute in fp32 (the HIP path on exact-f32 MFMA), observed
-error ~1e-5.  Gradients are held to the same 1e-3 (max-norm and L2) on an input whose ReLU masks agree
-exactly with the oracle's: a pre-activation within fp32 rounding of zero (observed with seed 99: one
-element of 49k in `conv4`, 2.3e-7 vs 0.0) legitimately takes the other subgradient, so the test counts
-mask flips, bounds their damage loosely, and demands strict parity on a flip-free seed.
+error ~1e-5.  Gradients are held to the same 1e-3 (max-norm and L2).  A ReLU pre-activation within fp32
+rounding of zero (a few of the 2.5 M per step; e.g. `conv4`: 2.3e-7 here vs 0.0 in the oracle) picks a
+different but equally valid subgradient, so for the BACKWARD comparison the oracle takes the ReLU on/off
+patterns from the HIP run (both sides then differentiate the same piecewise-linear function); forward
+values are compared independently and the number of such flips is printed.
 """
 import numpy as np
 import pytest
@@ -54,54 +55,65 @@ def build(device, num_skip, embedding, batch, lr=1e-3):
     return tr, orc, sess
 
 
-MASK_PAIRS = [("c11", "layer1/conv_1"), ("conv1", "conv1"), ("pool1", "pool1"), ("c21", "layer2/conv_1"),
-              ("conv2_0", "conv2_0"), ("dns", "dense"), ("net", "conv2d"), ("c41", "layer4/conv_1"), ("conv4", "conv4"),
-              ("c51", "layer5/conv_1"), ("conv5", "conv5"), ("c61", "layer6/conv_1"), ("conv6", "conv6"),
-              ("c71", "layer7/conv_1"), ("conv7", "conv7")]
+MASK_PAIRS = [("c11", "layer1/conv_1"), ("conv1", "layer1/conv_2"), ("pool1", "layer1/pool_2"),
+              ("c21", "layer2/conv_1"), ("conv2_0", "layer2/conv_2"), ("dns", "dense"), ("net", "conv2d"),
+              ("c41", "layer4/conv_1"), ("conv4", "layer4/conv_2"), ("c51", "layer5/conv_1"),
+              ("conv5", "layer5/conv_2"), ("c61", "layer6/conv_1"), ("conv6", "layer6/conv_2"),
+              ("c71", "layer7/conv_1"), ("conv7", "layer7/conv_2")]
+EP_KEYS = {"layer1/conv_2": "conv1", "layer1/pool_2": "pool1", "layer2/conv_2": "conv2_0", "layer4/conv_2": "conv4",
+           "layer5/conv_2": "conv5", "layer6/conv_2": "conv6", "layer7/conv_2": "conv7"}
 
 
-def relu_mask_flips(ma, ep):
-    """number of post-ReLU activations that are zero on one side and positive on the other (a
-    pre-activation within fp32 rounding of zero); every activation is also checked to 1e-3"""
-    flips = 0
+def saved_activations(g):
+    """{oracle layer name: post-ReLU activation saved by the HIP forward} (+ the ResNet feature)"""
+    out = {}
     for attr, key in MASK_PAIRS:
-        a = getattr(ma, attr)
-        t = a.t.cpu().reshape(a.N, a.H, a.W, -1)[..., a.off:a.off + a.C]
-        r = ep[key].detach()
-        assert rel_err(t, r) < TOL, "activation " + key
-        flips += int(((t > 0) != (r > 0)).sum())
-    return flips
+        a = getattr(g.modelac, attr)
+        out[key] = a.t.cpu().reshape(a.N, a.H, a.W, -1)[..., a.off:a.off + a.C]
+    out["conv_map"] = g.modelimages.output.cpu()
+    return out
 
 
-def run_case(device, num_skip, embedding, seed):
-    """returns True when the case ran with zero ReLU-mask flips and passed the strict gradient checks"""
+@pytest.mark.parametrize("num_skip,embedding", [(1, False), (2, False), (0, True)])
+def test_train_step_matches_oracle(device, num_skip, embedding):
     from oracle import trainer as otr
 
     B = 2
     tr, orc, sess = build(device, num_skip, embedding, B)
-    ac, mf, vid, eps = otr.synthetic_batch(B, seed=seed)
+    ac, mf, vid, eps = otr.synthetic_batch(B, seed=99)
     # state-dict round trip through the padded internal layouts is lossless
     sd = sess.store.state_dict()
     for k, v in orc.state_dict().items():
         assert torch.equal(sd[k], v.detach()), k
-    strict = True
+    total_flips = 0
     for step in range(3):
-        ep = {}
-        ref = orc.train_step(ac, mf, vid, eps, end_points=ep, keep_grads=True)
         got = tr.train_step((ac, mf, vid), eps=eps)
+        g = tr.primary
+        acts = saved_activations(g)
+        grads = sess.store.grad_dict() if step == 0 else None
+        # the oracle differentiates with the HIP run's ReLU on/off patterns (identical function on both
+        # sides); its forward VALUES are still its own and are compared below
+        masks = dict((k, v > 0) for k, v in acts.items())
+        ep = {}
+        ref = orc.train_step(ac, mf, vid, eps, end_points=ep, keep_grads=True, relu_masks=masks)
         for k in ("mse", "huber", "latent", "reg", "loss"):
             assert abs(got[k] - ref[k]) <= TOL * max(abs(ref[k]), 1e-8), (step, k, got[k], ref[k])
-        g = tr.primary
-        assert rel_err(g.modelimages.output, ep["resnet_v1_50/conv_map"]) < TOL, "resnet feature"
+        assert rel_err(acts["conv_map"], ep["resnet_v1_50/conv_map"]) < TOL, "resnet feature"
         assert rel_err(g.modelac.output, ref["output"]) < TOL, "generated image"
         assert rel_err(g.modelac.mean, ref["mean"]) < TOL, "mean"
         if not embedding:
             assert rel_err(g.modelac.std, ref["std"]) < TOL, "std"
         if step == 0:
             assert rel_err(g.modelac.network["features"], ep["features"]) < TOL, "145-ch feature map"
-            flips = relu_mask_flips(g.modelac, ep)
-            strict = flips == 0
-            grads = sess.store.grad_dict()
+            for _, key in MASK_PAIRS:
+                r = ep[EP_KEYS.get(key, key)].detach()
+                assert rel_err(acts[key], r) < TOL, "activation " + key
+            # how many ReLU outputs would have taken the other branch under a free-running oracle
+            free = {}
+            orc2 = otr.Oracle(num_skip=num_skip, embedding=embedding, randomize=True)
+            orc2.forward(vid, mf, eps, True, free)
+            for _, key in MASK_PAIRS:
+                total_flips += int(((acts[key] > 0) != (free[EP_KEYS.get(key, key)] > 0)).sum())
             worst, worst_l2 = ("", 0.0), ("", 0.0)
             for k, gr in ref["grads"].items():
                 e = rel_err(grads[k], gr)
@@ -110,12 +122,9 @@ def run_case(device, num_skip, embedding, seed):
                 e = l2_err(grads[k], gr)
                 if e > worst_l2[1]:
                     worst_l2 = (k, e)
-            if strict:
-                assert worst[1] < TOL, "gradient %s max-norm err %.3e" % worst
-                assert worst_l2[1] < TOL, "gradient %s L2 err %.3e" % worst_l2
-            else:  # one subgradient differs: the damage must stay small and local
-                assert worst_l2[1] < 2e-2, "gradient %s L2 err %.3e with %d mask flips" % (worst_l2 + (flips,))
-                return False
+            assert worst[1] < TOL, "gradient %s max-norm err %.3e" % worst
+            assert worst_l2[1] < TOL, "gradient %s L2 err %.3e" % worst_l2
+    print("ReLU outputs within rounding of zero (mask flips vs free-running oracle): %d" % total_flips)
     # weights, Adam slots and BN moving statistics after 3 steps
     sd = sess.store.state_dict()
     worst = ("", 0.0)
@@ -126,24 +135,13 @@ def run_case(device, num_skip, embedding, seed):
     assert worst[1] < TOL, "variable %s rel err %.3e after 3 steps" % worst
     m = sess.store.slot_dict("m")
     for k in orc.train_names:
-        assert l2_err(m[k], orc.m[k]) < 2e-3, "adam m " + k
+        assert l2_err(m[k], orc.m[k]) < TOL, "adam m " + k
     # evaluation pass (BN inference mode)
     refe = orc.eval_step(ac, mf, vid, eps)
     gote = tr.eval_step((ac, mf, vid), eps=eps)
     for k in ("mse", "mse0", "mse1", "mse2", "mse3"):
         assert abs(gote[k] - refe[k]) <= TOL * refe[k], (k, gote[k], refe[k])
     assert rel_err(tr.primary.modelac.output, refe["output"]) < TOL
-    return True
-
-
-@pytest.mark.parametrize("num_skip,embedding", [(1, False), (2, False), (0, True)])
-def test_train_step_matches_oracle(device, num_skip, embedding):
-    """strict parity must hold on an input whose ReLU masks agree exactly with the oracle's (tries up to
-    three seeds; a seed with a flipped mask still has to stay within the loose bound)"""
-    for seed in (99, 100, 101):
-        if run_case(device, num_skip, embedding, seed):
-            return
-    pytest.fail("no seed without ReLU-mask flips among 3")
 
 
 def test_partial_batch_and_device_noise(device):
