@@ -190,6 +190,20 @@ class ParamStore(object):
             loaded.append(name)
         return loaded
 
+    def load_slots(self, m_state, v_state):
+        """Adam slot variables from TF-named dicts (checkpoint resume / parity tests)"""
+        for which, state, buf in (("m", m_state, self.adam_m), ("v", v_state, self.adam_v)):
+            fused_internal = set()
+            for h in self.fused:
+                fused_internal.update((h.kernel.name, h.bias.name))
+                if all(n in state for n in h.tf_names):
+                    k, b = h.pack(state)
+                    self._view(buf, h.kernel).copy_(k.to(self.device))
+                    self._view(buf, h.bias).copy_(b.to(self.device))
+            for name, v in self.vars.items():
+                if v.group == "train" and name not in fused_internal and name in state:
+                    self._view(buf, v).copy_(v.pack(state[name]).to(self.device))
+
     def _export(self, getter):
         out = OrderedDict()
         fused_internal = set()
