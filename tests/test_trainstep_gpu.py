@@ -147,7 +147,7 @@ def test_train_step_matches_oracle(device, num_skip, embedding):
         for k in orc.train_names:
             p2, m2, v2 = tf_adam_fp64(before[k], grads[k], m0[k], v0[k], orc.step, lr)
             assert float((after[k].double() - p2).abs().max()) <= 2e-6 * max(float(p2.abs().max()), 1e-3), "adam p " + k
-            assert rel_err(m1[k], m2) < 1e-5 and rel_err(v1[k], v2) < 1e-5, "adam slots " + k
+            assert rel_err(m1[k], m2) < 1e-4 and rel_err(v1[k], v2) < 1e-4, "adam slots " + k
             # and stays within a fraction of one step of the oracle's weights
             assert float((after[k].double() - osd[k].detach().double()).abs().max()) <= 0.5 * lr, "vs oracle " + k
         for k, v in osd.items():
