@@ -83,6 +83,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime (libamdhip64.so.7).  Import it FIRST so libacimg.so
+    # binds to that same runtime instance: device pointers and hipStream_t handles are shared between
+    # torch (allocator, streams) and our kernels, which only works inside one runtime.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise AcimgError(
             "libacimg.so not found at %s: build the HIP extension first "
