@@ -7,21 +7,36 @@ namespace acimg {
 
 // ------------------------------------------------------------------------------------------
 // batch-norm statistics -> scale/shift (+ moving averages)
-// block = 256 threads = 8 row groups x 32 channels
+// block = 1024 threads = 32 row groups x 32 channels; 4 independent partial sums per thread keep
+// several loads in flight (the partials are tiny, the kernel is pure load latency)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float* stats, int rows, int C, int ld, double count, const float* gamma, const float* beta,
     float* moving_mean, float* moving_var, float decay, float eps, int training, float* scale,
     float* shift, float* save_mean, float* save_invstd) {
-    __shared__ double red[2][8][32];
+    __shared__ double red[2][32][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (training && c < C) {
-        for (int r = rg; r < rows; r += 8) {
-            s1 += (double)stats[((long)r * 2 + 0) * ld + c];
-            s2 += (double)stats[((long)r * 2 + 1) * ld + c];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        int r = rg;
+        for (; r + 96 < rows; r += 128) {
+            a0 += stats[((long)r * 2 + 0) * ld + c];
+            b0 += stats[((long)r * 2 + 1) * ld + c];
+            a1 += stats[((long)(r + 32) * 2 + 0) * ld + c];
+            b1 += stats[((long)(r + 32) * 2 + 1) * ld + c];
+            a2 += stats[((long)(r + 64) * 2 + 0) * ld + c];
+            b2 += stats[((long)(r + 64) * 2 + 1) * ld + c];
+            a3 += stats[((long)(r + 96) * 2 + 0) * ld + c];
+            b3 += stats[((long)(r + 96) * 2 + 1) * ld + c];
         }
+        for (; r < rows; r += 32) {
+            a0 += stats[((long)r * 2 + 0) * ld + c];
+            b0 += stats[((long)r * 2 + 1) * ld + c];
+        }
+        s1 = ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+        s2 = ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
     }
     red[0][rg][cl] = s1;
     red[1][rg][cl] = s2;
@@ -31,7 +46,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     if (training) {
         s1 = 0.0;
         s2 = 0.0;
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 32; ++i) {
             s1 += red[0][i][cl];
             s2 += red[1][i][cl];
         }
@@ -546,7 +561,7 @@ int acimg_bn_finalize(const float* stats, int rows, int C, int ldstats, double c
                       float* shift, float* save_mean, float* save_invstd, void* stream) {
     if (C <= 0 || (training && (!stats || rows <= 0 || count <= 0)) || (!training && (!moving_mean || !moving_var)))
         return fail(ACIMG_EINVAL, "bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, stats,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, stats,
                        rows, C, ldstats, count, gamma, beta, moving_mean, moving_var, decay, eps,
                        training, scale, shift, save_mean, save_invstd);
     return check_launch("bn_finalize");

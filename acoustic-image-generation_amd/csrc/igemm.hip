@@ -12,340 +12,9 @@
 // staged [k][n] (NN, ds_read_b32) or [n][k] (NT, ds_read_b128).  The k order inside a 16-deep step
 // is permuted identically for A and B (lane group g owns k = 4g..4g+3), which leaves the sum
 // unchanged.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t.
-#include "igemm.hpp"
+#include "igemm_kernel.hpp"
 
 namespace acimg {
-
-// ------------------------------------------------------------------------------------------
-// epilogue helpers (shared by the GEMM kernel and the split-K reducer)
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ long epi_row_pix(const EpiParams& e, int m) {
-    if (!e.scatter) return m;
-    const int hw = e.AH * e.AW;
-    const int img = m / hw;
-    const int rem = m - img * hw;
-    const int h = rem / e.AW;
-    const int w = rem - h * e.AW;
-    return ((long)img * e.YH + (long)e.sc * h) * e.YW + (long)e.sc * w;
-}
-__device__ __forceinline__ void epi_col(const EpiParams& e, int n, int& cn, int& pixoff) {
-    if (!e.scatter) {
-        cn = n;
-        pixoff = 0;
-    } else {
-        const int t = n / e.Ko;
-        cn = n - t * e.Ko;
-        const int r = t / e.Sq;
-        const int q = t - r * e.Sq;
-        pixoff = r * e.YW + q;
-    }
-}
-__device__ __forceinline__ void epi_store(const EpiParams& e, long opix, int cn, float v) {
-    if (e.bias) v += e.bias[cn];
-    if (e.res) v += e.res[opix * e.ldres + cn];
-    if (e.act == ACIMG_ACT_RELU)
-        v = fmaxf(v, 0.f);
-    else if (e.act == ACIMG_ACT_SIGMOID)
-        v = 1.f / (1.f + expf(-v));
-    if (e.mask && !(e.mask[opix * e.ldmask + cn] > 0.f)) v = 0.f;
-    e.Y[opix * e.ldy + cn] = v;
-}
-
-// ------------------------------------------------------------------------------------------
-// main implicit-GEMM kernel
-// ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, bool B_NT>
-__global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
-    constexpr int BK = 32;
-    constexpr int LDA_S = BK + 4;
-    constexpr int LDB_S = B_NT ? (BK + 4) : (BN + 4);
-    constexpr int A_ELEMS = BM * LDA_S;
-    constexpr int WTM = BM / WGM, WTN = BN / WGN;
-    constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int KQ = BK / 4;          // float4 per A row
-    constexpr int RPP = 256 / KQ;       // rows per pass (32)
-    constexpr int NA = BM / RPP;        // A float4 per thread
-    constexpr int NBT = (BN + RPP - 1) / RPP;           // B float4 per thread (NT)
-    constexpr int NQ = BN / 4;                          // float4 per B row (NN)
-    constexpr int RPPB = 256 / NQ;                      // B rows per pass (NN)
-    constexpr int NBN = (BK + RPPB - 1) / RPPB;         // B float4 per thread (NN)
-    constexpr int NB = B_NT ? NBT : NBN;
-    static_assert(WGM * WGN == 4, "4 waves");
-    static_assert(BM % RPP == 0, "BM multiple of 32");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Bs = smem + A_ELEMS;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    const int wm = wid / WGN, wn = wid % WGN;
-    const int li = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-
-    // ---- K range of this split -----------------------------------------------------------
-    int it_begin = 0, it_end = p.kiters;
-    if (p.splits > 1) {
-        const int per = (p.kiters + p.splits - 1) / p.splits;
-        it_begin = blockIdx.z * per;
-        it_end = min(p.kiters, it_begin + per);
-    }
-
-    // ---- per-thread A row bookkeeping ------------------------------------------------------
-    const int kq = tid % KQ;
-    const int arow0 = tid / KQ;
-    int a_pix[NA], a_ih0[NA], a_iw0[NA];
-    {
-        const int ohw = p.OH * p.OW;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int m = m0 + arow0 + j * RPP;
-            if (m < p.M) {
-                const int img = m / ohw;
-                const int rem = m - img * ohw;
-                const int oh = rem / p.OW;
-                const int ow = rem - oh * p.OW;
-                a_ih0[j] = oh * p.stride - p.pad_t;
-                a_iw0[j] = ow * p.stride - p.pad_l;
-                a_pix[j] = (img * p.H + a_ih0[j]) * p.W + a_iw0[j];
-            } else {
-                a_ih0[j] = -(1 << 28);
-                a_iw0[j] = -(1 << 28);
-                a_pix[j] = 0;
-            }
-        }
-    }
-
-    float4 ra[NA], rb[NB];
-
-    auto load_tiles = [&](int it) {
-        const int seg = it / p.cps;
-        const int chunk = it - seg * p.cps;
-        const int pp = chunk * BK + kq * 4;  // position of this thread's float4 inside the segment
-        const bool validk = pp < p.L;
-        int r, s, c;
-        if (p.rowrun) {
-            r = seg;
-            s = pp / p.C;
-            c = pp - s * p.C;
-        } else {
-            r = seg / p.S;
-            s = seg - r * p.S;
-            c = pp;
-        }
-        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        const bool affine = p.a_scale != nullptr;
-        if (affine && validk) {
-            sc4 = *reinterpret_cast<const float4*>(p.a_scale + c);
-            sh4 = *reinterpret_cast<const float4*>(p.a_shift + c);
-        }
-        const int rwoff = r * p.W + s;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int ih = a_ih0[j] + r, iw = a_iw0[j] + s;
-            const bool ok = validk && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(p.A + (long)(a_pix[j] + rwoff) * p.lda + c);
-                if (affine) {
-                    v.x = v.x * sc4.x + sh4.x;
-                    v.y = v.y * sc4.y + sh4.y;
-                    v.z = v.z * sc4.z + sh4.z;
-                    v.w = v.w * sc4.w + sh4.w;
-                    if (p.a_relu) {
-                        v.x = fmaxf(v.x, 0.f);
-                        v.y = fmaxf(v.y, 0.f);
-                        v.z = fmaxf(v.z, 0.f);
-                        v.w = fmaxf(v.w, 0.f);
-                    }
-                }
-            }
-            ra[j] = v;
-        }
-        if constexpr (B_NT) {
-            const int tap = p.rowrun ? (seg * p.S + s) : seg;
-            const int tapb = p.flip ? (p.ntaps - 1 - tap) : tap;
-            const float* bbase = p.B + (long)tapb * p.tap_stride + c;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int nrow = arow0 + j * RPP;
-                const int n = n0 + nrow;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (validk && nrow < BN && n < p.Ngemm)
-                    v = *reinterpret_cast<const float4*>(bbase + (long)n * p.ldb);
-                rb[j] = v;
-            }
-        } else {
-            const int nq = tid % NQ;
-            const int krow0 = tid / NQ;
-            const int n = n0 + nq * 4;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int krow = krow0 + j * RPPB;
-                const int pb = chunk * BK + krow;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (krow < BK && pb < p.L && n < p.Nld)
-                    v = *reinterpret_cast<const float4*>(p.B + ((long)seg * p.L + pb) * p.ldb + n);
-                rb[j] = v;
-            }
-        }
-    };
-
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int j = 0; j < NA; ++j)
-            *reinterpret_cast<float4*>(&As[(arow0 + j * RPP) * LDA_S + kq * 4]) = ra[j];
-        if constexpr (B_NT) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int nrow = arow0 + j * RPP;
-                if (nrow < BN) *reinterpret_cast<float4*>(&Bs[nrow * LDB_S + kq * 4]) = rb[j];
-            }
-        } else {
-            const int nq = tid % NQ;
-            const int krow0 = tid / NQ;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int krow = krow0 + j * RPPB;
-                if (krow < BK) *reinterpret_cast<float4*>(&Bs[krow * LDB_S + nq * 4]) = rb[j];
-            }
-        }
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (it_begin < it_end) {
-        load_tiles(it_begin);
-        store_tiles();
-    }
-    __syncthreads();
-
-    for (int it = it_begin; it < it_end; ++it) {
-        const bool more = (it + 1) < it_end;
-        if (more) load_tiles(it + 1);
-
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            float4 a4[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a4[i] = *reinterpret_cast<const float4*>(
-                    &As[(wm * WTM + i * 16 + li) * LDA_S + kk * 16 + 4 * g]);
-            float bf[TN][4];
-            if constexpr (B_NT) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(
-                        &Bs[(wn * WTN + j * 16 + li) * LDB_S + kk * 16 + 4 * g]);
-                    bf[j][0] = b4.x;
-                    bf[j][1] = b4.y;
-                    bf[j][2] = b4.z;
-                    bf[j][3] = b4.w;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        bf[j][t] = Bs[(kk * 16 + 4 * g + t) * LDB_S + wn * WTN + j * 16 + li];
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float av = t == 0 ? a4[i].x : (t == 1 ? a4[i].y : (t == 2 ? a4[i].z : a4[i].w));
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[j][t], acc[i][j], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();
-        if (more) {
-            store_tiles();
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue -----------------------------------------------------------------------------
-    if (p.splits > 1) {
-        float* slab = p.slab + (long)blockIdx.z * p.M * p.slab_ld;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int m = m0 + wm * WTM + i * 16 + g * 4 + rg;
-                if (m >= p.M) continue;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wn * WTN + j * 16 + li;
-                    if (n < p.Ngemm) slab[(long)m * p.slab_ld + n] = acc[i][j][rg];
-                }
-            }
-        return;
-    }
-
-    const EpiParams& e = p.e;
-    int cn[TN], pixoff[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) epi_col(e, n0 + wn * WTN + j * 16 + li, cn[j], pixoff[j]);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int m = m0 + wm * WTM + i * 16 + g * 4 + rg;
-            if (m >= e.M) continue;
-            const long rp = epi_row_pix(e, m);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WTN + j * 16 + li;
-                if (n < e.Nstore) epi_store(e, rp + pixoff[j], cn[j], acc[i][j][rg]);
-            }
-        }
-
-    if (e.stats) {
-        // column sums / sums of squares of the raw accumulators of this row block.  Rows >= M
-        // were zero-filled on load, so they add nothing.
-        __syncthreads();  // everyone is done with As/Bs
-        float* red = smem;  // [WGM][2][BN]
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const float v = acc[i][j][rg];
-                    s1 += v;
-                    s2 += v * v;
-                }
-            s1 += __shfl_xor(s1, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 16, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (g == 0) {
-                const int col = wn * WTN + j * 16 + li;
-                red[(wm * 2 + 0) * BN + col] = s1;
-                red[(wm * 2 + 1) * BN + col] = s2;
-            }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < 2 * BN; idx += 256) {
-            const int which = idx / BN, col = idx - which * BN;
-            const int n = n0 + col;
-            if (n < e.stats_ld) {
-                float s = 0.f;
-#pragma unroll
-                for (int w = 0; w < WGM; ++w) s += red[(w * 2 + which) * BN + col];
-                e.stats[((long)blockIdx.x * 2 + which) * e.stats_ld + n] = s;
-            }
-        }
-    }
-}
 
 // split-K reducer: sums the slabs and runs the epilogue
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float* slab, int splits,
@@ -544,6 +213,40 @@ __global__ void colsum_final_kernel(const float* partial, int parts, int ncols, 
     out[col] = s;
 }
 
+// per-256-row-block column sums / sums of squares of y[M][K] (pixel stride ldy) -> stats[blk][2][ld]:
+// the batch-norm partials for convs that ran split-K (their epilogue never sees a full accumulator)
+__global__ __launch_bounds__(256) void partial_stats_kernel(const float* y, int ldy, int M, int K,
+                                                            float* stats, int ld) {
+    __shared__ float red[2][8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * 256;
+    const int r1 = min(M, r0 + 256);
+    for (int cb = 0; cb < K; cb += 32) {
+        const int c = cb + cl;
+        float s1 = 0.f, s2 = 0.f;
+        if (c < K)
+            for (int r = r0 + rg; r < r1; r += 8) {
+                const float v = y[(long)r * ldy + c];
+                s1 += v;
+                s2 += v * v;
+            }
+        red[0][rg][cl] = s1;
+        red[1][rg][cl] = s2;
+        __syncthreads();
+        if (rg == 0 && c < K) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                a += red[0][i][cl];
+                b += red[1][i][cl];
+            }
+            stats[((long)blockIdx.x * 2 + 0) * ld + c] = a;
+            stats[((long)blockIdx.x * 2 + 1) * ld + c] = b;
+        }
+        __syncthreads();
+    }
+}
+
 // writes bias to the output positions of a kernel<stride transposed conv that no patch covers
 __global__ __launch_bounds__(256) void deconv_gap_fill_kernel(float* y, int ldy, const float* bias,
                                                               long pixels, int OH, int OW, int K,
@@ -594,15 +297,22 @@ static size_t igemm_ws_bytes(int M, int Ngemm, int kiters) {
     return (size_t)s * M * ld * sizeof(float);
 }
 
-template <int BM, int BN, int WGM, int WGN, bool NT>
-static void launch_cfg(const IgemmParams& p, dim3 grid, hipStream_t st) {
+template <int BM, int BN, int WGM, int WGN, int NTHR>
+static void launch_cfg(const IgemmParams& p, bool nt, bool cal, dim3 grid, hipStream_t st) {
     constexpr int BK = 32;
     constexpr int a_elems = BM * (BK + 4);
-    constexpr int b_elems = NT ? BN * (BK + 4) : BK * (BN + 4);
-    constexpr int stat_elems = WGM * 2 * BN;
-    constexpr int elems = (a_elems + b_elems) > stat_elems ? (a_elems + b_elems) : stat_elems;
-    hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, NT>), grid, dim3(256),
-                       elems * sizeof(float), st, p);
+    constexpr int bnt = BN * (BK + 4), bnn = BK * (BN + 4);
+    const int stage = a_elems + (nt ? bnt : bnn);
+    const int stat_elems = WGM * 2 * BN;
+    const int elems = 2 * stage > stat_elems ? 2 * stage : stat_elems;
+    const size_t shm = (size_t)elems * sizeof(float);
+    if (nt) {
+        if (cal) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, NTHR, true, true>), grid, dim3(NTHR), shm, st, p);
+        else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, NTHR, true, false>), grid, dim3(NTHR), shm, st, p);
+    } else {
+        if (cal) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, NTHR, false, true>), grid, dim3(NTHR), shm, st, p);
+        else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, NTHR, false, false>), grid, dim3(NTHR), shm, st, p);
+    }
 }
 
 static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -615,9 +325,29 @@ static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipSt
     p.cps = cdiv(p.L, 32);
     p.kiters = nseg * p.cps;
     p.ntaps = p.R * p.S;
+    const bool cal = (p.C % 32) == 0;
+    // buffer descriptors: extents of A (gathered NHWC tensor) and B
+    const long nimg = p.M / ((long)p.OH * p.OW);
+    const long a_bytes = ((nimg * p.H * p.W - 1) * p.lda + p.C) * 4;
+    const long b_bytes = nt ? (((long)(p.ntaps - 1) * p.tap_stride + (long)(p.Ngemm - 1) * p.ldb + p.C) * 4)
+                            : ((long)p.R * p.S * p.C * p.ldb * 4);
+    if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31) || a_bytes <= 0 || b_bytes <= 0)
+        return fail(ACIMG_EINVAL, "igemm: operand extent %ld / %ld bytes outside (0, 2 GiB)", a_bytes, b_bytes);
+    p.a_bytes = (unsigned)a_bytes;
+    p.b_bytes = (unsigned)b_bytes;
+    EpiParams& e = p.e;
+    e.vec = aligned16(e.Y) && (e.ldy & 3) == 0 && (!e.bias || aligned16(e.bias)) &&
+            (!e.res || (aligned16(e.res) && (e.ldres & 3) == 0)) &&
+            (!e.mask || (aligned16(e.mask) && (e.ldmask & 3) == 0)) && (!e.scatter || (e.Ko & 3) == 0);
     TileCfg c = pick_cfg(p.M, p.Ngemm);
     p.splits = pick_splits(p.M, p.Ngemm, c, p.kiters);
-    if (p.e.stats) p.splits = 1;
+    float* stats_after = nullptr;  // split-K + BN statistics: a small pass over y afterwards
+    if (e.stats && p.splits > 1) {
+        if (e.scatter || e.bias || e.res || e.mask || e.act != ACIMG_ACT_NONE)
+            return fail(ACIMG_EINVAL, "igemm: statistics with split-K need a plain raw output");
+        stats_after = e.stats;
+        e.stats = nullptr;
+    }
     p.slab = nullptr;
     p.slab_ld = (p.Ngemm + 3) & ~3;
     if (p.splits > 1) {
@@ -627,19 +357,10 @@ static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipSt
         p.slab = static_cast<float*>(ws);
     }
     dim3 grid(cdiv(p.M, c.bm), cdiv(p.Ngemm, c.bn), p.splits);
-    if (c.bm == 128 && c.bn == 128) {
-        if (nt) launch_cfg<128, 128, 2, 2, true>(p, grid, st);
-        else launch_cfg<128, 128, 2, 2, false>(p, grid, st);
-    } else if (c.bm == 128 && c.bn == 64) {
-        if (nt) launch_cfg<128, 64, 2, 2, true>(p, grid, st);
-        else launch_cfg<128, 64, 2, 2, false>(p, grid, st);
-    } else if (c.bm == 64 && c.bn == 64) {
-        if (nt) launch_cfg<64, 64, 2, 2, true>(p, grid, st);
-        else launch_cfg<64, 64, 2, 2, false>(p, grid, st);
-    } else {
-        if (nt) launch_cfg<256, 16, 4, 1, true>(p, grid, st);
-        else launch_cfg<256, 16, 4, 1, false>(p, grid, st);
-    }
+    if (c.bm == 128 && c.bn == 128) launch_cfg<128, 128, 2, 4, 512>(p, nt, cal, grid, st);
+    else if (c.bm == 128 && c.bn == 64) launch_cfg<128, 64, 2, 2, 256>(p, nt, cal, grid, st);
+    else if (c.bm == 64 && c.bn == 64) launch_cfg<64, 64, 2, 2, 256>(p, nt, cal, grid, st);
+    else launch_cfg<256, 16, 4, 1, 256>(p, nt, cal, grid, st);
     int rc = check_launch("igemm");
     if (rc) return rc;
     if (p.splits > 1) {
@@ -647,6 +368,11 @@ static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipSt
         hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
                            p.slab, p.splits, p.M, p.Ngemm, p.slab_ld, p.e);
         rc = check_launch("igemm_splitk_reduce");
+        if (!rc && stats_after) {
+            hipLaunchKernelGGL(partial_stats_kernel, dim3(cdiv(p.M, 256)), dim3(256), 0, st, e.Y, e.ldy, p.M,
+                               e.Nstore, stats_after, e.stats_ld);
+            rc = check_launch("partial_stats");
+        }
     }
     return rc;
 }
@@ -745,15 +471,16 @@ using namespace acimg;
 // ==========================================================================================
 extern "C" {
 
-int acimg_conv2d_stats_rows(const AcimgConvDesc* d) {
-    const int M = d->N * d->OH * d->OW;
-    return cdiv(M, pick_cfg(M, d->K).bm);
-}
-
 static int fwd_kiters(const AcimgConvDesc* d) {
     const bool rowrun = d->S > 1 && d->ldx == d->C;
     const int L = rowrun ? d->S * d->C : d->C;
     return (rowrun ? d->R : d->R * d->S) * cdiv(L, 32);
+}
+
+int acimg_conv2d_stats_rows(const AcimgConvDesc* d) {
+    const int M = d->N * d->OH * d->OW;
+    TileCfg c = pick_cfg(M, d->K);
+    return pick_splits(M, d->K, c, fwd_kiters(d)) > 1 ? cdiv(M, 256) : cdiv(M, c.bm);
 }
 
 int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {

@@ -23,6 +23,7 @@ struct EpiParams {
     // per-row-block column statistics of the raw accumulator (batch-norm), [gridDim.x][2][stats_ld]
     float* stats;
     int stats_ld;
+    int vec;  // every pointer / stride of the epilogue allows 16-byte accesses
 };
 
 // C[m][n] = sum_k A(m,k) * B(k,n);  A gathered from an NHWC tensor (im2col on the fly).
@@ -48,6 +49,7 @@ struct IgemmParams {
     int ntaps;
     int Ngemm;  // number of GEMM columns
     int Nld;    // NN: valid floats per B row (multiple of 4)
+    unsigned a_bytes, b_bytes;  // extents for the buffer resource descriptors
     // split-K
     int splits;
     float* slab;  // [splits][M][slab_ld]

@@ -1,0 +1,426 @@
+// fp32 implicit-GEMM kernel, version 2 (gfx950).  See igemm.hip for the op mapping.
+//
+//   * global loads are branch-free `buffer_load_dwordx4` through a resource descriptor: padding taps,
+//     rows past M and columns past N get an out-of-range offset and the hardware returns zeros;
+//   * K steps over (tap, 32-channel chunk); when C % 32 == 0 (template CAL) the tap/chunk counters
+//     are wave-uniform scalars advanced incrementally, no per-thread integer division in the loop;
+//   * LDS is double buffered: tile t+1 is written to the other buffer after the MFMAs of tile t and
+//     tile t+2's global loads are issued right after, so there is ONE barrier per K step and every
+//     global load has a full MFMA phase to land;
+//   * MFMA operand roles are swapped (weights in the A slot, activations in the B slot): the 4
+//     accumulator registers of a lane are then 4 CONSECUTIVE OUTPUT CHANNELS of one pixel, so the
+//     epilogue is one 16-byte store (and 16-byte bias / residual / mask loads) per 16x16 tile.
+#pragma once
+#include "igemm.hpp"
+
+namespace acimg {
+
+using u32x4 = __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int;
+
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+}
+constexpr unsigned OOB = 0x80000000u;  // >= num_records of every descriptor (tensors < 2 GiB)
+
+// ---- epilogue -------------------------------------------------------------------------------
+__device__ __forceinline__ long epi_row_pix(const EpiParams& e, int m) {
+    if (!e.scatter) return m;
+    const int hw = e.AH * e.AW;
+    const int img = m / hw;
+    const int rem = m - img * hw;
+    const int h = rem / e.AW;
+    const int w = rem - h * e.AW;
+    return ((long)img * e.YH + (long)e.sc * h) * e.YW + (long)e.sc * w;
+}
+__device__ __forceinline__ void epi_col(const EpiParams& e, int n, int& cn, int& pixoff) {
+    if (!e.scatter) {
+        cn = n;
+        pixoff = 0;
+    } else {
+        const int t = n / e.Ko;
+        cn = n - t * e.Ko;
+        const int r = t / e.Sq;
+        const int q = t - r * e.Sq;
+        pixoff = r * e.YW + q;
+    }
+}
+__device__ __forceinline__ float epi_act(float v, int act) {
+    if (act == ACIMG_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACIMG_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+__device__ __forceinline__ void epi_store(const EpiParams& e, long opix, int cn, float v) {
+    if (e.bias) v += e.bias[cn];
+    if (e.res) v += e.res[opix * e.ldres + cn];
+    v = epi_act(v, e.act);
+    if (e.mask && !(e.mask[opix * e.ldmask + cn] > 0.f)) v = 0.f;
+    e.Y[opix * e.ldy + cn] = v;
+}
+// 4 consecutive channels cn..cn+3 of one output pixel; `vec` = every pointer/stride is 16-byte friendly
+__device__ __forceinline__ void epi_store4(const EpiParams& e, long opix, int cn, int nvalid, float4 v) {
+    if (e.vec && nvalid == 4) {
+        if (e.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(e.bias + cn);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (e.res) {
+            const float4 r = *reinterpret_cast<const float4*>(e.res + opix * e.ldres + cn);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (e.act != ACIMG_ACT_NONE) {
+            v.x = epi_act(v.x, e.act); v.y = epi_act(v.y, e.act);
+            v.z = epi_act(v.z, e.act); v.w = epi_act(v.w, e.act);
+        }
+        if (e.mask) {
+            const float4 k = *reinterpret_cast<const float4*>(e.mask + opix * e.ldmask + cn);
+            v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f;
+            v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(e.Y + opix * e.ldy + cn) = v;
+    } else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nvalid) epi_store(e, opix, cn + k, vv[k]);
+    }
+}
+
+// ---- main kernel ------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, int NTHR, bool B_NT, bool CAL>
+__global__ __launch_bounds__(NTHR) void igemm_f32_kernel(const IgemmParams p) {
+    constexpr int BK = 32;
+    constexpr int LDA_S = BK + 4;
+    constexpr int LDB_S = B_NT ? (BK + 4) : (BN + 4);
+    constexpr int A_ELEMS = BM * LDA_S;
+    constexpr int B_ELEMS = B_NT ? BN * LDB_S : BK * LDB_S;
+    constexpr int STAGE = A_ELEMS + B_ELEMS;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int KQ = BK / 4;
+    constexpr int RPP = NTHR / KQ;
+    constexpr int NA = (BM + RPP - 1) / RPP;
+    constexpr int NBT = (BN + RPP - 1) / RPP;
+    constexpr int NQ = BN / 4;
+    constexpr int RPPB = NTHR / NQ;
+    constexpr int NBN = (BK + RPPB - 1) / RPPB;
+    constexpr int NB = B_NT ? NBT : NBN;
+    static_assert(WGM * WGN * 64 == NTHR, "one wave per (wm, wn)");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int li = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
+
+    int it_begin = 0, it_end = p.kiters;
+    if (p.splits > 1) {
+        const int per = (p.kiters + p.splits - 1) / p.splits;
+        it_begin = blockIdx.z * per;
+        it_end = min(p.kiters, it_begin + per);
+    }
+
+    // ---- per-thread A rows ---------------------------------------------------------------------
+    const int kq = tid % KQ;
+    const int arow0 = tid / KQ;
+    int a_off[NA], a_ih0[NA], a_iw0[NA];
+    {
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int row = arow0 + j * RPP;
+            const int m = m0 + row;
+            if (row < BM && m < p.M) {
+                const int img = m / ohw;
+                const int rem = m - img * ohw;
+                const int oh = rem / p.OW;
+                const int ow = rem - oh * p.OW;
+                a_ih0[j] = oh * p.stride - p.pad_t;
+                a_iw0[j] = ow * p.stride - p.pad_l;
+                a_off[j] = ((img * p.H + a_ih0[j]) * p.W + a_iw0[j]) * p.lda * 4;
+            } else {
+                a_ih0[j] = -(1 << 28);
+                a_iw0[j] = -(1 << 28);
+                a_off[j] = 0;
+            }
+        }
+    }
+
+    // K-step state: `nit` = next iteration to load
+    int nit = it_begin;
+    int st_r = 0, st_s = 0, st_c0 = 0;  // CAL: wave-uniform (tap, channel chunk)
+    if constexpr (CAL) {
+        const int cpt = p.C >> 5;
+        const int tap = it_begin / cpt;
+        st_c0 = (it_begin - tap * cpt) << 5;
+        st_r = tap / p.S;
+        st_s = tap - st_r * p.S;
+    }
+
+    float4 ra[NA], rb[NB];
+
+    auto load_tiles = [&]() {
+        int r, s, c, seg = 0, chunk = 0;
+        bool validk = true;
+        if constexpr (CAL) {
+            r = st_r;
+            s = st_s;
+            c = st_c0 + kq * 4;
+        } else {
+            seg = nit / p.cps;
+            chunk = nit - seg * p.cps;
+            const int pp = chunk * BK + kq * 4;
+            validk = pp < p.L;
+            if (p.rowrun) {
+                r = seg;
+                s = pp / p.C;
+                c = pp - s * p.C;
+            } else {
+                r = seg / p.S;
+                s = seg - r * p.S;
+                c = pp;
+            }
+        }
+        const bool affine = p.a_scale != nullptr;
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (affine && validk) {
+            sc4 = *reinterpret_cast<const float4*>(p.a_scale + c);
+            sh4 = *reinterpret_cast<const float4*>(p.a_shift + c);
+        }
+        const int tapoff = ((r * p.W + s) * p.lda + c) * 4;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int ih = a_ih0[j] + r, iw = a_iw0[j] + s;
+            const bool ok = validk && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            float4 v = buf_load4(rsA, ok ? (unsigned)(a_off[j] + tapoff) : OOB);
+            if (affine) {
+                v.x = v.x * sc4.x + sh4.x;
+                v.y = v.y * sc4.y + sh4.y;
+                v.z = v.z * sc4.z + sh4.z;
+                v.w = v.w * sc4.w + sh4.w;
+                if (p.a_relu) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding AFTER the affine
+            }
+            ra[j] = v;
+        }
+        if constexpr (B_NT) {
+            int tap;
+            if constexpr (CAL) tap = r * p.S + s;
+            else tap = p.rowrun ? (seg * p.S + s) : seg;
+            const int tapb = p.flip ? (p.ntaps - 1 - tap) : tap;
+            const int base = tapb * (int)p.tap_stride + c;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int nrow = arow0 + j * RPP;
+                const int n = n0 + nrow;
+                const bool ok = validk && nrow < BN && n < p.Ngemm;
+                rb[j] = buf_load4(rsB, ok ? (unsigned)((base + n * p.ldb) * 4) : OOB);
+            }
+        } else {
+            const int nq = tid % NQ;
+            const int krow0 = tid / NQ;
+            const int n = n0 + nq * 4;
+            int kb0, plim;
+            if constexpr (CAL) {
+                kb0 = (r * p.S + s) * p.C + st_c0;
+                plim = BK;
+            } else {
+                kb0 = seg * p.L + chunk * BK;
+                plim = p.L - chunk * BK;
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int krow = krow0 + j * RPPB;
+                const bool ok = krow < BK && krow < plim && n < p.Nld;
+                rb[j] = buf_load4(rsB, ok ? (unsigned)(((kb0 + krow) * p.ldb + n) * 4) : OOB);
+            }
+        }
+        // advance
+        ++nit;
+        if constexpr (CAL) {
+            st_c0 += BK;
+            if (st_c0 == p.C) {
+                st_c0 = 0;
+                if (++st_s == p.S) {
+                    st_s = 0;
+                    ++st_r;
+                }
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int row = arow0 + j * RPP;
+            if (row < BM) *reinterpret_cast<float4*>(&As[row * LDA_S + kq * 4]) = ra[j];
+        }
+        if constexpr (B_NT) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int nrow = arow0 + j * RPP;
+                if (nrow < BN) *reinterpret_cast<float4*>(&Bs[nrow * LDB_S + kq * 4]) = rb[j];
+            }
+        } else {
+            const int nq = tid % NQ;
+            const int krow0 = tid / NQ;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int krow = krow0 + j * RPPB;
+                if (krow < BK) *reinterpret_cast<float4*>(&Bs[krow * LDB_S + nq * 4]) = rb[j];
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (it_begin < it_end) {
+        load_tiles();
+        store_tiles(0);
+        if (nit < it_end) load_tiles();
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int it = it_begin; it < it_end; ++it) {
+        const float* As = smem + cur * STAGE;
+        const float* Bs = As + A_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            float4 a4[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a4[i] = *reinterpret_cast<const float4*>(&As[(wm * WTM + i * 16 + li) * LDA_S + kk * 16 + 4 * g]);
+            float bf[TN][4];
+            if constexpr (B_NT) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(
+                        &Bs[(wn * WTN + j * 16 + li) * LDB_S + kk * 16 + 4 * g]);
+                    bf[j][0] = b4.x;
+                    bf[j][1] = b4.y;
+                    bf[j][2] = b4.z;
+                    bf[j][3] = b4.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        bf[j][t] = Bs[(kk * 16 + 4 * g + t) * LDB_S + wn * WTN + j * 16 + li];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float av = t == 0 ? a4[i].x : (t == 1 ? a4[i].y : (t == 2 ? a4[i].z : a4[i].w));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)  // rows of D = output channels, columns = pixels
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][t], av, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (it + 1 < it_end) {
+            store_tiles(cur ^ 1);          // tile it+1 (loaded one step ago) -> the other buffer
+            if (nit < it_end) load_tiles();  // tile it+2
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane holds channels n4..n4+3 of pixel m for each (tm, tn) ---------------------
+    if (p.splits > 1) {
+        float* slab = p.slab + (long)blockIdx.z * p.M * p.slab_ld;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + li;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n4 = n0 + wn * WTN + j * 16 + 4 * g;
+                if (n4 < p.slab_ld)
+                    *reinterpret_cast<float4*>(slab + (long)m * p.slab_ld + n4) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+        return;
+    }
+
+    const EpiParams& e = p.e;
+    int cn[TN], pixoff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) epi_col(e, n0 + wn * WTN + j * 16 + 4 * g, cn[j], pixoff[j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + li;
+        if (m >= e.M) continue;
+        const long rp = epi_row_pix(e, m);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n4 = n0 + wn * WTN + j * 16 + 4 * g;
+            const int nvalid = e.Nstore - n4;
+            if (nvalid > 0)
+                epi_store4(e, rp + pixoff[j], cn[j], nvalid < 4 ? nvalid : 4,
+                           make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+        }
+    }
+
+    if (e.stats) {
+        // per-channel sum / sum of squares of the raw accumulators over this block's rows (rows past
+        // M were zero-filled on load and add nothing): reduce over the 16 pixel lanes, then over waves
+        __syncthreads();
+        float* red = smem;  // [WGM][2][BN]
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float v = acc[i][j][rg];
+                    s1 += v;
+                    s2 += v * v;
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if (li == 0) {
+                    const int col = wn * WTN + j * 16 + 4 * g + rg;
+                    red[(wm * 2 + 0) * BN + col] = s1;
+                    red[(wm * 2 + 1) * BN + col] = s2;
+                }
+            }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * BN; idx += NTHR) {
+            const int which = idx / BN, col = idx - which * BN;
+            const int n = n0 + col;
+            if (n < e.stats_ld) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGM; ++w) s += red[(w * 2 + which) * BN + col];
+                e.stats[((long)blockIdx.x * 2 + which) * e.stats_ld + n] = s;
+            }
+        }
+    }
+}
+
+}  // namespace acimg
