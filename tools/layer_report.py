@@ -1,5 +1,5 @@
-"""Per-launch report for the forward-conv kernel: aligns a rocprofv3 kernel trace of `bench.py` with the
-recorded plan (rebuilt on the CPU, no GPU needed) and prints time, TFLOP/s and GB/s per conv launch.
+"""Per-launch report for the implicit-GEMM kernels: aligns a rocprofv3 kernel trace of `bench.py` with
+the recorded plan (rebuilt on the CPU, no GPU needed) and prints time, TFLOP/s and GB/s per launch.
 usage: python tools/layer_report.py <kernel_trace.csv> [batch]"""
 import csv, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,26 +17,23 @@ FLAGS.model = "UNet"
 sess = Session(torch.device("cpu"))
 tr = Trainer(UNetAc(input_shape=[36, 48, 12]), ResNet50Model(input_shape=[224, 298, 3]), session=sess)
 g = tr._build_functions(batch_size=B)
-convs = []
+calls = []
 for name, fn, a in g.plan_train.calls:
-    if name == "conv2d_fwd":
-        d = a[0]._obj
-        bm, bn, sp = ops.conv2d_fwd_tiling(d)
-        convs.append((d, bm, bn, sp))
+    if name in ("conv2d_fwd", "conv2d_dgrad", "deconv_fwd", "deconv_dgrad"):
+        calls.append((name, a[0]._obj))
 rows = list(csv.DictReader(open(trace)))
-kname = [r for r in rows if "igemm_f32_kernel" in r["Kernel_Name"] and "false" in r["Kernel_Name"]]
-# the last full step: take the trailing len(convs) forward launches (backward uses NT kernels / deconv NN uses few)
-nn_per_step = len([c for c in convs])
-# deconv_dgrad also launches an NN kernel once per step (after the forward convs): drop it by name order
-per_step = nn_per_step + 1
-last = kname[-per_step:]
-durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in last][:nn_per_step]
-print("%-4s %-28s %-9s %8s %8s %8s %7s" % ("#", "conv (HxW C->K RxS/s)", "tile", "us", "TFLOP/s", "GB/s", "kiters"))
-tot = 0
-for i, ((d, bm, bn, sp), us) in enumerate(zip(convs, durs)):
+ig = [r for r in rows if "igemm_f32_kernel" in r["Kernel_Name"]]
+last = ig[-len(calls):]
+print("%-4s %-13s %-30s %-22s %8s %8s %8s" % ("#", "op", "HxW C->K RxS/s", "kernel", "us", "TFLOP/s", "GB/s"))
+tot = {}
+for i, ((name, d), r) in enumerate(zip(calls, last)):
+    us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     fl = 2.0 * d.N * d.OH * d.OW * d.K * d.R * d.S * d.C
+    if name.startswith("deconv"):
+        fl = 2.0 * d.N * d.H * d.W * d.K * d.R * d.S * d.C
     by = 4.0 * (d.N * d.H * d.W * d.C + d.N * d.OH * d.OW * d.K + d.R * d.S * d.C * d.K)
-    tot += us
-    print("%-4d %-28s %-9s %8.1f %8.1f %8.0f" % (i, "%dx%d %d->%d %dx%d/%d" % (d.H, d.W, d.C, d.K, d.R, d.S, d.stride),
-          "%dx%d/%d" % (bm, bn, sp), us, fl / us / 1e6, by / us / 1e3))
-print("total us", tot)
+    kn = r["Kernel_Name"].split("<")[1].split(">")[0].replace(" ", "")
+    tot[name] = tot.get(name, 0) + us
+    print("%-4d %-13s %-30s %-22s %8.1f %8.1f %8.0f" % (i, name, "%dx%d %d->%d %dx%d/%d" % (d.H, d.W, d.C, d.K, d.R, d.S, d.stride),
+          kn, us, fl / us / 1e6, by / us / 1e3))
+print("totals (us):", tot)
