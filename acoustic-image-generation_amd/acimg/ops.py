@@ -247,6 +247,23 @@ def conv2d_fwd(plan, d, x, w, bias, y, in_scale=None, in_shift=None, in_relu=0, 
              int(in_relu), stats, _WsPtr(plan.ws), _WsBytes(plan.ws))
 
 
+def conv2d_bf3_weight_bytes(d):
+    return _L().acimg_conv2d_bf3_weight_bytes(C.byref(d))
+
+
+def conv2d_fwd_bf3_stats_rows(d):
+    return _L().acimg_conv2d_fwd_bf3_stats_rows(C.byref(d))
+
+
+def conv2d_bf3_prepare(plan, d, w, wsplit):
+    plan.add("conv2d_bf3_prepare", _L().acimg_conv2d_bf3_prepare, C.byref(d), w, wsplit)
+
+
+def conv2d_fwd_bf3(plan, d, x, wsplit, y, in_scale=None, in_shift=None, in_relu=0, stats=None):
+    plan.add("conv2d_fwd_bf3", _L().acimg_conv2d_fwd_bf3, C.byref(d), x, wsplit, y, in_scale, in_shift,
+             int(in_relu), stats)
+
+
 def conv2d_dgrad(plan, d, gy, ldgy, w, dx, residual=None, ldres=0, mask=None, ldmask=0, lddx=0):
     L = _L()
     plan.ws.require(L.acimg_conv2d_dgrad_workspace(C.byref(d)))

@@ -108,6 +108,7 @@ class ParamStore(object):
         self.adam_v = None
         self._sizes = {"train": 0, "trunkw": 0, "state": 0}
         self._final = False
+        self.version = 0                # bumped whenever variables are (re)loaded from the host
 
     # ---- registration ---------------------------------------------------------------------------
     def add(self, var):
@@ -167,6 +168,7 @@ class ParamStore(object):
 
     def load_state(self, tf_state, strict=True, only=None):
         """tf_state: {TF variable name: array in TF layout}.  `only(name)->bool` filters names."""
+        self.version += 1
         loaded = []
         fused_internal = set()
         for h in self.fused:

@@ -31,8 +31,12 @@ BN_EPS = 1e-5
 
 class ResNet50Model(object):
 
-    def __init__(self, input_shape=None, num_classes=None):
+    def __init__(self, input_shape=None, num_classes=None, precision="bf16x3"):
+        """precision: arithmetic of the frozen trunk convs — "bf16x3" (split-bf16 MFMA, fp32-class
+        results, default) or "f32" (exact-f32 MFMA).  conv1 (C=3) and conv_map always use f32."""
         self.scope = 'resnet_v1_50'
+        assert precision in ("bf16x3", "f32")
+        self.precision = precision
         self.num_classes = num_classes
         self.height = input_shape[0]
         self.width = input_shape[1]
@@ -114,6 +118,7 @@ class ResNet50Model(object):
         self.plan_eval = sess.new_plan()
         self._record_forward(self.plan_train, True)
         self._record_forward(self.plan_eval, False)
+        self.wsplit = torch.zeros(max(self._bf3_bytes, 16), dtype=torch.uint8, device=sess.device)
         self.network = OrderedDict(input=visual_images, is_training=None, keep_prob=None)
         self.network[self.scope + "/conv_map"] = self.output
         cm = self.scope + "/conv_map"
@@ -167,6 +172,12 @@ class ResNet50Model(object):
         self.g_raw_cm = z(N, fh, fw, 12)
         self.stats = None
         self._stats_need = 0
+        # bf16x3: split + transposed copies of the frozen kernels, refreshed when the store changes
+        self._bf3 = {}
+        self._bf3_bytes = 0
+        self._bf3_version = -1
+        self.plan_prepare = sess.new_plan()
+        self.wsplit = None
 
     def _new_affine(self, c):
         sc = self.affine[self._aff_off:self._aff_off + c]
@@ -183,12 +194,24 @@ class ResNet50Model(object):
         P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
         d = ops.conv_desc(self.N, hw[0], hw[1], cin, cout, kh, kw, stride, padding, ldx=cin, ldy=up4(cout),
                           ldw=up4(cout))
-        rows = ops.conv2d_stats_rows(d)
+        bf3 = self.precision == "bf16x3" and cin % 32 == 0 and not save
+        rows = ops.conv2d_fwd_bf3_stats_rows(d) if bf3 else ops.conv2d_stats_rows(d)
         self._stats_need = max(self._stats_need, rows * 2 * up4(cout))
         stats = ops.LazyPtr(lambda: self.stats)
         isc, ish = (in_aff if in_aff is not None else (None, None))
-        ops.conv2d_fwd(plan, d, x, P(scope + "/weights"), None, out, isc, ish, 1,
-                       stats if training else None)
+        if bf3:
+            if scope not in self._bf3:
+                off = self._bf3_bytes
+                self._bf3[scope] = off
+                self._bf3_bytes += -(-ops.conv2d_bf3_weight_bytes(d) // 256) * 256
+                ops.conv2d_bf3_prepare(self.plan_prepare, d, P(scope + "/weights"),
+                                       ops.LazyPtr(lambda off=off: self.wsplit[off:]))
+            off = self._bf3[scope]
+            ops.conv2d_fwd_bf3(plan, d, x, ops.LazyPtr(lambda off=off: self.wsplit[off:]), out, isc, ish, 1,
+                               stats if training else None)
+        else:
+            ops.conv2d_fwd(plan, d, x, P(scope + "/weights"), None, out, isc, ish, 1,
+                           stats if training else None)
         if not hasattr(self, "_aff_cache"):
             self._aff_cache = {}
         if scope not in self._aff_cache:
@@ -201,9 +224,17 @@ class ResNet50Model(object):
                         self.save_mean if save else None, self.save_invstd if save else None)
         return d.OH, d.OW, sc, sh
 
+    def _refresh_split_weights(self):
+        """host hook at the head of the forward plans: re-split the frozen kernels iff they changed"""
+        st = self.session.store
+        if self._bf3_bytes and self._bf3_version != st.version:
+            self.plan_prepare.run()
+            self._bf3_version = st.version
+
     def _record_forward(self, plan, training):
         N = self.N
         H, W = self.height, self.width
+        plan.add_hook(self._refresh_split_weights)
         ops.pad_channels(plan, self.images, self.xpad, N * H * W, 3, 4)
         oh, ow, sc, sh = self._conv_bn(plan, self.scope + "/conv1", self.xpad, (H, W), 4, 7, 7, 64, 2, 3,
                                        self.raw0, None, training)

@@ -1,0 +1,242 @@
+// bf16x3 ("split bf16") implicit-GEMM forward convolution for gfx950.
+//
+// fp32 operands are split on the fly into hi = bf16(x) and lo = bf16(x - hi) (16 mantissa bits in all) and
+// every 16x16x32 product is three bf16 MFMAs accumulated in fp32:  a*w ~= ah*wh + ah*wl + al*wh.  The dropped
+// al*wl term and the split residuals are ~2^-16 relative per product, i.e. fp32-class results (the parity
+// tests hold the same 1e-3 bar as the exact-f32 kernel) at 3/16 of the fp32-MFMA cost per FLOP.
+//
+//   A (activations): fp32 NHWC in HBM, gathered like the fp32 kernel (branch-free buffer loads, deferred BN
+//      scale/shift/ReLU applied while staging), split to hi/lo when written to LDS.
+//   B (weights): pre-split + transposed once per step by `bf3_prepare_kernel` into [hi|lo][n][k] bf16 (k
+//      contiguous), so both operands are read with one ds_read_b128 per 16x16x32 fragment.
+//   LDS image: 64-byte rows (32 bf16), 16-byte chunk index XOR ((row>>2)&3): conflict-free b128 reads for the
+//      16 rows of a fragment without padding; 32 KiB per stage, double buffered.
+//   MFMA roles swapped as in the fp32 kernel (weights in the A slot): a lane's 4 accumulators are 4 consecutive
+//      output channels of one pixel -> shared 16-byte epilogue incl. the batch-norm statistics partials.
+#pragma once
+#include "igemm_kernel.hpp"
+
+namespace acimg {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+    const bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    const bf16x4 l = {(__bf16)(v.x - (float)h[0]), (__bf16)(v.y - (float)h[1]), (__bf16)(v.z - (float)h[2]),
+                      (__bf16)(v.w - (float)h[3])};
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
+// w fp32 [Ktot][ldw] (HWIO flattened) -> out bf16 [2][Nrows][Ktot]: out[0]=hi, out[1]=lo, transposed
+__global__ __launch_bounds__(256) void bf3_prepare_kernel(const float* w, int Ktot, int ldw, int Nrows,
+                                                          __bf16* out) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + 8 * i, n = n0 + tx;
+        tile[ty + 8 * i][tx] = (k < Ktot && n < ldw) ? w[(long)k * ldw + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, k = k0 + tx;
+        if (n < Nrows && k < Ktot) {
+            const float v = tile[tx][ty + 8 * i];
+            const __bf16 h = (__bf16)v;
+            out[(long)n * Ktot + k] = h;
+            out[((long)Nrows + n) * Ktot + k] = (__bf16)(v - (float)h);
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, int NTHR>
+__global__ __launch_bounds__(NTHR) void igemm_bf3_kernel(const IgemmParams p) {
+    constexpr int BK = 32;
+    constexpr int ROWB = BK * 2;                  // bytes per LDS row (32 bf16)
+    constexpr int A_BYTES = BM * ROWB;            // one of hi / lo
+    constexpr int B_BYTES = BN * ROWB;
+    constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int KQ = BK / 4;                    // float4 per A row
+    constexpr int RPP = NTHR / KQ;
+    constexpr int NA = BM / RPP;
+    constexpr int BCH = 2 * BN * 4;               // 16-byte chunks of the B tile (hi + lo)
+    constexpr int NB = BCH / NTHR;
+    static_assert(WGM * WGN * 64 == NTHR && BM % RPP == 0 && BCH % NTHR == 0, "tile / thread mapping");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int li = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
+
+    const int it_end = p.kiters;
+    const int Ktot = p.ntaps * p.C;               // bf16 elements per weight row
+
+    // ---- A rows of this thread ---------------------------------------------------------------------
+    const int kq = tid % KQ;
+    const int arow0 = tid / KQ;
+    int a_off[NA], a_ih0[NA], a_iw0[NA];
+    {
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int m = m0 + arow0 + j * RPP;
+            if (m < p.M) {
+                const int img = m / ohw;
+                const int rem = m - img * ohw;
+                const int oh = rem / p.OW;
+                const int ow = rem - oh * p.OW;
+                a_ih0[j] = oh * p.stride - p.pad_t;
+                a_iw0[j] = ow * p.stride - p.pad_l;
+                a_off[j] = ((img * p.H + a_ih0[j]) * p.W + a_iw0[j]) * p.lda * 4;
+            } else {
+                a_ih0[j] = -(1 << 28);
+                a_iw0[j] = -(1 << 28);
+                a_off[j] = 0;
+            }
+        }
+    }
+    // ---- B chunks of this thread: chunk c -> (hi/lo, row, 16-byte k chunk) --------------------------------
+    unsigned b_goff[NB];   // byte offset of (which, row) at k = 0, or OOB
+    int b_lds[NB];         // byte offset inside the stage
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int c = tid + j * NTHR;
+        const int which = c / (BN * 4);
+        const int rem = c - which * (BN * 4);
+        const int row = rem >> 2, kc = rem & 3;
+        const int n = n0 + row;
+        b_goff[j] = n < p.Nld ? (unsigned)((((long)which * p.Nld + n) * Ktot + kc * 8) * 2) : OOB;
+        b_lds[j] = 2 * A_BYTES + which * B_BYTES + row * ROWB + ((kc ^ ((row >> 2) & 3)) << 4);
+    }
+
+    int nit = 0, st_r = 0, st_s = 0, st_c0 = 0;
+    float4 ra[NA];
+    uint4 rb[NB];
+
+    auto load_tiles = [&]() {
+        const int c = st_c0 + kq * 4;
+        const bool affine = p.a_scale != nullptr;
+        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (affine) {
+            sc4 = *reinterpret_cast<const float4*>(p.a_scale + c);
+            sh4 = *reinterpret_cast<const float4*>(p.a_shift + c);
+        }
+        const int tapoff = ((st_r * p.W + st_s) * p.lda + c) * 4;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int ih = a_ih0[j] + st_r, iw = a_iw0[j] + st_s;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            float4 v = buf_load4(rsA, ok ? (unsigned)(a_off[j] + tapoff) : OOB);
+            if (affine) {
+                v.x = v.x * sc4.x + sh4.x;
+                v.y = v.y * sc4.y + sh4.y;
+                v.z = v.z * sc4.z + sh4.z;
+                v.w = v.w * sc4.w + sh4.w;
+                if (p.a_relu) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            ra[j] = v;
+        }
+        const unsigned kbyte = (unsigned)(((st_r * p.S + st_s) * p.C + st_c0) * 2);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            rb[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  rsB, b_goff[j] == OOB ? OOB : b_goff[j] + kbyte, 0, 0));
+        ++nit;
+        st_c0 += BK;
+        if (st_c0 == p.C) {
+            st_c0 = 0;
+            if (++st_s == p.S) {
+                st_s = 0;
+                ++st_r;
+            }
+        }
+    };
+
+    auto store_tiles = [&](int buf) {
+        char* st = lds + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int row = arow0 + j * RPP;
+            uint2 hi, lo;
+            split4(ra[j], hi, lo);
+            const int off = row * ROWB + (((kq >> 1) ^ ((row >> 2) & 3)) << 4) + ((kq & 1) << 3);
+            *reinterpret_cast<uint2*>(st + off) = hi;
+            *reinterpret_cast<uint2*>(st + A_BYTES + off) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<uint4*>(st + b_lds[j]) = rb[j];
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (it_end > 0) {
+        load_tiles();
+        store_tiles(0);
+        if (nit < it_end) load_tiles();
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int it = 0; it < it_end; ++it) {
+        const char* st = lds + cur * STAGE;
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * WTM + i * 16 + li;
+            const int off = row * ROWB + ((g ^ ((row >> 2) & 3)) << 4);
+            ah[i] = *reinterpret_cast<const bf16x8*>(st + off);
+            al[i] = *reinterpret_cast<const bf16x8*>(st + A_BYTES + off);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wn * WTN + j * 16 + li;
+            const int off = 2 * A_BYTES + row * ROWB + ((g ^ ((row >> 2) & 3)) << 4);
+            bh[j] = *reinterpret_cast<const bf16x8*>(st + off);
+            bl[j] = *reinterpret_cast<const bf16x8*>(st + B_BYTES + off);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                // rows of D = output channels (weights in the A slot), columns = pixels; small terms first
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+            }
+        if (it + 1 < it_end) {
+            store_tiles(cur ^ 1);
+            if (nit < it_end) load_tiles();
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    igemm_epilogue<BM, BN, WGM, WGN, NTHR, TM, TN>(p, acc, smem, m0, n0, wm, wn, li, g, tid);
+}
+
+}  // namespace acimg

@@ -85,6 +85,88 @@ __device__ __forceinline__ void epi_store4(const EpiParams& e, long opix, int cn
     }
 }
 
+// ---- shared epilogue: lane holds channels n4..n4+3 of pixel m for each (tm, tn) -------------------
+template <int BM, int BN, int WGM, int WGN, int NTHR, int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[TM][TN], float* smem, int m0,
+                                               int n0, int wm, int wn, int li, int g, int tid) {
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    if (p.splits > 1) {
+        float* slab = p.slab + (long)blockIdx.z * p.M * p.slab_ld;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + li;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n4 = n0 + wn * WTN + j * 16 + 4 * g;
+                if (n4 < p.slab_ld)
+                    *reinterpret_cast<float4*>(slab + (long)m * p.slab_ld + n4) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+        return;
+    }
+
+    const EpiParams& e = p.e;
+    int cn[TN], pixoff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) epi_col(e, n0 + wn * WTN + j * 16 + 4 * g, cn[j], pixoff[j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + li;
+        if (m >= e.M) continue;
+        const long rp = epi_row_pix(e, m);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n4 = n0 + wn * WTN + j * 16 + 4 * g;
+            const int nvalid = e.Nstore - n4;
+            if (nvalid > 0)
+                epi_store4(e, rp + pixoff[j], cn[j], nvalid < 4 ? nvalid : 4,
+                           make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
+        }
+    }
+
+    if (e.stats) {
+        // per-channel sum / sum of squares of the raw accumulators over this block's rows (rows past
+        // M were zero-filled on load and add nothing): reduce over the 16 pixel lanes, then over waves
+        __syncthreads();
+        float* red = smem;  // [WGM][2][BN]
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float v = acc[i][j][rg];
+                    s1 += v;
+                    s2 += v * v;
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if (li == 0) {
+                    const int col = wn * WTN + j * 16 + 4 * g + rg;
+                    red[(wm * 2 + 0) * BN + col] = s1;
+                    red[(wm * 2 + 1) * BN + col] = s2;
+                }
+            }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * BN; idx += NTHR) {
+            const int which = idx / BN, col = idx - which * BN;
+            const int n = n0 + col;
+            if (n < e.stats_ld) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGM; ++w) s += red[(w * 2 + which) * BN + col];
+                e.stats[((long)blockIdx.x * 2 + which) * e.stats_ld + n] = s;
+            }
+        }
+    }
+}
+
 // ---- main kernel ------------------------------------------------------------------------------
 template <int BM, int BN, int WGM, int WGN, int NTHR, bool B_NT, bool CAL>
 __global__ __launch_bounds__(NTHR) void igemm_f32_kernel(const IgemmParams p) {
@@ -345,82 +427,7 @@ __global__ __launch_bounds__(NTHR) void igemm_f32_kernel(const IgemmParams p) {
         cur ^= 1;
     }
 
-    // ---- epilogue: lane holds channels n4..n4+3 of pixel m for each (tm, tn) ---------------------
-    if (p.splits > 1) {
-        float* slab = p.slab + (long)blockIdx.z * p.M * p.slab_ld;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * WTM + i * 16 + li;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n4 = n0 + wn * WTN + j * 16 + 4 * g;
-                if (n4 < p.slab_ld)
-                    *reinterpret_cast<float4*>(slab + (long)m * p.slab_ld + n4) =
-                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            }
-        }
-        return;
-    }
-
-    const EpiParams& e = p.e;
-    int cn[TN], pixoff[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) epi_col(e, n0 + wn * WTN + j * 16 + 4 * g, cn[j], pixoff[j]);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 16 + li;
-        if (m >= e.M) continue;
-        const long rp = epi_row_pix(e, m);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n4 = n0 + wn * WTN + j * 16 + 4 * g;
-            const int nvalid = e.Nstore - n4;
-            if (nvalid > 0)
-                epi_store4(e, rp + pixoff[j], cn[j], nvalid < 4 ? nvalid : 4,
-                           make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
-        }
-    }
-
-    if (e.stats) {
-        // per-channel sum / sum of squares of the raw accumulators over this block's rows (rows past
-        // M were zero-filled on load and add nothing): reduce over the 16 pixel lanes, then over waves
-        __syncthreads();
-        float* red = smem;  // [WGM][2][BN]
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float v = acc[i][j][rg];
-                    s1 += v;
-                    s2 += v * v;
-                }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1 += __shfl_xor(s1, o, 64);
-                    s2 += __shfl_xor(s2, o, 64);
-                }
-                if (li == 0) {
-                    const int col = wn * WTN + j * 16 + 4 * g + rg;
-                    red[(wm * 2 + 0) * BN + col] = s1;
-                    red[(wm * 2 + 1) * BN + col] = s2;
-                }
-            }
-        __syncthreads();
-        for (int idx = tid; idx < 2 * BN; idx += NTHR) {
-            const int which = idx / BN, col = idx - which * BN;
-            const int n = n0 + col;
-            if (n < e.stats_ld) {
-                float s = 0.f;
-#pragma unroll
-                for (int w = 0; w < WGM; ++w) s += red[(w * 2 + which) * BN + col];
-                e.stats[((long)blockIdx.x * 2 + which) * e.stats_ld + n] = s;
-            }
-        }
-    }
+    igemm_epilogue<BM, BN, WGM, WGN, NTHR, TM, TN>(p, acc, smem, m0, n0, wm, wn, li, g, tid);
 }
 
 }  // namespace acimg

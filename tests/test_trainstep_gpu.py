@@ -3,8 +3,8 @@ noise: loss terms, generated image, mean/std, EVERY gradient, post-Adam weights 
 batch-norm moving statistics, and the evaluation pass.
 
 Tolerance (BASELINE.json north_star): outputs and losses within 1e-3 relative (max-norm, relative to
-the tensor's max magnitude).  Both sides compute in fp32 (the HIP path on exact-f32 MFMA), observed
-error ~1e-5.  Gradients are held to the same 1e-3 (max-norm and L2).  A ReLU pre-activation within fp32
+the tensor's max magnitude), for BOTH trunk arithmetic modes: exact-f32 MFMA ("f32", observed ~1e-5)
+and split-bf16 MFMA ("bf16x3": hi/lo bf16 operands, three MFMAs per product, fp32 accumulate).  Gradients are held to the same 1e-3 (max-norm and L2).  A ReLU pre-activation within fp32
 rounding of zero (a few of the 2.5 M per step; e.g. `conv4`: 2.3e-7 here vs 0.0 in the oracle) picks a
 different but equally valid subgradient, so for the BACKWARD comparison the oracle takes the ReLU on/off
 patterns from the HIP run (both sides then differentiate the same piecewise-linear function); forward
@@ -32,7 +32,7 @@ def l2_err(got, ref):
     return float((got - ref).norm() / max(float(ref.norm()), 1e-30))
 
 
-def build(device, num_skip, embedding, batch, lr=1e-3):
+def build(device, num_skip, embedding, batch, lr=1e-3, precision="bf16x3"):
     from acimg.flags import FLAGS
     from acimg.session import Session
     from acimg.trainer import Trainer
@@ -46,7 +46,7 @@ def build(device, num_skip, embedding, batch, lr=1e-3):
     orc = otr.Oracle(num_skip=num_skip, embedding=embedding, learning_rate=lr, latent_loss=FLAGS.latent_loss,
                      randomize=True)
     sess = Session(device)
-    mi = ResNet50Model(input_shape=[224, 298, 3], num_classes=None)
+    mi = ResNet50Model(input_shape=[224, 298, 3], num_classes=None, precision=precision)
     ma = UNetAc(input_shape=[36, 48, 12], embedding=embedding, num_skip=num_skip)
     tr = Trainer(ma, mi, learning_rate=lr, session=sess)
     tr._build_functions(batch_size=batch)
@@ -83,8 +83,9 @@ def tf_adam_fp64(p, g, m, v, step, lr):
     return p - lr_t * m2 / (v2.sqrt() + 1e-8), m2, v2
 
 
-@pytest.mark.parametrize("num_skip,embedding", [(1, False), (2, False), (0, True)])
-def test_train_step_matches_oracle(device, num_skip, embedding):
+@pytest.mark.parametrize("num_skip,embedding,precision", [(1, False, "bf16x3"), (1, False, "f32"), (2, False, "bf16x3"),
+                                                         (0, True, "f32")])
+def test_train_step_matches_oracle(device, num_skip, embedding, precision):
     """Three consecutive optimisation steps, each compared from IDENTICAL state (the HIP state is
     re-synchronised from the oracle before every step): forward tensors, loss terms, every gradient,
     BN moving statistics; and the optimiser itself against TF-1 Adam recomputed in fp64 from the
@@ -94,7 +95,7 @@ def test_train_step_matches_oracle(device, num_skip, embedding):
     from oracle import trainer as otr
 
     B, lr = 2, 1e-3
-    tr, orc, sess = build(device, num_skip, embedding, B, lr)
+    tr, orc, sess = build(device, num_skip, embedding, B, lr, precision)
     store = sess.store
     ac, mf, vid, eps = otr.synthetic_batch(B, seed=99)
     sd = store.state_dict()
