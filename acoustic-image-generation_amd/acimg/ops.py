@@ -247,20 +247,20 @@ def conv2d_fwd(plan, d, x, w, bias, y, in_scale=None, in_shift=None, in_relu=0, 
              int(in_relu), stats, _WsPtr(plan.ws), _WsBytes(plan.ws))
 
 
-def conv2d_bf3_weight_bytes(d):
-    return _L().acimg_conv2d_bf3_weight_bytes(C.byref(d))
+def conv2d_split3_weight_bytes(d):
+    return _L().acimg_conv2d_split3_weight_bytes(C.byref(d))
 
 
-def conv2d_fwd_bf3_stats_rows(d):
-    return _L().acimg_conv2d_fwd_bf3_stats_rows(C.byref(d))
+def conv2d_fwd_split3_stats_rows(d):
+    return _L().acimg_conv2d_fwd_split3_stats_rows(C.byref(d))
 
 
-def conv2d_bf3_prepare(plan, d, w, wsplit):
-    plan.add("conv2d_bf3_prepare", _L().acimg_conv2d_bf3_prepare, C.byref(d), w, wsplit)
+def conv2d_split3_prepare(plan, d, w, wsplit):
+    plan.add("conv2d_split3_prepare", _L().acimg_conv2d_split3_prepare, C.byref(d), w, wsplit)
 
 
-def conv2d_fwd_bf3(plan, d, x, wsplit, y, in_scale=None, in_shift=None, in_relu=0, stats=None):
-    plan.add("conv2d_fwd_bf3", _L().acimg_conv2d_fwd_bf3, C.byref(d), x, wsplit, y, in_scale, in_shift,
+def conv2d_fwd_split3(plan, d, x, wsplit, y, in_scale=None, in_shift=None, in_relu=0, stats=None):
+    plan.add("conv2d_fwd_split3", _L().acimg_conv2d_fwd_split3, C.byref(d), x, wsplit, y, in_scale, in_shift,
              int(in_relu), stats)
 
 

@@ -31,11 +31,11 @@ BN_EPS = 1e-5
 
 class ResNet50Model(object):
 
-    def __init__(self, input_shape=None, num_classes=None, precision="bf16x3"):
-        """precision: arithmetic of the frozen trunk convs — "bf16x3" (split-bf16 MFMA, fp32-class
+    def __init__(self, input_shape=None, num_classes=None, precision="f16x3"):
+        """precision: arithmetic of the frozen trunk convs — "f16x3" (split-fp16 MFMA, fp32-class
         results, default) or "f32" (exact-f32 MFMA).  conv1 (C=3) and conv_map always use f32."""
         self.scope = 'resnet_v1_50'
-        assert precision in ("bf16x3", "f32")
+        assert precision in ("f16x3", "f32")
         self.precision = precision
         self.num_classes = num_classes
         self.height = input_shape[0]
@@ -118,7 +118,7 @@ class ResNet50Model(object):
         self.plan_eval = sess.new_plan()
         self._record_forward(self.plan_train, True)
         self._record_forward(self.plan_eval, False)
-        self.wsplit = torch.zeros(max(self._bf3_bytes, 16), dtype=torch.uint8, device=sess.device)
+        self.wsplit = torch.zeros(max(self._sp3_bytes, 16), dtype=torch.uint8, device=sess.device)
         self.network = OrderedDict(input=visual_images, is_training=None, keep_prob=None)
         self.network[self.scope + "/conv_map"] = self.output
         cm = self.scope + "/conv_map"
@@ -172,10 +172,10 @@ class ResNet50Model(object):
         self.g_raw_cm = z(N, fh, fw, 12)
         self.stats = None
         self._stats_need = 0
-        # bf16x3: split + transposed copies of the frozen kernels, refreshed when the store changes
-        self._bf3 = {}
-        self._bf3_bytes = 0
-        self._bf3_version = -1
+        # f16x3: split + transposed copies of the frozen kernels, refreshed when the store changes
+        self._sp3 = {}
+        self._sp3_bytes = 0
+        self._sp3_version = -1
         self.plan_prepare = sess.new_plan()
         self.wsplit = None
 
@@ -194,20 +194,20 @@ class ResNet50Model(object):
         P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
         d = ops.conv_desc(self.N, hw[0], hw[1], cin, cout, kh, kw, stride, padding, ldx=cin, ldy=up4(cout),
                           ldw=up4(cout))
-        bf3 = self.precision == "bf16x3" and cin % 32 == 0 and not save
-        rows = ops.conv2d_fwd_bf3_stats_rows(d) if bf3 else ops.conv2d_stats_rows(d)
+        sp3 = self.precision == "f16x3" and cin % 32 == 0 and not save
+        rows = ops.conv2d_fwd_split3_stats_rows(d) if sp3 else ops.conv2d_stats_rows(d)
         self._stats_need = max(self._stats_need, rows * 2 * up4(cout))
         stats = ops.LazyPtr(lambda: self.stats)
         isc, ish = (in_aff if in_aff is not None else (None, None))
-        if bf3:
-            if scope not in self._bf3:
-                off = self._bf3_bytes
-                self._bf3[scope] = off
-                self._bf3_bytes += -(-ops.conv2d_bf3_weight_bytes(d) // 256) * 256
-                ops.conv2d_bf3_prepare(self.plan_prepare, d, P(scope + "/weights"),
+        if sp3:
+            if scope not in self._sp3:
+                off = self._sp3_bytes
+                self._sp3[scope] = off
+                self._sp3_bytes += -(-ops.conv2d_split3_weight_bytes(d) // 256) * 256
+                ops.conv2d_split3_prepare(self.plan_prepare, d, P(scope + "/weights"),
                                        ops.LazyPtr(lambda off=off: self.wsplit[off:]))
-            off = self._bf3[scope]
-            ops.conv2d_fwd_bf3(plan, d, x, ops.LazyPtr(lambda off=off: self.wsplit[off:]), out, isc, ish, 1,
+            off = self._sp3[scope]
+            ops.conv2d_fwd_split3(plan, d, x, ops.LazyPtr(lambda off=off: self.wsplit[off:]), out, isc, ish, 1,
                                stats if training else None)
         else:
             ops.conv2d_fwd(plan, d, x, P(scope + "/weights"), None, out, isc, ish, 1,
@@ -227,9 +227,9 @@ class ResNet50Model(object):
     def _refresh_split_weights(self):
         """host hook at the head of the forward plans: re-split the frozen kernels iff they changed"""
         st = self.session.store
-        if self._bf3_bytes and self._bf3_version != st.version:
+        if self._sp3_bytes and self._sp3_version != st.version:
             self.plan_prepare.run()
-            self._bf3_version = st.version
+            self._sp3_version = st.version
 
     def _record_forward(self, plan, training):
         N = self.N

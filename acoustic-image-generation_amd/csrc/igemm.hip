@@ -12,7 +12,7 @@
 // staged [k][n] (NN, ds_read_b32) or [n][k] (NT, ds_read_b128).  The k order inside a 16-deep step
 // is permuted identically for A and B (lane group g owns k = 4g..4g+3), which leaves the sum
 // unchanged.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t.
-#include "igemm_bf3_kernel.hpp"
+#include "igemm_split3_kernel.hpp"
 
 namespace acimg {
 
@@ -657,41 +657,41 @@ int acimg_deconv_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, 
 }
 
 // ------------------------------------------------------------------------------------------
-// bf16x3 forward convolution (frozen ResNet trunk)
+// f16x3 (split fp16) forward convolution (frozen ResNet trunk)
 // ------------------------------------------------------------------------------------------
-struct Bf3Cfg { int bm, bn; };
-static Bf3Cfg pick_bf3(int M, int K) {
+struct Split3Cfg { int bm, bn; };
+static Split3Cfg pick_split3(int M, int K) {
     if (K <= 64) return {128, 64};
     if ((long)cdiv(M, 128) * cdiv(K, 128) < 400) return {64, 128};
     return {128, 128};
 }
 
-int acimg_conv2d_fwd_bf3_stats_rows(const AcimgConvDesc* d) {
+int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d) {
     const int M = d->N * d->OH * d->OW;
-    return cdiv(M, pick_bf3(M, d->K).bm);
+    return cdiv(M, pick_split3(M, d->K).bm);
 }
 
-size_t acimg_conv2d_bf3_weight_bytes(const AcimgConvDesc* d) {
+size_t acimg_conv2d_split3_weight_bytes(const AcimgConvDesc* d) {
     return (size_t)2 * d->ldw * d->R * d->S * d->C * 2;
 }
 
-int acimg_conv2d_bf3_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream) {
-    int rc = check_desc(d, "conv2d_bf3_prepare");
+int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream) {
+    int rc = check_desc(d, "conv2d_split3_prepare");
     if (rc) return rc;
     const int Ktot = d->R * d->S * d->C;
-    hipLaunchKernelGGL(bf3_prepare_kernel, dim3(cdiv(Ktot, 32), cdiv(d->ldw, 32)), dim3(256), 0,
-                       (hipStream_t)stream, w, Ktot, d->ldw, d->ldw, static_cast<__bf16*>(wsplit));
-    return check_launch("bf3_prepare");
+    hipLaunchKernelGGL(split3_prepare_kernel, dim3(cdiv(Ktot, 32), cdiv(d->ldw, 32)), dim3(256), 0,
+                       (hipStream_t)stream, w, Ktot, d->ldw, d->ldw, static_cast<_Float16*>(wsplit));
+    return check_launch("split3_prepare");
 }
 
-int acimg_conv2d_fwd_bf3(const AcimgConvDesc* d, const float* x, const void* wsplit, float* y,
+int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* wsplit, float* y,
                          const float* in_scale, const float* in_shift, int in_relu, float* stats,
                          void* stream) {
-    int rc = check_desc(d, "conv2d_fwd_bf3");
+    int rc = check_desc(d, "conv2d_fwd_split3");
     if (rc) return rc;
-    if (d->C % 32) return fail(ACIMG_EINVAL, "conv2d_fwd_bf3: C=%d must be a multiple of 32", d->C);
+    if (d->C % 32) return fail(ACIMG_EINVAL, "conv2d_fwd_split3: C=%d must be a multiple of 32", d->C);
     if (d->ldw < d->K || !aligned16(x) || !aligned16(wsplit) || !aligned16(y) || (d->ldy & 3))
-        return fail(ACIMG_EINVAL, "conv2d_fwd_bf3: ldw<K or unaligned operands");
+        return fail(ACIMG_EINVAL, "conv2d_fwd_split3: ldw<K or unaligned operands");
     IgemmParams p{};
     p.A = x; p.H = d->H; p.W = d->W; p.C = d->C; p.lda = d->ldx;
     p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride;
@@ -703,22 +703,22 @@ int acimg_conv2d_fwd_bf3(const AcimgConvDesc* d, const float* x, const void* wsp
     p.kiters = p.ntaps * (d->C / 32);
     p.splits = 1;
     const long a_bytes = (((long)d->N * d->H * d->W - 1) * d->ldx + d->C) * 4;
-    const long b_bytes = (long)acimg_conv2d_bf3_weight_bytes(d);
-    if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) return fail(ACIMG_EINVAL, "conv2d_fwd_bf3: operand >= 2 GiB");
+    const long b_bytes = (long)acimg_conv2d_split3_weight_bytes(d);
+    if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) return fail(ACIMG_EINVAL, "conv2d_fwd_split3: operand >= 2 GiB");
     p.a_bytes = (unsigned)a_bytes; p.b_bytes = (unsigned)b_bytes;
     EpiParams& e = p.e;
     e.Y = y; e.ldy = d->ldy; e.M = p.M; e.Nstore = d->K; e.act = d->act;
     e.stats = stats; e.stats_ld = d->ldw; e.vec = 1;
-    Bf3Cfg c = pick_bf3(p.M, d->K);
+    Split3Cfg c = pick_split3(p.M, d->K);
     dim3 grid(cdiv(p.M, c.bm), cdiv(d->K, c.bn), 1);
     hipStream_t st = (hipStream_t)stream;
     if (c.bm == 128 && c.bn == 128)
-        hipLaunchKernelGGL((igemm_bf3_kernel<128, 128, 2, 4, 512>), grid, dim3(512), 65536, st, p);
+        hipLaunchKernelGGL((igemm_split3_kernel<128, 128, 2, 4, 512>), grid, dim3(512), 65536, st, p);
     else if (c.bm == 64 && c.bn == 128)
-        hipLaunchKernelGGL((igemm_bf3_kernel<64, 128, 1, 4, 256>), grid, dim3(256), 2 * (2 * 64 * 64 + 2 * 128 * 64), st, p);
+        hipLaunchKernelGGL((igemm_split3_kernel<64, 128, 1, 4, 256>), grid, dim3(256), 2 * (2 * 64 * 64 + 2 * 128 * 64), st, p);
     else
-        hipLaunchKernelGGL((igemm_bf3_kernel<128, 64, 2, 2, 256>), grid, dim3(256), 2 * (2 * 128 * 64 + 2 * 64 * 64), st, p);
-    return check_launch("conv2d_fwd_bf3");
+        hipLaunchKernelGGL((igemm_split3_kernel<128, 64, 2, 2, 256>), grid, dim3(256), 2 * (2 * 128 * 64 + 2 * 64 * 64), st, p);
+    return check_launch("conv2d_fwd_split3");
 }
 
 }  // extern "C"

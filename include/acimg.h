@@ -76,20 +76,22 @@ int acimg_conv2d_stats_rows(const AcimgConvDesc* d);
 int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out);
 size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d);
 
-/* bf16x3 ("split bf16") forward convolution for frozen weights (the ResNet-50 trunk): x and w are fp32,
- * each is split into hi = bf16(v), lo = bf16(v - hi) and every product is ah*wh + ah*wl + al*wh on the
- * bf16 matrix cores with fp32 accumulation (~2^-16 relative per product: fp32-class results, same 1e-3
- * parity bar) at 3/16 of the exact-f32 MFMA cost.  Needs C % 32 == 0.  `wsplit` (caller-owned,
- * acimg_conv2d_bf3_weight_bytes(d) bytes) is filled by acimg_conv2d_bf3_prepare from the HWIO fp32
- * kernel: [hi|lo][ldw][R*S*C] bf16.  Semantics otherwise as acimg_conv2d_fwd (deferred BN on load, raw
- * output + statistics partials of acimg_conv2d_fwd_bf3_stats_rows(d) rows; no bias / split-K).
+/* f16x3 ("split fp16") forward convolution for frozen weights (the ResNet-50 trunk): x and w are fp32,
+ * each is split into hi = f16(v), lo = f16(v - hi) (22 mantissa bits) and every product is
+ * ah*wh + ah*wl + al*wh on the fp16 matrix cores with fp32 accumulation (~2^-22 relative per product:
+ * fp32-class results, same 1e-3 parity bar) at 3/16 of the exact-f32 MFMA cost.  Exact power-of-two
+ * scaling (weights x2^10, activations x2^-2, accumulators x2^-8) keeps everything in fp16's range for
+ * |w| < 63 and |x| < 2.6e5.  Needs C % 32 == 0.  `wsplit` (caller-owned,
+ * acimg_conv2d_split3_weight_bytes(d) bytes) is filled by acimg_conv2d_split3_prepare from the HWIO fp32
+ * kernel: [hi|lo][ldw][R*S*C] fp16.  Semantics otherwise as acimg_conv2d_fwd (deferred BN on load, raw
+ * output + statistics partials of acimg_conv2d_fwd_split3_stats_rows(d) rows; no bias / split-K).
  * Replaces: slim layers.conv2d / conv2d_same in the trunk, models/resnet50.py:109-121. */
-size_t acimg_conv2d_bf3_weight_bytes(const AcimgConvDesc* d);
-int acimg_conv2d_bf3_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream);
-int acimg_conv2d_fwd_bf3_stats_rows(const AcimgConvDesc* d);
-int acimg_conv2d_fwd_bf3(const AcimgConvDesc* d, const float* x, const void* wsplit, float* y,
-                         const float* in_scale, const float* in_shift, int in_relu, float* stats,
-                         void* stream);
+size_t acimg_conv2d_split3_weight_bytes(const AcimgConvDesc* d);
+int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream);
+int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d);
+int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* wsplit, float* y,
+                            const float* in_scale, const float* in_shift, int in_relu, float* stats,
+                            void* stream);
 
 /* Data gradient.  gy is the gradient w.r.t. the conv's PRE-activation output [N,OH,OW,K]
  * (pixel stride ldgy); dx = relu_mask(conv_T(gy, w) + residual): `residual` (optional, pixel

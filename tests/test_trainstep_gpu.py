@@ -4,7 +4,7 @@ batch-norm moving statistics, and the evaluation pass.
 
 Tolerance (BASELINE.json north_star): outputs and losses within 1e-3 relative (max-norm, relative to
 the tensor's max magnitude), for BOTH trunk arithmetic modes: exact-f32 MFMA ("f32", observed ~1e-5)
-and split-bf16 MFMA ("bf16x3": hi/lo bf16 operands, three MFMAs per product, fp32 accumulate).  Gradients are held to the same 1e-3 (max-norm and L2).  A ReLU pre-activation within fp32
+and split-fp16 MFMA ("f16x3": hi/lo fp16 operands, three MFMAs per product, fp32 accumulate).  Gradients are held to the same 1e-3 (max-norm and L2).  A ReLU pre-activation within fp32
 rounding of zero (a few of the 2.5 M per step; e.g. `conv4`: 2.3e-7 here vs 0.0 in the oracle) picks a
 different but equally valid subgradient, so for the BACKWARD comparison the oracle takes the ReLU on/off
 patterns from the HIP run (both sides then differentiate the same piecewise-linear function); forward
@@ -32,7 +32,7 @@ def l2_err(got, ref):
     return float((got - ref).norm() / max(float(ref.norm()), 1e-30))
 
 
-def build(device, num_skip, embedding, batch, lr=1e-3, precision="bf16x3"):
+def build(device, num_skip, embedding, batch, lr=1e-3, precision="f16x3"):
     from acimg.flags import FLAGS
     from acimg.session import Session
     from acimg.trainer import Trainer
@@ -83,7 +83,7 @@ def tf_adam_fp64(p, g, m, v, step, lr):
     return p - lr_t * m2 / (v2.sqrt() + 1e-8), m2, v2
 
 
-@pytest.mark.parametrize("num_skip,embedding,precision", [(1, False, "bf16x3"), (1, False, "f32"), (2, False, "bf16x3"),
+@pytest.mark.parametrize("num_skip,embedding,precision", [(1, False, "f16x3"), (1, False, "f32"), (2, False, "f16x3"),
                                                          (0, True, "f32")])
 def test_train_step_matches_oracle(device, num_skip, embedding, precision):
     """Three consecutive optimisation steps, each compared from IDENTICAL state (the HIP state is
