@@ -133,10 +133,13 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
     }
 
     int nit = 0, st_r = 0, st_s = 0, st_c0 = 0;
-    float4 ra[NA];
-    uint4 rb[NB];
+    // two prefetch register sets: tiles t+1 and t+2 are in flight while tile t is multiplied, so every
+    // global load has TWO K steps to land (one step is only ~400 MFMA cycles here: with a single set the
+    // kernel ran at the L2 round-trip latency, ~6900 cycles per step)
+    float4 ra0[NA], ra1[NA];
+    uint4 rb0[NB], rb1[NB];
 
-    auto load_tiles = [&]() {
+    auto load_tiles = [&](float4 (&ra)[NA], uint4 (&rb)[NB]) {
         const int c = st_c0 + kq * 4;
         const bool affine = p.a_scale != nullptr;
         float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
         }
     };
 
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const float4 (&ra)[NA], const uint4 (&rb)[NB]) {
         char* st = lds + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -202,16 +205,8 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (it_end > 0) {
-        load_tiles();
-        store_tiles(0);
-        if (nit < it_end) load_tiles();
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (int it = 0; it < it_end; ++it) {
-        const char* st = lds + cur * STAGE;
+    auto compute = [&](int buf) {
+        const char* st = lds + buf * STAGE;
         h16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -236,12 +231,31 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
             }
+    };
+
+    if (it_end > 0) {
+        load_tiles(ra0, rb0);                       // tile 0
+        store_tiles(0, ra0, rb0);
+        if (nit < it_end) load_tiles(ra0, rb0);     // tile 1
+        if (nit < it_end) load_tiles(ra1, rb1);     // tile 2
+    }
+    __syncthreads();
+
+    // loop top (it even): LDS[0] = tile it, set 0 = tile it+1, set 1 = tile it+2
+    for (int it = 0; it < it_end; it += 2) {
+        compute(0);
         if (it + 1 < it_end) {
-            store_tiles(cur ^ 1);
-            if (nit < it_end) load_tiles();
+            store_tiles(1, ra0, rb0);
+            if (nit < it_end) load_tiles(ra0, rb0);  // tile it+3
         }
         __syncthreads();
-        cur ^= 1;
+        if (it + 1 >= it_end) break;
+        compute(1);
+        if (it + 2 < it_end) {
+            store_tiles(0, ra1, rb1);
+            if (nit < it_end) load_tiles(ra1, rb1);  // tile it+4
+        }
+        __syncthreads();
     }
 
 #pragma unroll
