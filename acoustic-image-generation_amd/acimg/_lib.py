@@ -42,6 +42,7 @@ PROTOTYPES = {
     "acimg_conv2d_split3_weight_bytes": (_SZ, [_DP]),
     "acimg_conv2d_split3_prepare": (_I, [_DP, _P, _P, _P]),
     "acimg_conv2d_fwd_split3_stats_rows": (_I, [_DP]),
+    "acimg_conv2d_fwd_split3_tiling": (_I, [_DP, C.POINTER(C.c_int)]),
     "acimg_conv2d_fwd_split3": (_I, [_DP, _P, _P, _P, _P, _P, _I, _P, _P]),
     "acimg_conv2d_dgrad": (_I, [_DP, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _SZ, _P]),
     "acimg_conv2d_dgrad_workspace": (_SZ, [_DP]),

@@ -255,6 +255,12 @@ def conv2d_fwd_split3_stats_rows(d):
     return _L().acimg_conv2d_fwd_split3_stats_rows(C.byref(d))
 
 
+def conv2d_fwd_split3_tiling(d):
+    out = (C.c_int * 2)()
+    _lib.check(_L().acimg_conv2d_fwd_split3_tiling(C.byref(d), out), "conv2d_fwd_split3_tiling")
+    return out[0], out[1]
+
+
 def conv2d_split3_prepare(plan, d, w, wsplit):
     plan.add("conv2d_split3_prepare", _L().acimg_conv2d_split3_prepare, C.byref(d), w, wsplit)
 

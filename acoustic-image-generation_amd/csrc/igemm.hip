@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
     const int arow0 = tid / AQ;
     const int kk = kk0 + aq * 4;
     const bool kk_ok = kk < p.KK;
+    const bool kk_ones = p.db_out != nullptr && kk == p.KK;   // the all-ones column (bias gradient)
     int r = 0, s = 0, c = 0;
     if (kk_ok) {
         const int tap = kk / p.C;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
             const int row = arow0 + j * ARPP;
             const int m = mb + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < BKR && kk_ones && m < m_end) v.x = 1.f;
             if (row < BKR && kk_ok && m < m_end) {
                 const int img = m / ohw;
                 const int rem = m - img * ohw;
@@ -165,11 +167,12 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             const int row = kk0 + wm * WTM + i * 16 + g * 4 + rg;
-            if (row >= p.KK) continue;
+            if (row > p.KK || (row == p.KK && p.db_out == nullptr)) continue;
+            float* dst = row < p.KK ? out + (long)row * p.ldo : p.db_out + (long)blockIdx.z * p.ldo;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * WTN + j * 16 + li;
-                if (n < p.Ngemm) out[(long)row * p.ldo + n] = acc[i][j][rg];
+                if (n < p.Ngemm) dst[n] = acc[i][j][rg];
             }
         }
 }
@@ -394,10 +397,11 @@ static size_t wgrad_ws_bytes(int M, int KK, int Ngemm, int ldo) {
     int bmo, bn;
     wgrad_tile(Ngemm, bmo, bn);
     const int s = pick_wgrad_splits(M, KK, Ngemm, bmo, bn);
-    return s > 1 ? (size_t)s * KK * ldo * sizeof(float) : 0;
+    return s > 1 ? (size_t)s * ((size_t)KK + 1) * ldo * sizeof(float) : 0;
 }
 
-static int launch_wgrad(WgradParams p, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+// db (optional): fused bias gradient, db[n] = sum_m G[m][n] for n < Ngemm
+static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t st) {
     if ((p.C & 3) || (p.ldx & 3) || (p.ldg & 3) || (p.ldo & 3))
         return fail(ACIMG_EINVAL, "wgrad: C=%d ldx=%d ldg=%d ldo=%d must be multiples of 4", p.C, p.ldx, p.ldg, p.ldo);
     if (!aligned16(p.X) || !aligned16(p.G) || !aligned16(dw))
@@ -409,15 +413,20 @@ static int launch_wgrad(WgradParams p, float* dw, void* ws, size_t ws_bytes, hip
     rps = ((rps + 15) / 16) * 16;
     p.rows_per_split = rps;
     p.splits = cdiv(p.M, rps);
+    float* db_slab = nullptr;
     if (p.splits > 1) {
-        const size_t need = (size_t)p.splits * p.KK * p.ldo * sizeof(float);
+        const size_t need = (size_t)p.splits * ((size_t)p.KK + 1) * p.ldo * sizeof(float);
         if (ws == nullptr || ws_bytes < need)
             return fail(ACIMG_EWORKSPACE, "wgrad: workspace %zu < %zu", ws_bytes, need);
         p.out = static_cast<float*>(ws);
+        db_slab = p.out + (size_t)p.splits * p.KK * p.ldo;
+        p.db_out = db ? db_slab : nullptr;
     } else {
         p.out = dw;
+        p.db_out = db;
     }
-    dim3 grid(cdiv(p.KK, bmo), cdiv(p.Ngemm, bn), p.splits);
+    const int rows = p.KK + (db ? 1 : 0);
+    dim3 grid(cdiv(rows, bmo), cdiv(p.Ngemm, bn), p.splits);
     if (bn == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, st, p);
     else if (bn == 64) hipLaunchKernelGGL((wgrad_f32_kernel<128, 64>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((wgrad_f32_kernel<128, 32>), grid, dim3(256), 0, st, p);
@@ -427,6 +436,9 @@ static int launch_wgrad(WgradParams p, float* dw, void* ws, size_t ws_bytes, hip
         const long total = (long)p.KK * p.Ngemm;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p.out,
                            p.splits, (long)p.KK, p.Ngemm, p.ldo, dw);
+        if (db)
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(p.Ngemm, 256)), dim3(256), 0, st, db_slab, p.splits,
+                               1L, p.Ngemm, p.ldo, db);
         rc = check_launch("wgrad_reduce");
     }
     return rc;
@@ -581,10 +593,7 @@ int acimg_conv2d_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, 
     p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
     p.M = d->N * d->OH * d->OW; p.KK = d->R * d->S * d->C;
     p.G = gy; p.ldg = ldgy; p.Ngemm = kp; p.Nld = kp; p.ldo = d->ldw;
-    rc = launch_wgrad(p, dw, ws, ws_bytes, (hipStream_t)stream);
-    if (rc) return rc;
-    if (db) rc = launch_colsum(gy, (long)p.M, d->K, ldgy, db, ws, ws_bytes, (hipStream_t)stream);
-    return rc;
+    return launch_wgrad(p, dw, db, ws, ws_bytes, (hipStream_t)stream);
 }
 
 size_t acimg_deconv_workspace(const AcimgConvDesc* d) {
@@ -650,8 +659,9 @@ int acimg_deconv_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, 
     p.OH = d->H; p.OW = d->W; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad_t = 0; p.pad_l = 0;
     p.M = d->N * d->H * d->W; p.KK = d->R * d->S * ca;
     p.G = x; p.ldg = d->ldx; p.Ngemm = d->C; p.Nld = d->C; p.ldo = d->ldw;
-    rc = launch_wgrad(p, dw, ws, ws_bytes, (hipStream_t)stream);
+    rc = launch_wgrad(p, dw, nullptr, ws, ws_bytes, (hipStream_t)stream);
     if (rc) return rc;
+    // the transposed conv adds its bias at EVERY output pixel (gaps included): plain column sum of gy
     if (db) rc = launch_colsum(gy, (long)d->N * d->OH * d->OW, d->K, ldgy, db, ws, ws_bytes, (hipStream_t)stream);
     return rc;
 }
@@ -660,15 +670,38 @@ int acimg_deconv_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, 
 // f16x3 (split fp16) forward convolution (frozen ResNet trunk)
 // ------------------------------------------------------------------------------------------
 struct Split3Cfg { int bm, bn; };
+// Tiles of one launch all cost the same, so the launch takes ceil(tiles / resident slots) "rounds": a layer
+// with 1050 tiles on 512 slots pays for 3 rounds of 128x128 work.  Pick the tiling with the least
+// rounds x tile-area (smaller tiles: 3 workgroups per CU instead of 2, slightly less reuse per tile).
 static Split3Cfg pick_split3(int M, int K) {
     if (K <= 64) return {128, 64};
-    if ((long)cdiv(M, 128) * cdiv(K, 128) < 400) return {64, 128};
-    return {128, 128};
+    struct Cand { int bm, bn, slots; double eff; };
+    const Cand cands[3] = {{128, 128, 512, 1.0}, {64, 128, 768, 0.88}, {128, 64, 768, 0.80}};
+    double best = 1e30;
+    Split3Cfg pick = {128, 128};
+    for (const Cand& c : cands) {
+        const long tiles = (long)cdiv(M, c.bm) * cdiv(K, c.bn);
+        const long rounds = (tiles + c.slots - 1) / c.slots;
+        const double cost = (double)rounds * c.bm * c.bn / c.eff;
+        if (cost < best) {
+            best = cost;
+            pick = {c.bm, c.bn};
+        }
+    }
+    return pick;
 }
 
 int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d) {
     const int M = d->N * d->OH * d->OW;
     return cdiv(M, pick_split3(M, d->K).bm);
+}
+
+int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out) {
+    if (!d || !out) return fail(ACIMG_EINVAL, "conv2d_fwd_split3_tiling: null argument");
+    Split3Cfg c = pick_split3(d->N * d->OH * d->OW, d->K);
+    out[0] = c.bm;
+    out[1] = c.bn;
+    return ACIMG_OK;
 }
 
 size_t acimg_conv2d_split3_weight_bytes(const AcimgConvDesc* d) {

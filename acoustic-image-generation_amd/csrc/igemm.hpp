@@ -73,6 +73,9 @@ struct WgradParams {
     int rows_per_split;  // multiple of BKR
     float* out;          // slab [splits][KK][ldo] when splits>1 else dW
     int ldo;
+    // optional fused bias gradient: an implicit all-ones im2col column at row KK, i.e.
+    // db[n] = sum_m G[m][n]; written to db_out[blockIdx.z * ldo + n] (slab when splits > 1)
+    float* db_out;
 };
 
 }  // namespace acimg

@@ -89,6 +89,7 @@ size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d);
 size_t acimg_conv2d_split3_weight_bytes(const AcimgConvDesc* d);
 int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream);
 int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d);
+int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out /* {BM, BN} */);
 int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* wsplit, float* y,
                             const float* in_scale, const float* in_shift, int in_relu, float* stats,
                             void* stream);
