@@ -270,6 +270,26 @@ def conv2d_fwd_split3(plan, d, x, wsplit, y, in_scale=None, in_shift=None, in_re
              int(in_relu), stats)
 
 
+def conv2d_fwd_split3p(plan, d, x_planes, x_lo_off, wsplit, y, stats=None):
+    plan.add("conv2d_fwd_split3p", _L().acimg_conv2d_fwd_split3p, C.byref(d), x_planes, int(x_lo_off), wsplit, y,
+             stats)
+
+
+def bn_relu_split(plan, x, scale, shift, relu, out, lo_off, rows, Cn):
+    plan.add("bn_relu_split", _L().acimg_bn_relu_split, x, scale, shift, int(relu), out, int(lo_off), int(rows), Cn)
+
+
+def bn_add_relu_split(plan, a, sa, ta, b32, sb, tb, b_planes, b_lo_off, out_planes, out_lo_off, out32, N, OH, OW,
+                      Cn, BH, BW, bstride):
+    plan.add("bn_add_relu_split", _L().acimg_bn_add_relu_split, a, sa, ta, b32, sb, tb, b_planes, int(b_lo_off),
+             out_planes, int(out_lo_off), out32, N, OH, OW, Cn, BH, BW, bstride)
+
+
+def bn_relu_maxpool_split(plan, x, scale, shift, out, lo_off, N, H, W, Cn, OH, OW, pad_t, pad_l):
+    plan.add("bn_relu_maxpool_split", _L().acimg_bn_relu_maxpool_split, x, scale, shift, out, int(lo_off), N, H, W,
+             Cn, OH, OW, pad_t, pad_l)
+
+
 def conv2d_dgrad(plan, d, gy, ldgy, w, dx, residual=None, ldres=0, mask=None, ldmask=0, lddx=0):
     L = _L()
     plan.ws.require(L.acimg_conv2d_dgrad_workspace(C.byref(d)))

@@ -159,6 +159,11 @@ class ResNet50Model(object):
         self.arena_r2 = z(mx_r2)
         self.arena_r3 = z(mx_r3)
         self.arena_sc = z(mx_r3)
+        if self.precision == "f16x3":
+            # split-format arenas (two fp16 planes per tensor = the bytes of the fp32 tensor)
+            u8 = lambda n: torch.zeros(int(n), dtype=torch.uint8, device=sess.device)  # noqa: E731
+            self.planes_a, self.planes_b = u8(4 * mx_io + 512), u8(4 * mx_io + 512)
+            self.planes_1, self.planes_2 = u8(4 * mx_r1 + 512), u8(4 * mx_r2 + 512)
         self.xfinal = z(N, h, w, 2048)          # block4 output, kept for the conv_map weight gradient
         self.affine = z(2 * (nch + 64 + 16))    # scale/shift of every BN layer
         self._aff_off = 0
@@ -194,7 +199,7 @@ class ResNet50Model(object):
         P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
         d = ops.conv_desc(self.N, hw[0], hw[1], cin, cout, kh, kw, stride, padding, ldx=cin, ldy=up4(cout),
                           ldw=up4(cout))
-        sp3 = self.precision == "f16x3" and cin % 32 == 0 and not save
+        sp3 = False   # the f16x3 trunk goes through _conv_bn_planes; conv1 (C=3) and conv_map stay exact-f32
         rows = ops.conv2d_fwd_split3_stats_rows(d) if sp3 else ops.conv2d_stats_rows(d)
         self._stats_need = max(self._stats_need, rows * 2 * up4(cout))
         stats = ops.LazyPtr(lambda: self.stats)
@@ -231,7 +236,93 @@ class ResNet50Model(object):
             self.plan_prepare.run()
             self._sp3_version = st.version
 
+    @staticmethod
+    def _lo_off(rows, c):
+        """byte offset of the lo plane of a [rows, c] split-format tensor"""
+        return -(-rows * c * 2 // 256) * 256
+
+    def _conv_bn_planes(self, plan, scope, xplanes, hw, cin, kh, kw, cout, stride, padding, out, training):
+        """like _conv_bn, for an input in split format (pre-normalised fp16 hi/lo planes)"""
+        st = self.session.store
+        P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
+        d = ops.conv_desc(self.N, hw[0], hw[1], cin, cout, kh, kw, stride, padding, ldx=cin, ldy=up4(cout),
+                          ldw=up4(cout))
+        rows = ops.conv2d_fwd_split3_stats_rows(d)
+        self._stats_need = max(self._stats_need, rows * 2 * up4(cout))
+        stats = ops.LazyPtr(lambda: self.stats)
+        if scope not in self._sp3:
+            off = self._sp3_bytes
+            self._sp3[scope] = off
+            self._sp3_bytes += -(-ops.conv2d_split3_weight_bytes(d) // 256) * 256
+            ops.conv2d_split3_prepare(self.plan_prepare, d, P(scope + "/weights"),
+                                      ops.LazyPtr(lambda off=off: self.wsplit[off:]))
+        off = self._sp3[scope]
+        ops.conv2d_fwd_split3p(plan, d, xplanes, self._lo_off(self.N * hw[0] * hw[1], cin),
+                               ops.LazyPtr(lambda off=off: self.wsplit[off:]), out, stats if training else None)
+        if not hasattr(self, "_aff_cache"):
+            self._aff_cache = {}
+        if scope not in self._aff_cache:
+            self._aff_cache[scope] = self._new_affine(up4(cout))
+        sc, sh = self._aff_cache[scope]
+        b = scope + "/BatchNorm/"
+        ops.bn_finalize(plan, stats if training else None, rows if training else 0, cout, up4(cout),
+                        self.N * d.OH * d.OW if training else 0, P(b + "gamma"), P(b + "beta"),
+                        P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, BN_DECAY, BN_EPS, training)
+        return d.OH, d.OW, sc, sh
+
+    def _record_forward_split(self, plan, training):
+        """f16x3 trunk: activations between convs live in split format.  Per bottleneck unit:
+             conv1(X) -> raw1 -> [BN+ReLU+split] -> conv2 -> raw2 -> [BN+ReLU+split] -> conv3 -> raw3
+             out = relu(BN(raw3) + shortcut) written straight in split format (next unit's X)."""
+        N = self.N
+        H, W = self.height, self.width
+        plan.add_hook(self._refresh_split_weights)
+        ops.pad_channels(plan, self.images, self.xpad, N * H * W, 3, 4)
+        oh, ow, sc, sh = self._conv_bn(plan, self.scope + "/conv1", self.xpad, (H, W), 4, 7, 7, 64, 2, 3,
+                                       self.raw0, None, training)
+        ph, pw = self.pool_hw
+        _, pt = ops.same_out_pad(oh, 3, 2)
+        _, pl = ops.same_out_pad(ow, 3, 2)
+        cur, nxt = self.planes_a, self.planes_b
+        ops.bn_relu_maxpool_split(plan, self.raw0, sc, sh, cur, self._lo_off(N * ph * pw, 64), N, oh, ow, 64, ph, pw,
+                                  pt, pl)
+        h, w = ph, pw
+        units = list(self._units())
+        for i, (scope, din, d, db, s) in enumerate(units):
+            last = i == len(units) - 1
+            oh1, ow1, s1, t1 = self._conv_bn_planes(plan, scope + "/conv1", cur, (h, w), din, 1, 1, db, 1, "SAME",
+                                                    self.arena_r1, training)
+            ops.bn_relu_split(plan, self.arena_r1, s1, t1, 1, self.planes_1, self._lo_off(N * h * w, db), N * h * w, db)
+            oh2, ow2, s2, t2 = self._conv_bn_planes(plan, scope + "/conv2", self.planes_1, (h, w), db, 3, 3, db, s,
+                                                    "SAME" if s == 1 else 1, self.arena_r2, training)
+            ops.bn_relu_split(plan, self.arena_r2, s2, t2, 1, self.planes_2, self._lo_off(N * oh2 * ow2, db),
+                              N * oh2 * ow2, db)
+            oh3, ow3, s3, t3 = self._conv_bn_planes(plan, scope + "/conv3", self.planes_2, (oh2, ow2), db, 1, 1, d, 1,
+                                                    "SAME", self.arena_r3, training)
+            out_planes = None if last else nxt
+            out_lo = 0 if last else self._lo_off(N * oh3 * ow3, d)
+            out32 = self.xfinal if last else None
+            if din != d:
+                _, _, ssc, tsc = self._conv_bn_planes(plan, scope + "/shortcut", cur, (h, w), din, 1, 1, d, s, "SAME",
+                                                      self.arena_sc, training)
+                ops.bn_add_relu_split(plan, self.arena_r3, s3, t3, self.arena_sc, ssc, tsc, None, 0, out_planes, out_lo,
+                                      out32, N, oh3, ow3, d, oh3, ow3, 1)
+            else:
+                ops.bn_add_relu_split(plan, self.arena_r3, s3, t3, None, None, None, cur, self._lo_off(N * h * w, din),
+                                      out_planes, out_lo, out32, N, oh3, ow3, d, h, w, s)
+            h, w = oh3, ow3
+            if not last:
+                cur, nxt = nxt, cur
+        fh, fw = self.feat_hw
+        _, _, scm, tcm = self._conv_bn(plan, self.scope + "/conv_map", self.xfinal, (h, w), 2048, 3, 4, 12, 1,
+                                       "VALID", self.raw_cm, None, training, save=True)
+        ops.bn_relu(plan, self.raw_cm, scm, tcm, self.output, N * fh * fw, 12, 12, 12)
+        if self.stats is None or self.stats.numel() < self._stats_need:
+            self.stats = self.session.zeros(self._stats_need)
+
     def _record_forward(self, plan, training):
+        if self.precision == "f16x3":
+            return self._record_forward_split(plan, training)
         N = self.N
         H, W = self.height, self.width
         plan.add_hook(self._refresh_split_weights)

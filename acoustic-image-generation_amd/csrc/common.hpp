@@ -66,6 +66,30 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= 17 floats 
     return r;
 }
 
+// ---- split-fp16 ("f16x3") operand format ------------------------------------------------------
+// A value v is kept as hi = f16(v*SCALE), lo = f16(v*SCALE - hi): 22 mantissa bits in 4 bytes.  The
+// power-of-two scales keep fp16 in range: activations x2^-2 (finite up to 2.6e5), weights x2^10.
+constexpr float SPLIT3_WSCALE = 1024.f;
+constexpr float SPLIT3_ASCALE = 0.25f;
+constexpr float SPLIT3_OUTSCALE = 1.f / 256.f;   // undoes both on the fp32 accumulators
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+// v (already scaled) -> packed hi / lo halves
+__device__ __forceinline__ void split4_scaled(const float4 v, uint2& hi, uint2& lo) {
+    const h16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    const h16x4 l = {(_Float16)(v.x - (float)h[0]), (_Float16)(v.y - (float)h[1]), (_Float16)(v.z - (float)h[2]),
+                     (_Float16)(v.w - (float)h[3])};
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+// packed hi / lo halves -> fp32 values (unscaled)
+__device__ __forceinline__ float4 unsplit4(const uint2 hi, const uint2 lo, float inv_scale) {
+    const h16x4 h = __builtin_bit_cast(h16x4, hi), l = __builtin_bit_cast(h16x4, lo);
+    return make_float4(((float)h[0] + (float)l[0]) * inv_scale, ((float)h[1] + (float)l[1]) * inv_scale,
+                       ((float)h[2] + (float)l[2]) * inv_scale, ((float)h[3] + (float)l[3]) * inv_scale);
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACIMG_ACT_RELU) return fmaxf(v, 0.f);
     if (act == ACIMG_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));

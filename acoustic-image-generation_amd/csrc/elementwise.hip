@@ -533,6 +533,115 @@ __global__ __launch_bounds__(256) void sqerr_channels_kernel(const float* a, con
     if (threadIdx.x < C) atomicAdd(&out[threadIdx.x], acc[threadIdx.x]);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// producers of the split-fp16 activation format (two fp16 planes [rows][ld], lo plane lo_off bytes after
+// the hi plane; values carry the 2^-2 scale) consumed by igemm_split3p_kernel
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* x, const float* scale, const float* shift,
+                                                            int relu, char* out, long lo_off, long total4, int C4) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C4) * 4;
+        float4 v = reinterpret_cast<const float4*>(x)[idx];
+        if (scale) {
+            const float4 s = *reinterpret_cast<const float4*>(scale + c);
+            const float4 t = *reinterpret_cast<const float4*>(shift + c);
+            v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
+        }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        v.x *= SPLIT3_ASCALE; v.y *= SPLIT3_ASCALE; v.z *= SPLIT3_ASCALE; v.w *= SPLIT3_ASCALE;
+        uint2 hi, lo;
+        split4_scaled(v, hi, lo);
+        *reinterpret_cast<uint2*>(out + idx * 8) = hi;
+        *reinterpret_cast<uint2*>(out + lo_off + idx * 8) = lo;
+    }
+}
+
+// out = relu(a*sa+ta + shortcut) -> split planes (+ optional fp32 copy); shortcut = b32*sb+tb (projection,
+// raw fp32) or the previous unit output read back from ITS split planes (identity, optional subsampling)
+__global__ __launch_bounds__(256) void bn_add_relu_split_kernel(
+    const float* a, const float* sa, const float* ta, const float* b32, const float* sb, const float* tb,
+    const char* bsp, long b_lo_off, char* out, long out_lo_off, float* out32, long total4, int OH, int OW,
+    int C4, int BH, int BW, int bstride) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        const int c4 = (int)(idx % C4);
+        const long pix = idx / C4;
+        const int c = c4 * 4;
+        const float4 va = reinterpret_cast<const float4*>(a)[idx];
+        const float4 s = *reinterpret_cast<const float4*>(sa + c);
+        const float4 t = *reinterpret_cast<const float4*>(ta + c);
+        long bpix = pix;
+        if (bstride != 1) {
+            const int ow = (int)(pix % OW);
+            const long t2 = pix / OW;
+            const int oh = (int)(t2 % OH);
+            const long n = t2 / OH;
+            bpix = (n * BH + (long)oh * bstride) * BW + (long)ow * bstride;
+        }
+        float4 vb;
+        if (b32) {
+            vb = *reinterpret_cast<const float4*>(b32 + bpix * (C4 * 4) + c);
+            const float4 s2 = *reinterpret_cast<const float4*>(sb + c);
+            const float4 t2 = *reinterpret_cast<const float4*>(tb + c);
+            vb.x = vb.x * s2.x + t2.x; vb.y = vb.y * s2.y + t2.y; vb.z = vb.z * s2.z + t2.z; vb.w = vb.w * s2.w + t2.w;
+        } else {
+            const long e = (bpix * C4 + c4) * 8;
+            vb = unsplit4(*reinterpret_cast<const uint2*>(bsp + e), *reinterpret_cast<const uint2*>(bsp + b_lo_off + e),
+                          1.f / SPLIT3_ASCALE);
+        }
+        float4 o;
+        o.x = fmaxf(va.x * s.x + t.x + vb.x, 0.f);
+        o.y = fmaxf(va.y * s.y + t.y + vb.y, 0.f);
+        o.z = fmaxf(va.z * s.z + t.z + vb.z, 0.f);
+        o.w = fmaxf(va.w * s.w + t.w + vb.w, 0.f);
+        if (out32) reinterpret_cast<float4*>(out32)[idx] = o;
+        if (out) {
+            o.x *= SPLIT3_ASCALE; o.y *= SPLIT3_ASCALE; o.z *= SPLIT3_ASCALE; o.w *= SPLIT3_ASCALE;
+            uint2 hi, lo;
+            split4_scaled(o, hi, lo);
+            *reinterpret_cast<uint2*>(out + idx * 8) = hi;
+            *reinterpret_cast<uint2*>(out + out_lo_off + idx * 8) = lo;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_maxpool_split_kernel(const float* x, const float* scale,
+                                                                    const float* shift, char* out, long lo_off,
+                                                                    long total4, int H, int W, int C4, int OH,
+                                                                    int OW, int pad_t, int pad_l) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C4) * 4;
+        long t = idx / C4;
+        const int ow = (int)(t % OW);
+        t /= OW;
+        const int oh = (int)(t % OH);
+        const long n = t / OH;
+        const float4 s = *reinterpret_cast<const float4*>(scale + c);
+        const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ih = oh * 2 - pad_t + r;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int iw = ow * 2 - pad_l + q;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + ((n * H + ih) * W + iw) * (C4 * 4) + c);
+                m.x = fmaxf(m.x, v.x * s.x + sh.x);
+                m.y = fmaxf(m.y, v.y * s.y + sh.y);
+                m.z = fmaxf(m.z, v.z * s.z + sh.z);
+                m.w = fmaxf(m.w, v.w * s.w + sh.w);
+            }
+        }
+        m.x *= SPLIT3_ASCALE; m.y *= SPLIT3_ASCALE; m.z *= SPLIT3_ASCALE; m.w *= SPLIT3_ASCALE;
+        uint2 hi, lo;
+        split4_scaled(m, hi, lo);
+        *reinterpret_cast<uint2*>(out + idx * 8) = hi;
+        *reinterpret_cast<uint2*>(out + lo_off + idx * 8) = lo;
+    }
+}
+
 static inline int ew_grid(long work_items) {
     long b = (work_items + 255) / 256;
     if (b > 4096) b = 4096;
@@ -714,6 +823,43 @@ int acimg_sqerr_channels(const float* a, const float* b, long pixels, int C, flo
     hipLaunchKernelGGL(sqerr_channels_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, a, b, pixels,
                        C, out);
     return check_launch("sqerr_channels");
+}
+
+int acimg_bn_relu_split(const float* x, const float* scale, const float* shift, int relu, void* out,
+                        size_t lo_off, long rows, int C, void* stream) {
+    if ((C & 3) || (lo_off & 7) || !aligned16(x) || !aligned16(out))
+        return fail(ACIMG_EINVAL, "bn_relu_split: C must be a multiple of 4, buffers aligned");
+    const long total4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_relu_split_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, scale,
+                       shift, relu, static_cast<char*>(out), (long)lo_off, total4, C / 4);
+    return check_launch("bn_relu_split");
+}
+
+int acimg_bn_add_relu_split(const float* a, const float* sa, const float* ta, const float* b32,
+                            const float* sb, const float* tb, const void* b_planes, size_t b_lo_off,
+                            void* out_planes, size_t out_lo_off, float* out32, int N, int OH, int OW, int C,
+                            int BH, int BW, int bstride, void* stream) {
+    if (C & 3) return fail(ACIMG_EINVAL, "bn_add_relu_split: C must be a multiple of 4");
+    if ((b32 == nullptr) == (b_planes == nullptr))
+        return fail(ACIMG_EINVAL, "bn_add_relu_split: exactly one of b32 / b_planes");
+    if (b32 && (!sb || !tb)) return fail(ACIMG_EINVAL, "bn_add_relu_split: projection shortcut needs scale/shift");
+    const long total4 = (long)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(bn_add_relu_split_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, a, sa,
+                       ta, b32, sb, tb, static_cast<const char*>(b_planes), (long)b_lo_off,
+                       static_cast<char*>(out_planes), (long)out_lo_off, out32, total4, OH, OW, C / 4, BH, BW,
+                       bstride);
+    return check_launch("bn_add_relu_split");
+}
+
+int acimg_bn_relu_maxpool_split(const float* x, const float* scale, const float* shift, void* out,
+                                size_t lo_off, int N, int H, int W, int C, int OH, int OW, int pad_t, int pad_l,
+                                void* stream) {
+    if (C & 3) return fail(ACIMG_EINVAL, "bn_relu_maxpool_split: C must be a multiple of 4");
+    const long total4 = (long)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_split_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x,
+                       scale, shift, static_cast<char*>(out), (long)lo_off, total4, H, W, C / 4, OH, OW, pad_t,
+                       pad_l);
+    return check_launch("bn_relu_maxpool_split");
 }
 
 }  // extern "C"

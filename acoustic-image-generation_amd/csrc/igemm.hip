@@ -754,4 +754,42 @@ int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* 
     return check_launch("conv2d_fwd_split3");
 }
 
+int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
+                             float* y, float* stats, void* stream) {
+    int rc = check_desc(d, "conv2d_fwd_split3p");
+    if (rc) return rc;
+    if (d->C % 32) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: C=%d must be a multiple of 32", d->C);
+    if (d->ldw < d->K || !aligned16(x_planes) || !aligned16(wsplit) || !aligned16(y) || (d->ldy & 3) || (d->ldx & 7) ||
+        (x_lo_off & 15))
+        return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: ldw<K or unaligned operands");
+    IgemmParams p{};
+    p.A = static_cast<const float*>(x_planes); p.H = d->H; p.W = d->W; p.C = d->C; p.lda = d->ldx;
+    p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride;
+    p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.M = d->N * d->OH * d->OW;
+    p.B = static_cast<const float*>(wsplit); p.Nld = d->ldw; p.Ngemm = d->K;
+    p.ntaps = d->R * d->S;
+    p.kiters = p.ntaps * (d->C / 32);
+    p.splits = 1;
+    const long plane = (((long)d->N * d->H * d->W - 1) * d->ldx + d->C) * 2;
+    const long a_bytes = (long)x_lo_off + plane;
+    const long b_bytes = (long)acimg_conv2d_split3_weight_bytes(d);
+    if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31) || (long)x_lo_off < plane)
+        return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: operand >= 2 GiB or overlapping planes");
+    p.a_bytes = (unsigned)a_bytes; p.b_bytes = (unsigned)b_bytes; p.a_lo_off = (unsigned)x_lo_off;
+    EpiParams& e = p.e;
+    e.Y = y; e.ldy = d->ldy; e.M = p.M; e.Nstore = d->K; e.act = d->act;
+    e.stats = stats; e.stats_ld = d->ldw; e.vec = 1;
+    Split3Cfg c = pick_split3(p.M, d->K);
+    dim3 grid(cdiv(p.M, c.bm), cdiv(d->K, c.bn), 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (c.bm == 128 && c.bn == 128)
+        hipLaunchKernelGGL((igemm_split3p_kernel<128, 128, 2, 4, 512>), grid, dim3(512), 65536, st, p);
+    else if (c.bm == 64 && c.bn == 128)
+        hipLaunchKernelGGL((igemm_split3p_kernel<64, 128, 1, 4, 256>), grid, dim3(256), 2 * (2 * 64 * 64 + 2 * 128 * 64), st, p);
+    else
+        hipLaunchKernelGGL((igemm_split3p_kernel<128, 64, 2, 2, 256>), grid, dim3(256), 2 * (2 * 128 * 64 + 2 * 64 * 64), st, p);
+    return check_launch("conv2d_fwd_split3p");
+}
+
 }  // extern "C"

@@ -50,6 +50,7 @@ struct IgemmParams {
     int Ngemm;  // number of GEMM columns
     int Nld;    // NN: valid floats per B row (multiple of 4)
     unsigned a_bytes, b_bytes;  // extents for the buffer resource descriptors
+    unsigned a_lo_off;          // split3p: byte distance from the hi plane to the lo plane of A
     // split-K
     int splits;
     float* slab;  // [splits][M][slab_ld]

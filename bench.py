@@ -120,7 +120,7 @@ def main():
     f16 = args.precision == "f16x3"
     cand = {}
     for i, (name, fn, a) in enumerate(g.plan_train.calls):
-        if name == "conv2d_fwd_split3" and f16:
+        if name in ("conv2d_fwd_split3", "conv2d_fwd_split3p") and f16:
             d = a[0]._obj
             key = ops.conv2d_fwd_split3_tiling(d)
         elif name == "conv2d_fwd" and not f16:
@@ -135,7 +135,7 @@ def main():
     probe_idx = set(i for i, _ in cand[tile])
     flops = dict(cand[tile])
     TILE_THREADS = {(128, 128): "2,4,512", (64, 128): "1,4,256", (128, 64): "2,2,256"}
-    kernel_name = ("igemm_split3_kernel<%d,%d,%s>" % (tile[0], tile[1], TILE_THREADS[tile[:2]]) if f16
+    kernel_name = ("igemm_split3p_kernel<%d,%d,%s>" % (tile[0], tile[1], TILE_THREADS[tile[:2]]) if f16
                    else "igemm_f32_kernel<%d,%d,...,false,true>" % (tile[0], tile[1]))
     for _ in range(args.warmup):
         tr.train_step(sync=False)

@@ -94,6 +94,27 @@ int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* 
                             const float* in_scale, const float* in_shift, int in_relu, float* stats,
                             void* stream);
 
+/* Pre-split activation format: a tensor [rows][C] is stored as TWO fp16 planes (hi at ptr, lo `lo_off`
+ * bytes further), hi = f16(v/4), lo = f16(v/4 - hi): 22 mantissa bits in the same 4 bytes per element as
+ * fp32.  The elementwise producers below write it (the BN affine + ReLU is already applied), and
+ * acimg_conv2d_fwd_split3p consumes it: both GEMM operands are then plain 16-byte copies into LDS, so the
+ * K loop of the trunk convs carries no conversion / normalisation work at all.
+ *   acimg_bn_relu_split:         planes = relu?(x*scale+shift)            (BN of a bottleneck conv, resnet50.py:109-121)
+ *   acimg_bn_add_relu_split:     planes (+ optional fp32) = relu(a*sa+ta + shortcut); shortcut = b32*sb+tb
+ *                                (projection) or the previous unit's planes (identity / subsample)   (resnet50.py:104-123)
+ *   acimg_bn_relu_maxpool_split: planes = maxpool3x3/s2(relu(x*scale+shift))                        (resnet50.py:207-208) */
+int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
+                             float* y, float* stats, void* stream);
+int acimg_bn_relu_split(const float* x, const float* scale, const float* shift, int relu, void* out,
+                        size_t lo_off, long rows, int C, void* stream);
+int acimg_bn_add_relu_split(const float* a, const float* sa, const float* ta, const float* b32,
+                            const float* sb, const float* tb, const void* b_planes, size_t b_lo_off,
+                            void* out_planes, size_t out_lo_off, float* out32, int N, int OH, int OW, int C,
+                            int BH, int BW, int bstride, void* stream);
+int acimg_bn_relu_maxpool_split(const float* x, const float* scale, const float* shift, void* out,
+                                size_t lo_off, int N, int H, int W, int C, int OH, int OW, int pad_t, int pad_l,
+                                void* stream);
+
 /* Data gradient.  gy is the gradient w.r.t. the conv's PRE-activation output [N,OH,OW,K]
  * (pixel stride ldgy); dx = relu_mask(conv_T(gy, w) + residual): `residual` (optional, pixel
  * stride ldres) is another gradient flowing into x (fan-out), `mask` (optional, pixel stride

@@ -216,6 +216,96 @@ def test_conv2d_fwd_f16x3(device, case):
     close(y, tf_conv_ref(x, w, stride, pads), tol=2e-6, what="f16x3 conv plain %s" % (case,))
 
 
+def unsplit(planes, lo_off, rows, Cc):
+    """two fp16 planes (uint8 buffer) -> float64 [rows, C] (undoing the 2^-2 scale)"""
+    n = rows * Cc
+    hi = planes[: 2 * n].view(torch.float16).double()
+    lo = planes[lo_off: lo_off + 2 * n].view(torch.float16).double()
+    return ((hi + lo) * 4.0).reshape(rows, Cc).cpu()
+
+
+@pytest.mark.parametrize("case", SPLIT3_CASES[:4])
+def test_presplit_activation_path(device, case):
+    """pre-split activation format: bn_relu_split producer + split3p conv (with statistics) vs fp64, and
+    the planes themselves vs the values they encode (22 mantissa bits: 5e-7 relative to max)"""
+    from acimg import ops
+
+    N, H, W, Cc, K, R, S, stride, padding = case
+    g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)) + 9)
+    x = rnd(g, N, H, W, Cc)
+    sc, sh = rnd(g, Cc).abs() + 0.5, rnd(g, Cc)
+    w = rnd(g, R, S, Cc, K) * (2.0 / (R * S * Cc)) ** 0.5
+    OH, OW, pads = _conv_geom(H, W, R, S, stride, padding)
+    xa = torch.relu(x * sc + sh)
+    ref = tf_conv_ref(xa, w, stride, pads)
+    d = ops.conv_desc(N, H, W, Cc, K, R, S, stride, padding)
+    rows = N * H * W
+    lo_off = -(-rows * Cc * 2 // 256) * 256
+    planes = torch.zeros(lo_off * 2, dtype=torch.uint8, device=device)
+    plan = ops.Plan(device, eager=True)
+    ops.bn_relu_split(plan, dev(x, device), dev(sc, device), dev(sh, device), 1, planes, lo_off, rows, Cc)
+    torch.cuda.synchronize()
+    close(unsplit(planes, lo_off, rows, Cc), xa.reshape(rows, Cc), tol=5e-7, what="split planes")
+    wsplit = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=device)
+    ops.conv2d_split3_prepare(plan, d, dev(w, device), wsplit)
+    y = torch.full((N, OH, OW, K), 7.0, device=device)
+    srows = ops.conv2d_fwd_split3_stats_rows(d)
+    stats = torch.zeros(srows, 2, K, device=device)
+    ops.conv2d_fwd_split3p(plan, d, planes, lo_off, wsplit, y, stats)
+    torch.cuda.synchronize()
+    close(y, ref, tol=2e-6, what="split3p conv %s" % (case,))
+    flat = ref.reshape(-1, K)
+    close(stats[:, 0].sum(0), flat.sum(0), tol=2e-4, what="split3p stats sum")
+    close(stats[:, 1].sum(0), (flat * flat).sum(0), tol=2e-4, what="split3p stats sumsq")
+
+
+def test_presplit_unit_output_and_pool(device):
+    from acimg import ops
+
+    g = torch.Generator().manual_seed(21)
+    plan = ops.Plan(device, eager=True)
+    N, OH, OW, Cc = 2, 7, 9, 64
+    rows = N * OH * OW
+    lo = -(-rows * Cc * 2 // 256) * 256
+    a, sa, ta = rnd(g, N, OH, OW, Cc), rnd(g, Cc), rnd(g, Cc)
+    # projection shortcut (raw fp32 + affine), planes + fp32 copy out
+    b, sb, tb = rnd(g, N, OH, OW, Cc), rnd(g, Cc), rnd(g, Cc)
+    out = torch.zeros(2 * lo, dtype=torch.uint8, device=device)
+    out32 = torch.empty(N, OH, OW, Cc, device=device)
+    ops.bn_add_relu_split(plan, dev(a, device), dev(sa, device), dev(ta, device), dev(b, device), dev(sb, device),
+                          dev(tb, device), None, 0, out, lo, out32, N, OH, OW, Cc, OH, OW, 1)
+    ref = torch.relu(a * sa + ta + b * sb + tb)
+    torch.cuda.synchronize()
+    close(out32, ref, what="unit out fp32")
+    close(unsplit(out, lo, rows, Cc), ref.reshape(rows, Cc), tol=5e-7, what="unit out planes")
+    # identity shortcut read back from split planes, with stride-2 subsampling
+    BH, BW = 2 * OH - 1, 2 * OW
+    prev = torch.relu(rnd(g, N, BH, BW, Cc))
+    prow = N * BH * BW
+    plo = -(-prow * Cc * 2 // 256) * 256
+    pplanes = torch.zeros(2 * plo, dtype=torch.uint8, device=device)
+    ops.bn_relu_split(plan, dev(prev, device), None, None, 0, pplanes, plo, prow, Cc)
+    ops.bn_add_relu_split(plan, dev(a, device), dev(sa, device), dev(ta, device), None, None, None, pplanes, plo, out,
+                          lo, None, N, OH, OW, Cc, BH, BW, 2)
+    torch.cuda.synchronize()
+    close(unsplit(out, lo, rows, Cc), torch.relu(a * sa + ta + prev[:, ::2, ::2]).reshape(rows, Cc), tol=1e-6,
+          what="unit out (identity from planes)")
+    # pool1 writing planes
+    N, H, W, Cc = 2, 112, 149, 8
+    x, sc, sh = rnd(g, N, H, W, Cc), rnd(g, Cc), rnd(g, Cc)
+    OHp, pt, pb = same_pads(H, 3, 2)
+    OWp, pl, pr = same_pads(W, 3, 2)
+    xa = torch.relu(x * sc + sh).permute(0, 3, 1, 2)
+    ref = F.max_pool2d(F.pad(xa, (pl, pr, pt, pb), value=-1e30), 3, 2).permute(0, 2, 3, 1)
+    rows = N * OHp * OWp
+    lo = -(-rows * Cc * 2 // 256) * 256
+    out = torch.zeros(2 * lo, dtype=torch.uint8, device=device)
+    ops.bn_relu_maxpool_split(plan, dev(x, device), dev(sc, device), dev(sh, device), out, lo, N, H, W, Cc, OHp, OWp,
+                              pt, pl)
+    torch.cuda.synchronize()
+    close(unsplit(out, lo, rows, Cc), ref.reshape(rows, Cc), tol=5e-7, what="pool planes")
+
+
 DGRAD_CASES = [
     (2, 9, 11, 8, 20, 3, 3, 1, "SAME"),
     (2, 12, 16, 12, 133, 3, 3, 1, "SAME"),

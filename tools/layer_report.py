@@ -19,10 +19,10 @@ tr = Trainer(UNetAc(input_shape=[36, 48, 12]), ResNet50Model(input_shape=[224, 2
 g = tr._build_functions(batch_size=B)
 calls = []
 for name, fn, a in g.plan_train.calls:
-    if name in ("conv2d_fwd", "conv2d_fwd_split3", "conv2d_dgrad", "deconv_fwd", "deconv_dgrad"):
+    if name in ("conv2d_fwd", "conv2d_fwd_split3", "conv2d_fwd_split3p", "conv2d_dgrad", "deconv_fwd", "deconv_dgrad"):
         calls.append((name, a[0]._obj))
 rows = list(csv.DictReader(open(trace)))
-ig = [r for r in rows if "igemm_f32_kernel" in r["Kernel_Name"] or "igemm_split3_kernel" in r["Kernel_Name"]]
+ig = [r for r in rows if "igemm_f32_kernel" in r["Kernel_Name"] or "igemm_split3" in r["Kernel_Name"]]
 last = ig[-len(calls):]
 print("%-4s %-13s %-30s %-22s %8s %8s %8s" % ("#", "op", "HxW C->K RxS/s", "kernel", "us", "TFLOP/s", "GB/s"))
 tot = {}
