@@ -13,6 +13,7 @@
 // is permuted identically for A and B (lane group g owns k = 4g..4g+3), which leaves the sum
 // unchanged.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t.
 #include "igemm_split3_kernel.hpp"
+#include <cstdlib>
 
 namespace acimg {
 
@@ -670,30 +671,19 @@ int acimg_deconv_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, 
 // f16x3 (split fp16) forward convolution (frozen ResNet trunk)
 // ------------------------------------------------------------------------------------------
 struct Split3Cfg { int bm, bn; };
-// Tiles of one launch all cost the same, so the launch takes ceil(tiles / resident slots) "rounds": a layer
-// with 1050 tiles on 512 slots pays for 3 rounds of 128x128 work.  Pick the tiling with the least
-// rounds x tile-area (smaller tiles: 3 workgroups per CU instead of 2, slightly less reuse per tile).
+// Tile choice, measured per trunk conv shape at batch 32 (tools/tune_split3.py): the 8-wave 128x128 tile
+// (2 workgroups/CU) beats or ties 64x128 on every shape but the 1x1 convs of the 14x19 stage (M = 8512,
+// 67 row tiles), 128x64 always loses, 256x128 drops to 2 waves/SIMD and loses 17 %.
 static Split3Cfg pick_split3(int M, int K) {
     if (K <= 64) return {128, 64};
-    struct Cand { int bm, bn, slots; double eff; };
-    const Cand cands[3] = {{128, 128, 512, 1.0}, {64, 128, 768, 0.88}, {128, 64, 768, 0.80}};
-    double best = 1e30;
-    Split3Cfg pick = {128, 128};
-    for (const Cand& c : cands) {
-        const long tiles = (long)cdiv(M, c.bm) * cdiv(K, c.bn);
-        const long rounds = (tiles + c.slots - 1) / c.slots;
-        const double cost = (double)rounds * c.bm * c.bn / c.eff;
-        if (cost < best) {
-            best = cost;
-            pick = {c.bm, c.bn};
-        }
+    if (const char* ov = getenv("ACIMG_SPLIT3_TILE")) {   // experiments only: "BMxBN"
+        int bm = 0, bn = 0;
+        if (sscanf(ov, "%dx%d", &bm, &bn) == 2 && ((bm == 128 && bn == 128) || (bm == 64 && bn == 128) ||
+                                                   (bm == 128 && bn == 64) || (bm == 256 && bn == 128)))
+            return {bm, bn};
     }
-    return pick;
-}
-
-int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d) {
-    const int M = d->N * d->OH * d->OW;
-    return cdiv(M, pick_split3(M, d->K).bm);
+    if ((long)cdiv(M, 128) * cdiv(K, 128) < 300) return {64, 128};
+    return {128, 128};
 }
 
 int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out) {
@@ -783,7 +773,9 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
     Split3Cfg c = pick_split3(p.M, d->K);
     dim3 grid(cdiv(p.M, c.bm), cdiv(d->K, c.bn), 1);
     hipStream_t st = (hipStream_t)stream;
-    if (c.bm == 128 && c.bn == 128)
+    if (c.bm == 256 && c.bn == 128)
+        hipLaunchKernelGGL((igemm_split3p_kernel<256, 128, 4, 2, 512>), grid, dim3(512), 2 * (2 * 256 * 64 + 2 * 128 * 64), st, p);
+    else if (c.bm == 128 && c.bn == 128)
         hipLaunchKernelGGL((igemm_split3p_kernel<128, 128, 2, 4, 512>), grid, dim3(512), 65536, st, p);
     else if (c.bm == 64 && c.bn == 128)
         hipLaunchKernelGGL((igemm_split3p_kernel<64, 128, 1, 4, 256>), grid, dim3(256), 2 * (2 * 64 * 64 + 2 * 128 * 64), st, p);

@@ -134,7 +134,7 @@ def main():
     tile = max(cand, key=lambda k: sum(f for _, f in cand[k]))
     probe_idx = set(i for i, _ in cand[tile])
     flops = dict(cand[tile])
-    TILE_THREADS = {(128, 128): "2,4,512", (64, 128): "1,4,256", (128, 64): "2,2,256"}
+    TILE_THREADS = {(128, 128): "2,4,512", (64, 128): "1,4,256", (128, 64): "2,2,256", (256, 128): "4,2,512"}
     kernel_name = ("igemm_split3p_kernel<%d,%d,%s>" % (tile[0], tile[1], TILE_THREADS[tile[:2]]) if f16
                    else "igemm_f32_kernel<%d,%d,...,false,true>" % (tile[0], tile[1]))
     for _ in range(args.warmup):
