@@ -265,9 +265,22 @@ def conv2d_split3_prepare(plan, d, w, wsplit):
     plan.add("conv2d_split3_prepare", _L().acimg_conv2d_split3_prepare, C.byref(d), w, wsplit)
 
 
-def conv2d_fwd_split3(plan, d, x, wsplit, y, in_scale=None, in_shift=None, in_relu=0, stats=None):
-    plan.add("conv2d_fwd_split3", _L().acimg_conv2d_fwd_split3, C.byref(d), x, wsplit, y, in_scale, in_shift,
+def conv2d_fwd_split3(plan, d, x, wsplit, y, in_scale=None, in_shift=None, in_relu=0, stats=None, bias=None):
+    plan.add("conv2d_fwd_split3", _L().acimg_conv2d_fwd_split3, C.byref(d), x, wsplit, bias, y, in_scale, in_shift,
              int(in_relu), stats)
+
+
+def conv2d_split3_dgrad_weight_bytes(d):
+    return _L().acimg_conv2d_split3_dgrad_weight_bytes(C.byref(d))
+
+
+def conv2d_split3_prepare_dgrad(plan, d, w, wsplit):
+    plan.add("conv2d_split3_prepare_dgrad", _L().acimg_conv2d_split3_prepare_dgrad, C.byref(d), w, wsplit)
+
+
+def conv2d_dgrad_split3(plan, d, gy, ldgy, wsplit_t, dx, residual=None, ldres=0, mask=None, ldmask=0, lddx=0):
+    plan.add("conv2d_dgrad_split3", _L().acimg_conv2d_dgrad_split3, C.byref(d), gy, int(ldgy), wsplit_t, dx,
+             int(lddx), residual, int(ldres), mask, int(ldmask))
 
 
 def conv2d_fwd_split3p(plan, d, x_planes, x_lo_off, wsplit, y, stats=None):

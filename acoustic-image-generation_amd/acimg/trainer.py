@@ -143,7 +143,7 @@ class Trainer(object):
         # a different batch size (last partial batch): same variables, new buffers + plans
         mi = type(self.modelimages)(input_shape=[224, 298, 3], num_classes=None, precision=self.modelimages.precision)
         ma = type(self.modelac)(input_shape=[36, 48, 12], embedding=self.modelac.embedding,
-                                num_skip=self.modelac.num_skip)
+                                num_skip=self.modelac.num_skip, precision=self.modelac.precision)
         mi._register = lambda store: None
         ma_heads = self.modelac.heads
 

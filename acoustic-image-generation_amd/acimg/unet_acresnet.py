@@ -50,7 +50,13 @@ class Act(object):
 
 class UNetAc(object):
 
-    def __init__(self, input_shape=None, num_frames=12, embedding=False, num_skip=1):
+    def __init__(self, input_shape=None, num_frames=12, embedding=False, num_skip=1, precision="split"):
+        """precision: "split" = the large convs on the split-MFMA kernels (fp32-class results), "f32" = every
+        conv on the exact-f32 MFMA kernel"""
+        assert precision in ("split", "f32")
+        self.precision = precision
+        self.split_min_rows = 16384      # below this the f32 kernel (64x64 tiles + split-K) fills the chip better
+        self._wsplit_bufs = {}
         self.scope = 'UNetAcRes'
         self.num_frames = num_frames
         self.height = input_shape[0]
@@ -212,10 +218,28 @@ class UNetAc(object):
         return ops.conv_desc(x.N, x.H, x.W, x.Cp if x.off == 0 and x.ld == x.Cp else x.C, K, 3, 3, stride, "SAME",
                              ldx=x.ld, ldy=(y.ld if y is not None else up4(K)), ldw=up4(K), act=act)
 
+    def _use_split(self, d):
+        """big stride-1 convs of the generator run on the split-MFMA kernels (forward f16x3, data gradient
+        bf16x3); the 12x16 layers (48 row tiles: they need split-K) and the 12/133-channel layers stay f32"""
+        return (self.precision == "split" and d.stride == 1 and d.C % 32 == 0 and d.K % 32 == 0 and
+                d.N * d.OH * d.OW >= self.split_min_rows)
+
+    def _wsplit(self, name, nbytes, kind):
+        key = (name, kind)
+        if key not in self._wsplit_bufs:
+            self._wsplit_bufs[key] = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.session.device)
+        return self._wsplit_bufs[key]
+
     def _conv(self, plan, name, x, y, stride=1, act=ACT_RELU):
         d = self._desc(x, y.C, stride, y, act)
         self._descs[name] = (d, x, y)
-        ops.conv2d_fwd(plan, d, x.ptr, self._P(name + "/kernel"), self._P(name + "/bias"), y.ptr)
+        if self._use_split(d):
+            # the kernel changes every step: re-split it right before use (one tiny launch)
+            ws = self._wsplit(name, ops.conv2d_split3_weight_bytes(d), "fwd")
+            ops.conv2d_split3_prepare(plan, d, self._P(name + "/kernel"), ws)
+            ops.conv2d_fwd_split3(plan, d, x.ptr, ws, y.ptr, bias=self._P(name + "/bias"))
+        else:
+            ops.conv2d_fwd(plan, d, x.ptr, self._P(name + "/kernel"), self._P(name + "/bias"), y.ptr)
 
     def _record_forward(self, plan):
         N = self.N
@@ -275,7 +299,14 @@ class UNetAc(object):
             """weight/bias gradient of conv `name`, and its data gradient into dx (if given)"""
             d, x, y = self._descs[name]
             ops.conv2d_wgrad(plan, d, x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
-            if dx is not None:
+            if dx is not None and self._use_split(d):
+                wt = self._wsplit(name, ops.conv2d_split3_dgrad_weight_bytes(d), "dgrad")
+                ops.conv2d_split3_prepare_dgrad(plan, d, self._P(name + "/kernel"), wt)
+                ops.conv2d_dgrad_split3(plan, d, gy.ptr, gy.ld, wt, dx.ptr,
+                                        res.ptr if res is not None else None, res.ld if res is not None else 0,
+                                        mask.ptr if mask is not None else None, mask.ld if mask is not None else 0,
+                                        lddx=dx.ld)
+            elif dx is not None:
                 ops.conv2d_dgrad(plan, d, gy.ptr, gy.ld, self._P(name + "/kernel"), dx.ptr,
                                  res.ptr if res is not None else None, res.ld if res is not None else 0,
                                  mask.ptr if mask is not None else None, mask.ld if mask is not None else 0,

@@ -686,6 +686,11 @@ static Split3Cfg pick_split3(int M, int K) {
     return {128, 128};
 }
 
+int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d) {
+    const int M = d->N * d->OH * d->OW;
+    return cdiv(M, pick_split3(M, d->K).bm);
+}
+
 int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out) {
     if (!d || !out) return fail(ACIMG_EINVAL, "conv2d_fwd_split3_tiling: null argument");
     Split3Cfg c = pick_split3(d->N * d->OH * d->OW, d->K);
@@ -702,18 +707,55 @@ int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* ws
     int rc = check_desc(d, "conv2d_split3_prepare");
     if (rc) return rc;
     const int Ktot = d->R * d->S * d->C;
-    hipLaunchKernelGGL(split3_prepare_kernel, dim3(cdiv(Ktot, 32), cdiv(d->ldw, 32)), dim3(256), 0,
-                       (hipStream_t)stream, w, Ktot, d->ldw, d->ldw, static_cast<_Float16*>(wsplit));
+    hipLaunchKernelGGL((split3_prepare_kernel<SplitF16, false>), dim3(cdiv(Ktot, 32), cdiv(d->ldw, 32)), dim3(256), 0,
+                       (hipStream_t)stream, w, d->R * d->S, d->C, d->K, d->ldw, d->ldw, static_cast<_Float16*>(wsplit));
     return check_launch("split3_prepare");
 }
 
-int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* wsplit, float* y,
-                         const float* in_scale, const float* in_shift, int in_relu, float* stats,
-                         void* stream) {
+size_t acimg_conv2d_split3_dgrad_weight_bytes(const AcimgConvDesc* d) {
+    return (size_t)2 * d->C * d->R * d->S * up4(d->K) * 2;
+}
+
+int acimg_conv2d_split3_prepare_dgrad(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream) {
+    int rc = check_desc(d, "conv2d_split3_prepare_dgrad");
+    if (rc) return rc;
+    if (d->K % 32 || d->K > d->ldw) return fail(ACIMG_EINVAL, "conv2d_split3_prepare_dgrad: K must be a multiple of 32");
+    const int Ktot = d->R * d->S * d->K;
+    hipLaunchKernelGGL((split3_prepare_kernel<SplitBF16, true>), dim3(cdiv(Ktot, 32), cdiv(d->C, 32)), dim3(256), 0,
+                       (hipStream_t)stream, w, d->R * d->S, d->C, d->K, d->ldw, d->C, static_cast<__bf16*>(wsplit));
+    return check_launch("split3_prepare_dgrad");
+}
+
+extern "C++" {
+template <typename TR>
+static int launch_split3(IgemmParams& p, hipStream_t st) {
+    Split3Cfg c = pick_split3(p.M, p.Ngemm);
+    dim3 grid(cdiv(p.M, c.bm), cdiv(p.Ngemm, c.bn), 1);
+    if (c.bm == 128 && c.bn == 128)
+        hipLaunchKernelGGL((igemm_split3_kernel<128, 128, 2, 4, 512, TR>), grid, dim3(512), 65536, st, p);
+    else if (c.bm == 64 && c.bn == 128)
+        hipLaunchKernelGGL((igemm_split3_kernel<64, 128, 1, 4, 256, TR>), grid, dim3(256), 2 * (2 * 64 * 64 + 2 * 128 * 64), st, p);
+    else if (c.bm == 128 && c.bn == 64)
+        hipLaunchKernelGGL((igemm_split3_kernel<128, 64, 2, 2, 256, TR>), grid, dim3(256), 2 * (2 * 128 * 64 + 2 * 64 * 64), st, p);
+    else
+        return fail(ACIMG_EINVAL, "split3: unsupported tile %dx%d", c.bm, c.bn);
+    return check_launch("igemm_split3");
+}
+
+static void epi_vec_flag(EpiParams& e) {
+    e.vec = aligned16(e.Y) && (e.ldy & 3) == 0 && (!e.bias || aligned16(e.bias)) &&
+            (!e.res || (aligned16(e.res) && (e.ldres & 3) == 0)) &&
+            (!e.mask || (aligned16(e.mask) && (e.ldmask & 3) == 0)) && (!e.scatter || (e.Ko & 3) == 0);
+}
+}  // extern "C++"
+
+int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* wsplit, const float* bias,
+                            float* y, const float* in_scale, const float* in_shift, int in_relu, float* stats,
+                            void* stream) {
     int rc = check_desc(d, "conv2d_fwd_split3");
     if (rc) return rc;
     if (d->C % 32) return fail(ACIMG_EINVAL, "conv2d_fwd_split3: C=%d must be a multiple of 32", d->C);
-    if (d->ldw < d->K || !aligned16(x) || !aligned16(wsplit) || !aligned16(y) || (d->ldy & 3))
+    if (d->ldw < d->K || !aligned16(x) || !aligned16(wsplit))
         return fail(ACIMG_EINVAL, "conv2d_fwd_split3: ldw<K or unaligned operands");
     IgemmParams p{};
     p.A = x; p.H = d->H; p.W = d->W; p.C = d->C; p.lda = d->ldx;
@@ -730,18 +772,39 @@ int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* 
     if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) return fail(ACIMG_EINVAL, "conv2d_fwd_split3: operand >= 2 GiB");
     p.a_bytes = (unsigned)a_bytes; p.b_bytes = (unsigned)b_bytes;
     EpiParams& e = p.e;
-    e.Y = y; e.ldy = d->ldy; e.M = p.M; e.Nstore = d->K; e.act = d->act;
-    e.stats = stats; e.stats_ld = d->ldw; e.vec = 1;
-    Split3Cfg c = pick_split3(p.M, d->K);
-    dim3 grid(cdiv(p.M, c.bm), cdiv(d->K, c.bn), 1);
-    hipStream_t st = (hipStream_t)stream;
-    if (c.bm == 128 && c.bn == 128)
-        hipLaunchKernelGGL((igemm_split3_kernel<128, 128, 2, 4, 512>), grid, dim3(512), 65536, st, p);
-    else if (c.bm == 64 && c.bn == 128)
-        hipLaunchKernelGGL((igemm_split3_kernel<64, 128, 1, 4, 256>), grid, dim3(256), 2 * (2 * 64 * 64 + 2 * 128 * 64), st, p);
-    else
-        hipLaunchKernelGGL((igemm_split3_kernel<128, 64, 2, 2, 256>), grid, dim3(256), 2 * (2 * 128 * 64 + 2 * 64 * 64), st, p);
-    return check_launch("conv2d_fwd_split3");
+    e.Y = y; e.ldy = d->ldy; e.M = p.M; e.Nstore = d->K; e.act = d->act; e.bias = bias;
+    e.stats = stats; e.stats_ld = d->ldw;
+    epi_vec_flag(e);
+    return launch_split3<SplitF16>(p, (hipStream_t)stream);
+}
+
+/* data gradient on the bf16x3 path (stride-1 convs): a forward conv of gy with the flipped/transposed kernel */
+int acimg_conv2d_dgrad_split3(const AcimgConvDesc* d, const float* gy, int ldgy, const void* wsplit_t, float* dx,
+                              int lddx, const float* residual, int ldres, const float* mask, int ldmask,
+                              void* stream) {
+    int rc = check_desc(d, "conv2d_dgrad_split3");
+    if (rc) return rc;
+    if (d->stride != 1 || d->K % 32 || d->K > ldgy || (ldgy & 3))
+        return fail(ACIMG_EINVAL, "conv2d_dgrad_split3: needs stride 1 and K %% 32 == 0 (K=%d)", d->K);
+    if (lddx <= 0) lddx = d->ldx;
+    IgemmParams p{};
+    p.A = gy; p.H = d->OH; p.W = d->OW; p.C = d->K; p.lda = ldgy;
+    p.OH = d->H; p.OW = d->W; p.R = d->R; p.S = d->S; p.stride = 1;
+    p.pad_t = d->R - 1 - d->pad_t; p.pad_l = d->S - 1 - d->pad_l;
+    p.M = d->N * d->H * d->W;
+    p.B = static_cast<const float*>(wsplit_t); p.Nld = d->C; p.Ngemm = d->C;
+    p.ntaps = d->R * d->S;
+    p.kiters = p.ntaps * (d->K / 32);
+    p.splits = 1;
+    const long a_bytes = (((long)d->N * d->OH * d->OW - 1) * ldgy + d->K) * 4;
+    const long b_bytes = (long)acimg_conv2d_split3_dgrad_weight_bytes(d);
+    if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) return fail(ACIMG_EINVAL, "conv2d_dgrad_split3: operand >= 2 GiB");
+    p.a_bytes = (unsigned)a_bytes; p.b_bytes = (unsigned)b_bytes;
+    EpiParams& e = p.e;
+    e.Y = dx; e.ldy = lddx; e.M = p.M; e.Nstore = d->C; e.act = ACIMG_ACT_NONE;
+    e.res = residual; e.ldres = ldres; e.mask = mask; e.ldmask = ldmask;
+    epi_vec_flag(e);
+    return launch_split3<SplitBF16>(p, (hipStream_t)stream);
 }
 
 int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,

@@ -24,37 +24,83 @@ namespace acimg {
 
 // SPLIT3_* constants and the h16 vector types live in common.hpp (shared with the elementwise producers)
 
+// Element type of the split: fp16 (22 mantissa bits, needs the power-of-two range scaling; forward passes)
+// or bf16 (16 mantissa bits, fp32's range, no scaling; backward passes, where gradients ~1e-7 would
+// underflow fp16).
+struct SplitF16 {
+    typedef _Float16 T;
+    typedef h16x8 V8;
+    static constexpr float ASCALE = SPLIT3_ASCALE, WSCALE = SPLIT3_WSCALE, OUTSCALE = SPLIT3_OUTSCALE;
+    static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x4 __attribute__((ext_vector_type(4)));
+struct SplitBF16 {
+    typedef __bf16 T;
+    typedef b16x8 V8;
+    static constexpr float ASCALE = 1.f, WSCALE = 1.f, OUTSCALE = 1.f;
+    static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename TR>
 __device__ __forceinline__ void split4(float4 v, uint2& hi, uint2& lo) {
-    v.x *= SPLIT3_ASCALE; v.y *= SPLIT3_ASCALE; v.z *= SPLIT3_ASCALE; v.w *= SPLIT3_ASCALE;
-    split4_scaled(v, hi, lo);
+    typedef typename TR::T T;
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    if (TR::ASCALE != 1.f) { v.x *= TR::ASCALE; v.y *= TR::ASCALE; v.z *= TR::ASCALE; v.w *= TR::ASCALE; }
+    const T4 h = {(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+    const T4 l = {(T)(v.x - (float)h[0]), (T)(v.y - (float)h[1]), (T)(v.z - (float)h[2]), (T)(v.w - (float)h[3])};
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
 }
 
-// w fp32 [Ktot][ldw] (HWIO flattened) -> out fp16 [2][Nrows][Ktot]: out[0]=hi, out[1]=lo of w*2^10, transposed
-__global__ __launch_bounds__(256) void split3_prepare_kernel(const float* w, int Ktot, int ldw, int Nrows,
-                                                             _Float16* out) {
+// Weight preparation: fp32 HWIO kernel w[tap][c][ldw] -> split + transposed planes out[2][Nrows][Ktot]
+// (out[0] = hi, out[1] = lo of w * WSCALE, k contiguous).
+//   FWD  : rows n = output channel,  k = tap*C + c            value W[tap][c][n]
+//   DGRAD: rows n = input channel c, k = tap'*K + ko          value W[ntaps-1-tap'][n][ko]   (flipped taps)
+template <typename TR, bool DGRAD>
+__global__ __launch_bounds__(256) void split3_prepare_kernel(const float* w, int ntaps, int C, int K, int ldw,
+                                                             int Nrows, typename TR::T* out) {
+    typedef typename TR::T T;
     __shared__ float tile[32][33];
+    const int Ktot = DGRAD ? ntaps * K : ntaps * C;
     const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int k = k0 + ty + 8 * i, n = n0 + tx;
-        tile[ty + 8 * i][tx] = (k < Ktot && n < ldw) ? w[(long)k * ldw + n] : 0.f;
+        float v = 0.f;
+        if constexpr (!DGRAD) {
+            const int k = k0 + ty + 8 * i, n = n0 + tx;      // coalesced along n
+            if (k < Ktot && n < ldw) v = w[(long)k * ldw + n];
+            tile[ty + 8 * i][tx] = v;                        // tile[k][n]
+        } else {
+            const int n = n0 + ty + 8 * i, k = k0 + tx;      // coalesced along ko
+            if (k < Ktot && n < C) {
+                const int tp = k / K, ko = k - tp * K;
+                v = w[((long)(ntaps - 1 - tp) * C + n) * ldw + ko];
+            }
+            tile[tx][ty + 8 * i] = v;                        // tile[k][n]
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + ty + 8 * i, k = k0 + tx;
         if (n < Nrows && k < Ktot) {
-            const float v = tile[tx][ty + 8 * i] * SPLIT3_WSCALE;
-            const _Float16 h = (_Float16)v;
+            const float v = tile[tx][ty + 8 * i] * TR::WSCALE;
+            const T h = (T)v;
             out[(long)n * Ktot + k] = h;
-            out[((long)Nrows + n) * Ktot + k] = (_Float16)(v - (float)h);
+            out[((long)Nrows + n) * Ktot + k] = (T)(v - (float)h);
         }
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NTHR>
+template <int BM, int BN, int WGM, int WGN, int NTHR, typename TR>
 __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p) {
+    typedef typename TR::V8 V8;
     constexpr int BK = 32;
     constexpr int ROWB = BK * 2;                  // bytes per LDS row (32 halves)
     constexpr int A_BYTES = BM * ROWB;            // one of hi / lo
@@ -182,7 +228,7 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
         for (int j = 0; j < NA; ++j) {
             const int row = arow0 + j * RPP;
             uint2 hi, lo;
-            split4(ra[j], hi, lo);
+            split4<TR>(ra[j], hi, lo);
             const int off = row * ROWB + (((kq >> 1) ^ ((row >> 2) & 3)) << 4) + ((kq & 1) << 3);
             *reinterpret_cast<uint2*>(st + off) = hi;
             *reinterpret_cast<uint2*>(st + A_BYTES + off) = lo;
@@ -199,29 +245,29 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
 
     auto compute = [&](int buf) {
         const char* st = lds + buf * STAGE;
-        h16x8 ah[TM], al[TM], bh[TN], bl[TN];
+        V8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = wm * WTM + i * 16 + li;
             const int off = row * ROWB + ((g ^ ((row >> 2) & 3)) << 4);
-            ah[i] = *reinterpret_cast<const h16x8*>(st + off);
-            al[i] = *reinterpret_cast<const h16x8*>(st + A_BYTES + off);
+            ah[i] = *reinterpret_cast<const V8*>(st + off);
+            al[i] = *reinterpret_cast<const V8*>(st + A_BYTES + off);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int row = wn * WTN + j * 16 + li;
             const int off = 2 * A_BYTES + row * ROWB + ((g ^ ((row >> 2) & 3)) << 4);
-            bh[j] = *reinterpret_cast<const h16x8*>(st + off);
-            bl[j] = *reinterpret_cast<const h16x8*>(st + B_BYTES + off);
+            bh[j] = *reinterpret_cast<const V8*>(st + off);
+            bl[j] = *reinterpret_cast<const V8*>(st + B_BYTES + off);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 // rows of D = output channels (weights in the A slot), columns = pixels; small terms first
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = TR::mfma(bl[j], ah[i], acc[i][j]);
+                acc[i][j] = TR::mfma(bh[j], al[i], acc[i][j]);
+                acc[i][j] = TR::mfma(bh[j], ah[i], acc[i][j]);
             }
     };
 
@@ -253,7 +299,8 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] *= SPLIT3_OUTSCALE;   // exact: undo the power-of-two operand scaling
+        for (int j = 0; j < TN; ++j)
+            if (TR::OUTSCALE != 1.f) acc[i][j] *= TR::OUTSCALE;   // exact: undo the power-of-two operand scaling
     igemm_epilogue<BM, BN, WGM, WGN, NTHR, TM, TN>(p, acc, smem, m0, n0, wm, wn, li, g, tid);
 }
 

@@ -84,15 +84,26 @@ size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d);
  * |w| < 63 and |x| < 2.6e5.  Needs C % 32 == 0.  `wsplit` (caller-owned,
  * acimg_conv2d_split3_weight_bytes(d) bytes) is filled by acimg_conv2d_split3_prepare from the HWIO fp32
  * kernel: [hi|lo][ldw][R*S*C] fp16.  Semantics otherwise as acimg_conv2d_fwd (deferred BN on load, raw
- * output + statistics partials of acimg_conv2d_fwd_split3_stats_rows(d) rows; no bias / split-K).
+ * output + statistics partials of acimg_conv2d_fwd_split3_stats_rows(d) rows; optional bias + d->act; no
+ * split-K).
  * Replaces: slim layers.conv2d / conv2d_same in the trunk, models/resnet50.py:109-121. */
 size_t acimg_conv2d_split3_weight_bytes(const AcimgConvDesc* d);
 int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream);
 int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d);
 int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out /* {BM, BN} */);
-int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* wsplit, float* y,
-                            const float* in_scale, const float* in_shift, int in_relu, float* stats,
+int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* wsplit, const float* bias,
+                            float* y, const float* in_scale, const float* in_shift, int in_relu, float* stats,
                             void* stream);
+/* Data gradient of a stride-1 conv on the same structure with a bf16 hi/lo split (gradients ~1e-7 are
+ * outside fp16's range; bf16 keeps fp32's range, 16 mantissa bits, no scaling): a forward conv of gy with
+ * the flipped + transposed kernel prepared by acimg_conv2d_split3_prepare_dgrad ([hi|lo][C][R*S*K] bf16,
+ * acimg_conv2d_split3_dgrad_weight_bytes(d) bytes).  Needs K % 32 == 0.  residual / mask / lddx as in
+ * acimg_conv2d_dgrad. */
+size_t acimg_conv2d_split3_dgrad_weight_bytes(const AcimgConvDesc* d);
+int acimg_conv2d_split3_prepare_dgrad(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream);
+int acimg_conv2d_dgrad_split3(const AcimgConvDesc* d, const float* gy, int ldgy, const void* wsplit_t, float* dx,
+                              int lddx, const float* residual, int ldres, const float* mask, int ldmask,
+                              void* stream);
 
 /* Pre-split activation format: a tensor [rows][C] is stored as TWO fp16 planes (hi at ptr, lo `lo_off`
  * bytes further), hi = f16(v/4), lo = f16(v/4 - hi): 22 mantissa bits in the same 4 bytes per element as

@@ -216,6 +216,43 @@ def test_conv2d_fwd_f16x3(device, case):
     close(y, tf_conv_ref(x, w, stride, pads), tol=2e-6, what="f16x3 conv plain %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(2, 36, 48, 128, 128, 3, 3, 1, "SAME"), (2, 36, 48, 256, 128, 3, 3, 1, "SAME"),
+                                  (3, 18, 20, 128, 64, 3, 3, 1, "SAME"), (2, 17, 9, 64, 64, 3, 3, 1, "SAME")])
+def test_split3_generator_convs(device, case):
+    """generator convs on the split-MFMA kernels: forward f16x3 with bias + ReLU into a concat slice, data
+    gradient bf16x3 (gradients are outside fp16's range) with fan-in residual + ReLU mask"""
+    from acimg import ops
+
+    N, H, W, Cc, K, R, S, stride, padding = case
+    g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)) + 3)
+    x = rnd(g, N, H, W, Cc).requires_grad_(True)
+    w = (rnd(g, R, S, Cc, K) * (2.0 / (R * S * Cc)) ** 0.5).requires_grad_(True)
+    b = rnd(g, K).requires_grad_(True)
+    OH, OW, pads = _conv_geom(H, W, R, S, stride, padding)
+    pre = tf_conv_ref(x, w, stride, pads, b)
+    d = ops.conv_desc(N, H, W, Cc, K, R, S, stride, padding, ldy=2 * K, act=ops.ACT_RELU)
+    plan = ops.Plan(device, eager=True)
+    wd = dev(w.detach(), device)
+    wsplit = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=device)
+    ops.conv2d_split3_prepare(plan, d, wd, wsplit)
+    ybuf = torch.zeros(N, OH, OW, 2 * K, device=device)
+    ops.conv2d_fwd_split3(plan, d, dev(x.detach(), device), wsplit, ops.Ptr(ybuf, K), bias=dev(b.detach(), device))
+    torch.cuda.synchronize()
+    close(ybuf[..., K:], torch.relu(pre), tol=2e-6, what="f16x3 fwd+bias+relu %s" % (case,))
+    assert (ybuf[..., :K] == 0).all()
+    # data gradient with tiny gradient magnitudes (as in the real backward pass)
+    gy = rnd(g, N, OH, OW, K) * 1e-7
+    pre.backward(gy)
+    res = rnd(g, N, H, W, Cc) * 1e-7
+    maskt = rnd(g, N, H, W, Cc)
+    wt = torch.zeros(ops.conv2d_split3_dgrad_weight_bytes(d), dtype=torch.uint8, device=device)
+    ops.conv2d_split3_prepare_dgrad(plan, d, wd, wt)
+    dx = torch.full((N, H, W, Cc), 3.0, device=device)
+    ops.conv2d_dgrad_split3(plan, d, dev(gy, device), K, wt, dx, dev(res, device), Cc, dev(maskt, device), Cc)
+    torch.cuda.synchronize()
+    close(dx, (x.grad + res) * (maskt > 0), tol=3e-5, what="bf16x3 dgrad %s" % (case,))
+
+
 def unsplit(planes, lo_off, rows, Cc):
     """two fp16 planes (uint8 buffer) -> float64 [rows, C] (undoing the 2^-2 scale)"""
     n = rows * Cc

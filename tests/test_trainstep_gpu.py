@@ -47,7 +47,9 @@ def build(device, num_skip, embedding, batch, lr=1e-3, precision="f16x3"):
                      randomize=True)
     sess = Session(device)
     mi = ResNet50Model(input_shape=[224, 298, 3], num_classes=None, precision=precision)
-    ma = UNetAc(input_shape=[36, 48, 12], embedding=embedding, num_skip=num_skip)
+    ma = UNetAc(input_shape=[36, 48, 12], embedding=embedding, num_skip=num_skip,
+                precision="split" if precision == "f16x3" else "f32")
+    ma.split_min_rows = 0   # exercise the split-MFMA generator convs even at the tiny test batch
     tr = Trainer(ma, mi, learning_rate=lr, session=sess)
     tr._build_functions(batch_size=batch)
     loaded = sess.store.load_state(orc.state_dict(), strict=True)
