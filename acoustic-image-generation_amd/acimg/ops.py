@@ -317,6 +317,13 @@ def conv2d_wgrad(plan, d, x, gy, ldgy, dw, db=None):
              _WsPtr(plan.ws), _WsBytes(plan.ws))
 
 
+def conv2d_wgrad_split3(plan, d, x, gy, ldgy, dw, db=None):
+    L = _L()
+    plan.ws.require(L.acimg_conv2d_wgrad_workspace(C.byref(d)))
+    plan.add("conv2d_wgrad_split3", L.acimg_conv2d_wgrad_split3, C.byref(d), x, gy, int(ldgy), dw, db,
+             _WsPtr(plan.ws), _WsBytes(plan.ws))
+
+
 def deconv_fwd(plan, d, x, w, bias, y):
     L = _L()
     plan.ws.require(L.acimg_deconv_workspace(C.byref(d)))

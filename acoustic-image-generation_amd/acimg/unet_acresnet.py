@@ -298,7 +298,8 @@ class UNetAc(object):
         def back(name, gy, dx=None, mask=None, res=None):
             """weight/bias gradient of conv `name`, and its data gradient into dx (if given)"""
             d, x, y = self._descs[name]
-            ops.conv2d_wgrad(plan, d, x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
+            wg = ops.conv2d_wgrad_split3 if (self.precision == "split" and d.K % 64 == 0) else ops.conv2d_wgrad
+            wg(plan, d, x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
             if dx is not None and self._use_split(d):
                 wt = self._wsplit(name, ops.conv2d_split3_dgrad_weight_bytes(d), "dgrad")
                 ops.conv2d_split3_prepare_dgrad(plan, d, self._P(name + "/kernel"), wt)

@@ -12,7 +12,7 @@
 // staged [k][n] (NN, ds_read_b32) or [n][k] (NT, ds_read_b128).  The k order inside a 16-deep step
 // is permuted identically for A and B (lane group g owns k = 4g..4g+3), which leaves the sum
 // unchanged.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t.
-#include "igemm_split3_kernel.hpp"
+#include "wgrad_split3_kernel.hpp"
 #include <cstdlib>
 
 namespace acimg {
@@ -398,20 +398,22 @@ static size_t wgrad_ws_bytes(int M, int KK, int Ngemm, int ldo) {
     int bmo, bn;
     wgrad_tile(Ngemm, bmo, bn);
     const int s = pick_wgrad_splits(M, KK, Ngemm, bmo, bn);
-    return s > 1 ? (size_t)s * ((size_t)KK + 1) * ldo * sizeof(float) : 0;
+    return s > 1 ? (size_t)(s + 1) * ((size_t)KK + 1) * ldo * sizeof(float) : 0;
 }
 
 // db (optional): fused bias gradient, db[n] = sum_m G[m][n] for n < Ngemm
-static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t st) {
+static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t st,
+                        bool split3 = false) {
     if ((p.C & 3) || (p.ldx & 3) || (p.ldg & 3) || (p.ldo & 3))
         return fail(ACIMG_EINVAL, "wgrad: C=%d ldx=%d ldg=%d ldo=%d must be multiples of 4", p.C, p.ldx, p.ldg, p.ldo);
     if (!aligned16(p.X) || !aligned16(p.G) || !aligned16(dw))
         return fail(ACIMG_EINVAL, "wgrad: operands must be 16-byte aligned");
     int bmo, bn;
     wgrad_tile(p.Ngemm, bmo, bn);
+    if (split3) bn = p.Ngemm > 64 ? 128 : 64;
     p.splits = pick_wgrad_splits(p.M, p.KK, p.Ngemm, bmo, bn);
     int rps = cdiv(p.M, p.splits);
-    rps = ((rps + 15) / 16) * 16;
+    rps = ((rps + 31) / 32) * 32;
     p.rows_per_split = rps;
     p.splits = cdiv(p.M, rps);
     float* db_slab = nullptr;
@@ -428,7 +430,9 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
     }
     const int rows = p.KK + (db ? 1 : 0);
     dim3 grid(cdiv(rows, bmo), cdiv(p.Ngemm, bn), p.splits);
-    if (bn == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, st, p);
+    if (split3 && bn == 128) hipLaunchKernelGGL((wgrad_split3_kernel<128>), grid, dim3(256), 65536, st, p);
+    else if (split3) hipLaunchKernelGGL((wgrad_split3_kernel<64>), grid, dim3(256), 65536, st, p);
+    else if (bn == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, st, p);
     else if (bn == 64) hipLaunchKernelGGL((wgrad_f32_kernel<128, 64>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((wgrad_f32_kernel<128, 32>), grid, dim3(256), 0, st, p);
     int rc = check_launch("wgrad");
@@ -845,6 +849,21 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
     else
         hipLaunchKernelGGL((igemm_split3p_kernel<128, 64, 2, 2, 256>), grid, dim3(256), 2 * (2 * 128 * 64 + 2 * 64 * 64), st, p);
     return check_launch("conv2d_fwd_split3p");
+}
+
+/* weight + bias gradient on the bf16x3 MFMA path (same contract as acimg_conv2d_wgrad) */
+int acimg_conv2d_wgrad_split3(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
+                              float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_desc(d, "conv2d_wgrad_split3");
+    if (rc) return rc;
+    const int kp = up4(d->K);
+    if (kp > ldgy || kp > d->ldw) return fail(ACIMG_EINVAL, "conv2d_wgrad_split3: padded K exceeds ldgy/ldw");
+    WgradParams p{};
+    p.X = x; p.H = d->H; p.W = d->W; p.C = d->C; p.ldx = d->ldx;
+    p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.M = d->N * d->OH * d->OW; p.KK = d->R * d->S * d->C;
+    p.G = gy; p.ldg = ldgy; p.Ngemm = kp; p.Nld = kp; p.ldo = d->ldw;
+    return launch_wgrad(p, dw, db, ws, ws_bytes, (hipStream_t)stream, true);
 }
 
 }  // extern "C"

@@ -145,6 +145,11 @@ size_t acimg_conv2d_dgrad_workspace(const AcimgConvDesc* d);
 int acimg_conv2d_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
                        float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
 size_t acimg_conv2d_wgrad_workspace(const AcimgConvDesc* d);
+/* the same on the bf16x3 MFMA path: x and gy are split into bf16 hi/lo on the fly (gradients need fp32's
+ * range), 3 MFMAs per product, fp32 accumulate; fragments come out of LDS through ds_read_b64_tr_b16
+ * because the reduction runs over pixels.  Same workspace as acimg_conv2d_wgrad. */
+int acimg_conv2d_wgrad_split3(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
+                              float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
 
 /* Transposed convolution with kernel <= stride, VALID (TF output = in*stride):
  *   x : [N,H,W,C] low-res input, y : [N,H*stride,W*stride,K], w : [R][S][K][ldw>=C].

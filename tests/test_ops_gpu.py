@@ -251,6 +251,39 @@ def test_split3_generator_convs(device, case):
     ops.conv2d_dgrad_split3(plan, d, dev(gy, device), K, wt, dx, dev(res, device), Cc, dev(maskt, device), Cc)
     torch.cuda.synchronize()
     close(dx, (x.grad + res) * (maskt > 0), tol=3e-5, what="bf16x3 dgrad %s" % (case,))
+    # weight + bias gradient (bf16x3, transposing LDS reads)
+    dw = torch.full((R, S, Cc, K), 9.0, device=device)
+    db = torch.zeros(K, device=device)
+    ops.conv2d_wgrad_split3(plan, d, dev(x.detach(), device), dev(gy, device), K, dw, db)
+    torch.cuda.synchronize()
+    close(dw, w.grad, tol=3e-5, what="bf16x3 wgrad %s" % (case,))
+    close(db, b.grad, tol=3e-5, what="bf16x3 bgrad %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [(2, 36, 48, 128, 128, 3, 3, 3, "SAME"), (3, 12, 16, 136, 128, 3, 3, 1, "SAME"),
+                                  (2, 36, 48, 12, 128, 3, 3, 1, "SAME"), (5, 9, 7, 64, 64, 3, 3, 1, "SAME")])
+def test_wgrad_split3_geometries(device, case):
+    """strided (pool_2), padded-channel, tiny-C and ragged-M weight gradients on the bf16x3 kernel; gy read
+    as a channel slice of a wider buffer"""
+    from acimg import ops
+
+    N, H, W, Cc, K, R, S, stride, padding = case
+    g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)) + 5)
+    x = rnd(g, N, H, W, Cc).requires_grad_(True)
+    w = (rnd(g, R, S, Cc, K) * 0.05).requires_grad_(True)
+    b = rnd(g, K).requires_grad_(True)
+    OH, OW, pads = _conv_geom(H, W, R, S, stride, padding)
+    y = tf_conv_ref(x, w, stride, pads, b)
+    gywide = rnd(g, N, OH, OW, 2 * K) * 1e-6
+    y.backward(gywide[..., K:])
+    d = ops.conv_desc(N, H, W, Cc, K, R, S, stride, padding)
+    plan = ops.Plan(device, eager=True)
+    dw = torch.full((R, S, Cc, K), 9.0, device=device)
+    db = torch.zeros(K, device=device)
+    ops.conv2d_wgrad_split3(plan, d, dev(x.detach(), device), ops.Ptr(dev(gywide, device), K), 2 * K, dw, db)
+    torch.cuda.synchronize()
+    close(dw, w.grad, tol=3e-5, what="bf16x3 wgrad %s" % (case,))
+    close(db, b.grad, tol=3e-5, what="bf16x3 bgrad %s" % (case,))
 
 
 def unsplit(planes, lo_off, rows, Cc):
