@@ -383,7 +383,7 @@ static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipSt
 
 static int pick_wgrad_splits(int M, int KK, int Ngemm, int bmo, int bn) {
     const long tiles = (long)cdiv(KK, bmo) * cdiv(Ngemm, bn);
-    long s = (768 + tiles - 1) / tiles;
+    long s = (512 + tiles - 1) / tiles;   // ~2 workgroups per CU; every split costs a KK x N slab round trip
     const long maxs = (M + 255) / 256;  // at least 256 pixels per split
     if (s > maxs) s = maxs;
     if (s > 128) s = 128;
@@ -840,7 +840,9 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
     Split3Cfg c = pick_split3(p.M, d->K);
     dim3 grid(cdiv(p.M, c.bm), cdiv(d->K, c.bn), 1);
     hipStream_t st = (hipStream_t)stream;
-    if (c.bm == 256 && c.bn == 128)
+    if (c.bm == 128 && c.bn == 128 && getenv("ACIMG_SPLIT3_W4"))   // experiment: 4 waves of 64x64
+        hipLaunchKernelGGL((igemm_split3p_kernel<128, 128, 2, 2, 256>), grid, dim3(256), 65536, st, p);
+    else if (c.bm == 256 && c.bn == 128)
         hipLaunchKernelGGL((igemm_split3p_kernel<256, 128, 4, 2, 512>), grid, dim3(512), 2 * (2 * 256 * 64 + 2 * 128 * 64), st, p);
     else if (c.bm == 128 && c.bn == 128)
         hipLaunchKernelGGL((igemm_split3p_kernel<128, 128, 2, 4, 512>), grid, dim3(512), 65536, st, p);

@@ -46,6 +46,14 @@ struct SplitBF16 {
     }
 };
 
+// LDS chunk swizzle: a tile row is 64 bytes = four 16-byte chunks; logical chunk kc of row `row` is stored at
+// chunk kc ^ swz(row).  ds_read_b128 is serviced in the hardware lane groups {0-3,12-15,20-27},
+// {4-11,16-19,28-31}, ... (not in natural 16-lane groups): each group sees all 16 fragment rows once, rows
+// 0-3/12-15 with one k-chunk g and rows 4-11 with g^1.  swz = (0,3,2,1)[(row>>2)&3] is the assignment that
+// makes the 16 lanes of every such group hit 16 distinct 16-byte slots of the 256-byte bank window
+// (the plain (row>>2)&3 pattern measured 35 % of LDS cycles as bank conflicts).
+__device__ __forceinline__ int swz(int row) { return (0 - (row >> 2)) & 3; }
+
 template <typename TR>
 __device__ __forceinline__ void split4(float4 v, uint2& hi, uint2& lo) {
     typedef typename TR::T T;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
         const int row = rem >> 2, kc = rem & 3;
         const int n = n0 + row;
         b_goff[j] = n < p.Nld ? (unsigned)((((long)which * p.Nld + n) * Ktot + kc * 8) * 2) : OOB;
-        b_lds[j] = 2 * A_BYTES + which * B_BYTES + row * ROWB + ((kc ^ ((row >> 2) & 3)) << 4);
+        b_lds[j] = 2 * A_BYTES + which * B_BYTES + row * ROWB + ((kc ^ swz(row)) << 4);
     }
 
     int nit = 0, st_r = 0, st_s = 0, st_c0 = 0;
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
             const int row = arow0 + j * RPP;
             uint2 hi, lo;
             split4<TR>(ra[j], hi, lo);
-            const int off = row * ROWB + (((kq >> 1) ^ ((row >> 2) & 3)) << 4) + ((kq & 1) << 3);
+            const int off = row * ROWB + (((kq >> 1) ^ swz(row)) << 4) + ((kq & 1) << 3);
             *reinterpret_cast<uint2*>(st + off) = hi;
             *reinterpret_cast<uint2*>(st + A_BYTES + off) = lo;
         }
@@ -249,14 +257,14 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = wm * WTM + i * 16 + li;
-            const int off = row * ROWB + ((g ^ ((row >> 2) & 3)) << 4);
+            const int off = row * ROWB + ((g ^ swz(row)) << 4);
             ah[i] = *reinterpret_cast<const V8*>(st + off);
             al[i] = *reinterpret_cast<const V8*>(st + A_BYTES + off);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int row = wn * WTN + j * 16 + li;
-            const int off = 2 * A_BYTES + row * ROWB + ((g ^ ((row >> 2) & 3)) << 4);
+            const int off = 2 * A_BYTES + row * ROWB + ((g ^ swz(row)) << 4);
             bh[j] = *reinterpret_cast<const V8*>(st + off);
             bl[j] = *reinterpret_cast<const V8*>(st + B_BYTES + off);
         }
@@ -353,7 +361,7 @@ __global__ __launch_bounds__(NTHR) void igemm_split3p_kernel(const IgemmParams p
             const int rem = c - which * (BM * 4);
             const int row = rem >> 2, kc = rem & 3;
             const int m = m0 + row;
-            a_lds[j] = which * A_BYTES + row * ROWB + ((kc ^ ((row >> 2) & 3)) << 4);
+            a_lds[j] = which * A_BYTES + row * ROWB + ((kc ^ swz(row)) << 4);
             if (m < p.M) {
                 const int img = m / ohw;
                 const int r2 = m - img * ohw;
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(NTHR) void igemm_split3p_kernel(const IgemmParams p
         const int row = rem >> 2, kc = rem & 3;
         const int n = n0 + row;
         b_goff[j] = n < p.Nld ? (unsigned)((((long)which * p.Nld + n) * Ktot + kc * 8) * 2) : OOB;
-        b_lds[j] = 2 * A_BYTES + which * B_BYTES + row * ROWB + ((kc ^ ((row >> 2) & 3)) << 4);
+        b_lds[j] = 2 * A_BYTES + which * B_BYTES + row * ROWB + ((kc ^ swz(row)) << 4);
     }
 
     int nit = 0, st_r = 0, st_s = 0, st_c0 = 0;
@@ -429,14 +437,14 @@ __global__ __launch_bounds__(NTHR) void igemm_split3p_kernel(const IgemmParams p
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = wm * WTM + i * 16 + li;
-            const int off = row * ROWB + ((g ^ ((row >> 2) & 3)) << 4);
+            const int off = row * ROWB + ((g ^ swz(row)) << 4);
             ah[i] = *reinterpret_cast<const h16x8*>(st + off);
             al[i] = *reinterpret_cast<const h16x8*>(st + A_BYTES + off);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int row = wn * WTN + j * 16 + li;
-            const int off = 2 * A_BYTES + row * ROWB + ((g ^ ((row >> 2) & 3)) << 4);
+            const int off = 2 * A_BYTES + row * ROWB + ((g ^ swz(row)) << 4);
             bh[j] = *reinterpret_cast<const h16x8*>(st + off);
             bl[j] = *reinterpret_cast<const h16x8*>(st + B_BYTES + off);
         }
@@ -457,19 +465,26 @@ __global__ __launch_bounds__(NTHR) void igemm_split3p_kernel(const IgemmParams p
         if (nit < it_end) load_tiles(ra1, rb1);
     }
     __syncthreads();
+    // Each K step first parks tile it+1 in the OTHER LDS buffer (last read one step ago, everyone is past that
+    // barrier) and re-arms the freed register set with tile it+3, THEN runs the MFMA block of tile it: the
+    // global loads and LDS writes of a step overlap its own matrix work instead of trailing it.
     for (int it = 0; it < it_end; it += 2) {
-        compute(0);
         if (it + 1 < it_end) {
             store_tiles(1, ra0, rb0);
             if (nit < it_end) load_tiles(ra0, rb0);
         }
+        __builtin_amdgcn_s_setprio(1);
+        compute(0);
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         if (it + 1 >= it_end) break;
-        compute(1);
         if (it + 2 < it_end) {
             store_tiles(0, ra1, rb1);
             if (nit < it_end) load_tiles(ra1, rb1);
         }
+        __builtin_amdgcn_s_setprio(1);
+        compute(1);
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
     }
 #pragma unroll
