@@ -13,7 +13,9 @@
 // is permuted identically for A and B (lane group g owns k = 4g..4g+3), which leaves the sum
 // unchanged.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t.
 #include "wgrad_split3_kernel.hpp"
+#include "igemm_split3d_kernel.hpp"
 #include <cstdlib>
+#include <algorithm>
 
 namespace acimg {
 
@@ -675,18 +677,18 @@ int acimg_deconv_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, 
 // f16x3 (split fp16) forward convolution (frozen ResNet trunk)
 // ------------------------------------------------------------------------------------------
 struct Split3Cfg { int bm, bn; };
-// Tile choice, measured per trunk conv shape at batch 32 (tools/tune_split3.py): the 8-wave 128x128 tile
-// (2 workgroups/CU) beats or ties 64x128 on every shape but the 1x1 convs of the 14x19 stage (M = 8512,
-// 67 row tiles), 128x64 always loses, 256x128 drops to 2 waves/SIMD and loses 17 %.
+// Tile choice, measured per trunk conv shape at batch 32 (tools/tune_dma.py): the 8-wave 128x128 tile
+// (2 workgroups/CU) wins on every shape with at least ~1 tile per CU; below that (the stride-2 3x3 conv into
+// the 14x19 stage: 134 tiles) 64x128 fills more CUs; Cout = 64 uses 128x64.
 static Split3Cfg pick_split3(int M, int K) {
     if (K <= 64) return {128, 64};
     if (const char* ov = getenv("ACIMG_SPLIT3_TILE")) {   // experiments only: "BMxBN"
         int bm = 0, bn = 0;
         if (sscanf(ov, "%dx%d", &bm, &bn) == 2 && ((bm == 128 && bn == 128) || (bm == 64 && bn == 128) ||
-                                                   (bm == 128 && bn == 64) || (bm == 256 && bn == 128)))
+                                                   (bm == 128 && bn == 64)))
             return {bm, bn};
     }
-    if ((long)cdiv(M, 128) * cdiv(K, 128) < 300) return {64, 128};
+    if ((long)cdiv(M, 128) * cdiv(K, 128) < 200) return {64, 128};
     return {128, 128};
 }
 
@@ -838,18 +840,20 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
     e.Y = y; e.ldy = d->ldy; e.M = p.M; e.Nstore = d->K; e.act = d->act;
     e.stats = stats; e.stats_ld = d->ldw; e.vec = 1;
     Split3Cfg c = pick_split3(p.M, d->K);
-    dim3 grid(cdiv(p.M, c.bm), cdiv(d->K, c.bn), 1);
     hipStream_t st = (hipStream_t)stream;
-    if (c.bm == 128 && c.bn == 128 && getenv("ACIMG_SPLIT3_W4"))   // experiment: 4 waves of 64x64
-        hipLaunchKernelGGL((igemm_split3p_kernel<128, 128, 2, 2, 256>), grid, dim3(256), 65536, st, p);
-    else if (c.bm == 256 && c.bn == 128)
-        hipLaunchKernelGGL((igemm_split3p_kernel<256, 128, 4, 2, 512>), grid, dim3(512), 2 * (2 * 256 * 64 + 2 * 128 * 64), st, p);
-    else if (c.bm == 128 && c.bn == 128)
-        hipLaunchKernelGGL((igemm_split3p_kernel<128, 128, 2, 4, 512>), grid, dim3(512), 65536, st, p);
+    // XCD-aware rasterisation: the ~64 tiles resident on one XCD form a (64/gn) x gn rectangle of the tile grid
+    p.ras_tiles_m = cdiv(p.M, c.bm);
+    p.ras_tiles_n = cdiv(d->K, c.bn);
+    p.ras_gn = std::min(p.ras_tiles_n, 8);
+    p.ras_gm = std::max(1, 64 / p.ras_gn);
+    const dim3 grid(p.ras_tiles_m * p.ras_tiles_n);
+    const size_t lds_bytes = (size_t)2 * 2 * (c.bm + c.bn) * 64;   // 2 stages x (hi, lo) x 64-byte rows
+    if (c.bm == 128 && c.bn == 128)
+        hipLaunchKernelGGL((igemm_split3d_kernel<128, 128, 2, 4, 512, 2, 2>), grid, dim3(512), lds_bytes, st, p);
     else if (c.bm == 64 && c.bn == 128)
-        hipLaunchKernelGGL((igemm_split3p_kernel<64, 128, 1, 4, 256>), grid, dim3(256), 2 * (2 * 64 * 64 + 2 * 128 * 64), st, p);
+        hipLaunchKernelGGL((igemm_split3d_kernel<64, 128, 1, 4, 256, 2, 2>), grid, dim3(256), lds_bytes, st, p);
     else
-        hipLaunchKernelGGL((igemm_split3p_kernel<128, 64, 2, 2, 256>), grid, dim3(256), 2 * (2 * 128 * 64 + 2 * 64 * 64), st, p);
+        hipLaunchKernelGGL((igemm_split3d_kernel<128, 64, 2, 2, 256, 2, 2>), grid, dim3(256), lds_bytes, st, p);
     return check_launch("conv2d_fwd_split3p");
 }
 

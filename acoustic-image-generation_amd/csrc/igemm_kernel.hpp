@@ -88,8 +88,10 @@ __device__ __forceinline__ void epi_store4(const EpiParams& e, long opix, int cn
 // ---- shared epilogue: lane holds channels n4..n4+3 of pixel m for each (tm, tn) -------------------
 template <int BM, int BN, int WGM, int WGN, int NTHR, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[TM][TN], float* smem, int m0,
-                                               int n0, int wm, int wn, int li, int g, int tid) {
+                                               int n0, int wm, int wn, int li, int g, int tid,
+                                               int stat_row = -1) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    if (stat_row < 0) stat_row = blockIdx.x;
     if (p.splits > 1) {
         float* slab = p.slab + (long)blockIdx.z * p.M * p.slab_ld;
 #pragma unroll
@@ -161,7 +163,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                 float s = 0.f;
 #pragma unroll
                 for (int w = 0; w < WGM; ++w) s += red[(w * 2 + which) * BN + col];
-                e.stats[((long)blockIdx.x * 2 + which) * e.stats_ld + n] = s;
+                e.stats[((long)stat_row * 2 + which) * e.stats_ld + n] = s;
             }
         }
     }

@@ -312,186 +312,4 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
     igemm_epilogue<BM, BN, WGM, WGN, NTHR, TM, TN>(p, acc, smem, m0, n0, wm, wn, li, g, tid);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Variant with PRE-SPLIT activations: A is stored in HBM as two fp16 planes [pixel][lda] (hi at p.A, lo
-// p.a_lo_off bytes further; values already carry the 2^-2 scale and any BN affine + ReLU, written by the
-// elementwise producers in elementwise.hip).  Both operands are then plain 16-byte chunk copies into
-// LDS: no VALU work in the K loop besides the im2col bounds check.
-// ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int NTHR>
-__global__ __launch_bounds__(NTHR) void igemm_split3p_kernel(const IgemmParams p) {
-    constexpr int BK = 32;
-    constexpr int ROWB = BK * 2;
-    constexpr int A_BYTES = BM * ROWB;
-    constexpr int B_BYTES = BN * ROWB;
-    constexpr int STAGE = 2 * A_BYTES + 2 * B_BYTES;
-    constexpr int WTM = BM / WGM, WTN = BN / WGN;
-    constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int ACH = 2 * BM * 4;
-    constexpr int NAC = ACH / NTHR;
-    constexpr int BCH = 2 * BN * 4;
-    constexpr int NB = BCH / NTHR;
-    static_assert(WGM * WGN * 64 == NTHR && ACH % NTHR == 0 && BCH % NTHR == 0, "tile / thread mapping");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* const lds = reinterpret_cast<char*>(smem);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    const int wm = wid / WGN, wn = wid % WGN;
-    const int li = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-
-    const __amdgpu_buffer_rsrc_t rsA =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
-
-    const int it_end = p.kiters;
-    const int Ktot = p.ntaps * p.C;
-
-    // ---- A chunks of this thread: chunk c -> (hi/lo plane, row, 16-byte k chunk) --------------------------
-    int a_off[NAC], a_ih0[NAC], a_iw0[NAC], a_lds[NAC];
-    {
-        const int ohw = p.OH * p.OW;
-#pragma unroll
-        for (int j = 0; j < NAC; ++j) {
-            const int c = tid + j * NTHR;
-            const int which = c / (BM * 4);
-            const int rem = c - which * (BM * 4);
-            const int row = rem >> 2, kc = rem & 3;
-            const int m = m0 + row;
-            a_lds[j] = which * A_BYTES + row * ROWB + ((kc ^ swz(row)) << 4);
-            if (m < p.M) {
-                const int img = m / ohw;
-                const int r2 = m - img * ohw;
-                const int oh = r2 / p.OW;
-                const int ow = r2 - oh * p.OW;
-                a_ih0[j] = oh * p.stride - p.pad_t;
-                a_iw0[j] = ow * p.stride - p.pad_l;
-                a_off[j] = ((img * p.H + a_ih0[j]) * p.W + a_iw0[j]) * p.lda * 2 + which * (int)p.a_lo_off + kc * 16;
-            } else {
-                a_ih0[j] = -(1 << 28);
-                a_iw0[j] = -(1 << 28);
-                a_off[j] = 0;
-            }
-        }
-    }
-    unsigned b_goff[NB];
-    int b_lds[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int c = tid + j * NTHR;
-        const int which = c / (BN * 4);
-        const int rem = c - which * (BN * 4);
-        const int row = rem >> 2, kc = rem & 3;
-        const int n = n0 + row;
-        b_goff[j] = n < p.Nld ? (unsigned)((((long)which * p.Nld + n) * Ktot + kc * 8) * 2) : OOB;
-        b_lds[j] = 2 * A_BYTES + which * B_BYTES + row * ROWB + ((kc ^ swz(row)) << 4);
-    }
-
-    int nit = 0, st_r = 0, st_s = 0, st_c0 = 0;
-    uint4 ra0[NAC], ra1[NAC], rb0[NB], rb1[NB];
-
-    auto load_tiles = [&](uint4 (&ra)[NAC], uint4 (&rb)[NB]) {
-        const int tapoff = ((st_r * p.W + st_s) * p.lda + st_c0) * 2;
-#pragma unroll
-        for (int j = 0; j < NAC; ++j) {
-            const int ih = a_ih0[j] + st_r, iw = a_iw0[j] + st_s;
-            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            ra[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                  rsA, ok ? (unsigned)(a_off[j] + tapoff) : OOB, 0, 0));
-        }
-        const unsigned kbyte = (unsigned)(((st_r * p.S + st_s) * p.C + st_c0) * 2);
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            rb[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                  rsB, b_goff[j] == OOB ? OOB : b_goff[j] + kbyte, 0, 0));
-        ++nit;
-        st_c0 += BK;
-        if (st_c0 == p.C) {
-            st_c0 = 0;
-            if (++st_s == p.S) {
-                st_s = 0;
-                ++st_r;
-            }
-        }
-    };
-    auto store_tiles = [&](int buf, const uint4 (&ra)[NAC], const uint4 (&rb)[NB]) {
-        char* st = lds + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < NAC; ++j) *reinterpret_cast<uint4*>(st + a_lds[j]) = ra[j];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) *reinterpret_cast<uint4*>(st + b_lds[j]) = rb[j];
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto compute = [&](int buf) {
-        const char* st = lds + buf * STAGE;
-        h16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = wm * WTM + i * 16 + li;
-            const int off = row * ROWB + ((g ^ swz(row)) << 4);
-            ah[i] = *reinterpret_cast<const h16x8*>(st + off);
-            al[i] = *reinterpret_cast<const h16x8*>(st + A_BYTES + off);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int row = wn * WTN + j * 16 + li;
-            const int off = 2 * A_BYTES + row * ROWB + ((g ^ swz(row)) << 4);
-            bh[j] = *reinterpret_cast<const h16x8*>(st + off);
-            bl[j] = *reinterpret_cast<const h16x8*>(st + B_BYTES + off);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-            }
-    };
-
-    if (it_end > 0) {
-        load_tiles(ra0, rb0);
-        store_tiles(0, ra0, rb0);
-        if (nit < it_end) load_tiles(ra0, rb0);
-        if (nit < it_end) load_tiles(ra1, rb1);
-    }
-    __syncthreads();
-    // Each K step first parks tile it+1 in the OTHER LDS buffer (last read one step ago, everyone is past that
-    // barrier) and re-arms the freed register set with tile it+3, THEN runs the MFMA block of tile it: the
-    // global loads and LDS writes of a step overlap its own matrix work instead of trailing it.
-    for (int it = 0; it < it_end; it += 2) {
-        if (it + 1 < it_end) {
-            store_tiles(1, ra0, rb0);
-            if (nit < it_end) load_tiles(ra0, rb0);
-        }
-        __builtin_amdgcn_s_setprio(1);
-        compute(0);
-        __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
-        if (it + 1 >= it_end) break;
-        if (it + 2 < it_end) {
-            store_tiles(0, ra1, rb1);
-            if (nit < it_end) load_tiles(ra1, rb1);
-        }
-        __builtin_amdgcn_s_setprio(1);
-        compute(1);
-        __builtin_amdgcn_s_setprio(0);
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] *= SPLIT3_OUTSCALE;
-    igemm_epilogue<BM, BN, WGM, WGN, NTHR, TM, TN>(p, acc, smem, m0, n0, wm, wn, li, g, tid);
-}
-
 }  // namespace acimg

@@ -1,0 +1,253 @@
+// f16x3 forward convolution on PRE-SPLIT activations with LDS-DMA operand staging (gfx950): the trunk kernel.
+//
+// A is stored in HBM as two fp16 planes [pixel][lda] (hi at p.A, lo p.a_lo_off bytes further; values already
+// carry the 2^-2 scale and any BN affine + ReLU, written by the elementwise producers in elementwise.hip), B is
+// the split + transposed weight image of `split3_prepare_kernel`.  Same GEMM core, LDS image (64-byte rows,
+// chunk ^ swz(row)) and epilogue as `igemm_split3_kernel`, but neither operand tile passes through VGPRs:
+// every wave copies 1-KiB pieces (16 tile rows of one fp16 plane) global -> LDS with
+// `buffer_load_dwordx4 ... lds`.  That removes the ds_write_b128 pass (13 store-path cycles per
+// wave-instruction), the staging registers and the s_waitcnt/VALU work between them (72 VGPRs in all).
+//
+//   * LDS destination of a DMA is wave-uniform base + 16*lane, so the XOR swizzle is applied on the SOURCE
+//     side: lane l of a piece fills physical chunk (l&3) of tile row (l>>2) and therefore fetches logical k
+//     chunk (l&3)^swz(row).
+//   * im2col: per-lane buffer offsets; padding taps / M tail / N tail use an out-of-range offset, for which
+//     the DMA writes zeros.
+//   * rings of NSA A stages and NSB B stages (NSA = NSB or NSB + 1), ONE barrier per K step:
+//         s_waitcnt vmcnt(INFLIGHT)          own pieces of tile `it` have landed
+//         s_barrier                          everyone's have, and everyone is done reading tile it-1
+//         request B(it+NSB-1), A(it+NSA-1)   into the slots tile it-1 just left
+//         12 ds_read_b128, then 24 MFMAs back to back (term-major: no MFMA waits on its predecessor)
+//   * measured (profiles/r01, tools/tune_dma.py): 2+2 stages at 2 workgroups/CU is the best point; a third A
+//     stage (80 KiB, still 2/CU), 3+3 stages at 1/CU and a 256x128 tile are all equal or slower - the K step is
+//     not bound by DMA latency.  In-round MFMA utilisation is ~53 %; the rest of the loss is tile quantisation.
+//   * workgroup -> tile mapping is XCD-aware (raster_tile below).
+#pragma once
+#include "igemm_split3_kernel.hpp"
+
+namespace acimg {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else static_assert(N == 0, "add the immediate");
+}
+
+// linear workgroup id -> (row tile, column tile), see IgemmParams::ras_*
+__device__ __forceinline__ void raster_tile(const IgemmParams& p, int L, int& mt, int& nt) {
+    const int T = p.ras_tiles_m * p.ras_tiles_n;
+    const int xcd = L & 7, slot = L >> 3;
+    const int base = T >> 3, extra = T & 7;
+    const int ord = xcd * base + min(xcd, extra) + slot;
+    const int band = p.ras_gm * p.ras_tiles_n;
+    const int mband = ord / band;
+    const int rem = ord - mband * band;
+    const int gm = min(p.ras_gm, p.ras_tiles_m - mband * p.ras_gm);
+    const int grp = gm * p.ras_gn;
+    const int ngroup = rem / grp;
+    const int r2 = rem - ngroup * grp;
+    const int gn = min(p.ras_gn, p.ras_tiles_n - ngroup * p.ras_gn);
+    const int mi = r2 / gn;
+    mt = mband * p.ras_gm + mi;
+    nt = ngroup * p.ras_gn + (r2 - mi * gn);
+}
+
+template <int BM, int BN, int WGM, int WGN, int NTHR, int NSA, int NSB>
+__global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p) {
+    constexpr int BK = 32;
+    constexpr int ROWB = BK * 2;
+    constexpr int A_BYTES = BM * ROWB;            // one plane of one stage
+    constexpr int B_BYTES = BN * ROWB;
+    constexpr int B_BASE = NSA * 2 * A_BYTES;     // LDS: NSA x [A hi | A lo], then NSB x [B hi | B lo]
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int NW = NTHR / 64;
+    constexpr int RA = BM / 16 / NW;              // 16-row blocks of A per wave (each: hi piece + lo piece)
+    constexpr int RB = BN / 16 / NW;
+    // pieces that may stay in flight at the top of a step (see the loop): whole younger tiles, plus the A
+    // pieces of the extra A stage (A pieces are requested after the B pieces of the same step)
+    constexpr int INFLIGHT = (NSB - 2) * 2 * (RA + RB) + (NSA - NSB) * 2 * RA;
+    static_assert(WGM * WGN == NW && (BM / 16) % NW == 0 && (BN / 16) % NW == 0, "tile / wave mapping");
+    static_assert(NSB >= 2 && (NSA == NSB || NSA == NSB + 1), "stage counts");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int li = lane & 15, g = lane >> 4;
+    int mt, nt;
+    raster_tile(p, blockIdx.x, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
+
+    const int it_end = p.kiters;
+    const int Ktot = p.ntaps * p.C;
+
+    // ---- this lane's slot in a piece: tile row (lane>>2) of the 16-row block, physical chunk (lane&3) -------
+    const int prow = lane >> 2, pch = lane & 3;
+    int a_off[RA], a_ih0[RA], a_iw0[RA];
+    {
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int row = (wid + j * NW) * 16 + prow;
+            const int kc = pch ^ swz(row);
+            const int m = m0 + row;
+            if (m < p.M) {
+                const int img = m / ohw;
+                const int r2 = m - img * ohw;
+                const int oh = r2 / p.OW;
+                const int ow = r2 - oh * p.OW;
+                a_ih0[j] = oh * p.stride - p.pad_t;
+                a_iw0[j] = ow * p.stride - p.pad_l;
+                a_off[j] = ((img * p.H + a_ih0[j]) * p.W + a_iw0[j]) * p.lda * 2 + kc * 16;
+            } else {
+                a_ih0[j] = -(1 << 28);
+                a_iw0[j] = -(1 << 28);
+                a_off[j] = 0;
+            }
+        }
+    }
+    unsigned b_goff[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int row = (wid + j * NW) * 16 + prow;
+        const int kc = pch ^ swz(row);
+        const int n = n0 + row;
+        b_goff[j] = n < p.Nld ? (unsigned)(((long)n * Ktot + kc * 8) * 2) : OOB;
+    }
+    const unsigned b_lo_off = (unsigned)((long)p.Nld * Ktot * 2);
+
+    // request cursors: A walks (tap row, tap column, channel chunk); B's k offset is linear in the step
+    int qa = 0, sa = 0, st_r = 0, st_s = 0, st_c0 = 0;     // next A tile to request, its LDS slot
+    int qb = 0, sb = 0;
+
+    auto issue_a = [&]() {
+        char* st = lds + sa * (2 * A_BYTES);
+        const int tapoff = ((st_r * p.W + st_s) * p.lda + st_c0) * 2;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int ih = a_ih0[j] + st_r, iw = a_iw0[j] + st_s;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const unsigned off = ok ? (unsigned)(a_off[j] + tapoff) : OOB;
+            char* dst = st + (wid + j * NW) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + A_BYTES), 16, off, (int)p.a_lo_off, 0, 0);
+        }
+        ++qa;
+        sa = sa + 1 == NSA ? 0 : sa + 1;
+        st_c0 += BK;
+        if (st_c0 == p.C) {
+            st_c0 = 0;
+            if (++st_s == p.S) {
+                st_s = 0;
+                ++st_r;
+            }
+        }
+    };
+    auto issue_b = [&]() {
+        char* st = lds + B_BASE + sb * (2 * B_BYTES);
+        const unsigned kbyte = (unsigned)(qb * (BK * 2));
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const unsigned off = b_goff[j] == OOB ? OOB : b_goff[j] + kbyte;
+            char* dst = st + (wid + j * NW) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)dst, 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + B_BYTES), 16, off, (int)b_lo_off, 0, 0);
+        }
+        ++qb;
+        sb = sb + 1 == NSB ? 0 : sb + 1;
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int ca, int cb) {
+        const char* sta = lds + ca * (2 * A_BYTES);
+        const char* stb = lds + B_BASE + cb * (2 * B_BYTES);
+        h16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * WTM + i * 16 + li;
+            const int off = row * ROWB + ((g ^ swz(row)) << 4);
+            ah[i] = *reinterpret_cast<const h16x8*>(sta + off);
+            al[i] = *reinterpret_cast<const h16x8*>(sta + A_BYTES + off);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wn * WTN + j * 16 + li;
+            const int off = row * ROWB + ((g ^ swz(row)) << 4);
+            bh[j] = *reinterpret_cast<const h16x8*>(stb + off);
+            bl[j] = *reinterpret_cast<const h16x8*>(stb + B_BYTES + off);
+        }
+        // all 12 fragment reads are in flight before the first MFMA (one exposed LDS latency per step instead
+        // of one per fragment pair), and the three terms of a product are issued a whole sweep apart so that no
+        // MFMA waits on its predecessor's accumulator (the per-accumulator order lo*hi, hi*lo, hi*hi is kept)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+    };
+
+    // prologue = the requests the steps -(NSA-1) .. -1 would have made, in the same order (B before A)
+#pragma unroll
+    for (int v = -(NSA - 1); v < 0; ++v) {
+        if (v + NSB - 1 >= 0 && qb < it_end) issue_b();
+        if (qa < it_end) issue_a();
+    }
+
+    int ca = 0, cb = 0;                 // LDS slots of the tile being multiplied
+    for (int it = 0; it < it_end; ++it) {
+        // oldest-first the queue holds ... B(it) A(it+NSA-NSB) | B(it+1) A(..) ...: everything up to B(it) must
+        // have landed, INFLIGHT younger pieces may stay in flight; near the tail fewer exist -> drain
+        if (it + NSA - 1 <= it_end) wait_vmcnt<INFLIGHT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();   // everyone's pieces of tile `it` landed; everyone left tile it-1
+        if (qb < it_end) issue_b();     // -> slot of B(it-1)
+        if (qa < it_end) issue_a();     // -> slot of A(it-1)
+        __builtin_amdgcn_s_setprio(1);
+        compute(ca, cb);
+        __builtin_amdgcn_s_setprio(0);
+        ca = ca + 1 == NSA ? 0 : ca + 1;
+        cb = cb + 1 == NSB ? 0 : cb + 1;
+    }
+    __syncthreads();                    // the epilogue reuses the LDS
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] *= SPLIT3_OUTSCALE;
+    igemm_epilogue<BM, BN, WGM, WGN, NTHR, TM, TN>(p, acc, smem, m0, n0, wm, wn, li, g, tid, mt);
+}
+
+}  // namespace acimg

@@ -13,7 +13,7 @@ weights.  N > 1: one process per GPU, weak scaling (32 images per GPU), bucketed
 the 43 MB gradient overlapped with backward.
 
 One JSON line on rank 0.  `roofline` is for the dominant kernel (the 128x128-tile implicit-GEMM
-forward conv that runs the ResNet trunk: split-fp16 "f16x3" MFMA by default, exact-f32 MFMA with
+forward conv that runs the ResNet trunk (LDS-DMA staged, XCD-aware tile order): split-fp16 "f16x3" MFMA by default, exact-f32 MFMA with
 --precision f32): ALGORITHMIC FLOPs (2*M*N*K per conv) of its launches divided by their
 HIP-event-measured duration inside the timed region, against the dense MFMA peak of the dtype the
 matrix cores run in.  The f16x3 kernel issues 3 MFMA FLOPs per algorithmic FLOP (`hw_flop_factor`).  `cpu_baseline` times the CPU oracle
@@ -134,8 +134,8 @@ def main():
     tile = max(cand, key=lambda k: sum(f for _, f in cand[k]))
     probe_idx = set(i for i, _ in cand[tile])
     flops = dict(cand[tile])
-    TILE_THREADS = {(128, 128): "2,4,512", (64, 128): "1,4,256", (128, 64): "2,2,256", (256, 128): "4,2,512"}
-    kernel_name = ("igemm_split3p_kernel<%d,%d,%s>" % (tile[0], tile[1], TILE_THREADS[tile[:2]]) if f16
+    TILE_THREADS = {(128, 128): "2,4,512", (64, 128): "1,4,256", (128, 64): "2,2,256"}
+    kernel_name = ("igemm_split3d_kernel<%d,%d,%s,2,2>" % (tile[0], tile[1], TILE_THREADS[tile[:2]]) if f16
                    else "igemm_f32_kernel<%d,%d,...,false,true>" % (tile[0], tile[1]))
     for _ in range(args.warmup):
         tr.train_step(sync=False)
