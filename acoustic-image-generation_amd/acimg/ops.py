@@ -210,13 +210,14 @@ def conv_desc(N, H, W, C, K, R, S, stride=1, padding="SAME", ldx=None, ldy=None,
 
 
 def deconv_desc(N, H, W, C, K, R, S, stride, ldx=None, ldy=None, ldw=None):
-    """Descriptor for tf.layers.conv2d_transpose VALID with kernel <= stride: out = in*stride."""
+    """Descriptor for tf.layers.conv2d_transpose VALID: out = in*stride + max(kernel - stride, 0)."""
     d = ConvDesc()
     d.N, d.H, d.W, d.C = N, H, W, C
     d.ldx = C if ldx is None else ldx
     d.K = K
     d.ldy = K if ldy is None else ldy
-    d.OH, d.OW, d.R, d.S, d.stride, d.pad_t, d.pad_l = H * stride, W * stride, R, S, stride, 0, 0
+    d.OH, d.OW = H * stride + max(R - stride, 0), W * stride + max(S - stride, 0)
+    d.R, d.S, d.stride, d.pad_t, d.pad_l = R, S, stride, 0, 0
     d.ldw = C if ldw is None else ldw
     d.act = ACT_NONE
     return d

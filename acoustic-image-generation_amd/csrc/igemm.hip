@@ -270,6 +270,26 @@ __global__ __launch_bounds__(256) void deconv_gap_fill_kernel(float* y, int ldy,
     *reinterpret_cast<float4*>(y + pix * ldy + c) = b;
 }
 
+// zero insertion: out[n, h*s, w*s, :] = in[n, h, w, :], zeros elsewhere; out is [N][(H-1)s+1][(W-1)s+1][C].
+// Turns the data gradient of a stride-s conv (and the forward of a transposed conv whose kernel exceeds
+// its stride) into a stride-1 correlation over a 4x larger, mostly-zero tensor: used only for the small
+// stride-2 layers of the RGB / spectrogram U-Nets.
+__global__ __launch_bounds__(256) void dilate2d_kernel(const float* in, int ldin, float* out, long opixels,
+                                                       int H, int W, int OH, int OW, int C, int s) {
+    const int c4 = C / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= opixels * c4) return;
+    const long pix = idx / c4;
+    const int c = (int)(idx - pix * c4) * 4;
+    const int ow = (int)(pix % OW);
+    const int oh = (int)((pix / OW) % OH);
+    const long n = pix / ((long)OW * OH);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (oh % s == 0 && ow % s == 0)
+        v = *reinterpret_cast<const float4*>(in + ((n * H + oh / s) * W + ow / s) * ldin + c);
+    *reinterpret_cast<float4*>(out + pix * C + c) = v;
+}
+
 // ------------------------------------------------------------------------------------------
 // host side: configuration choice and launch
 // ------------------------------------------------------------------------------------------
@@ -535,10 +555,21 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
     return launch_igemm(p, false, ws, ws_bytes, (hipStream_t)stream);
 }
 
+static bool dgrad_is_patch(const AcimgConvDesc* d) {
+    return d->stride > 1 && d->stride == d->R && d->stride == d->S && !d->pad_t && !d->pad_l &&
+           d->OH * d->stride == d->H && d->OW * d->stride == d->W;
+}
+static size_t dilated_bytes(int N, int H, int W, int C, int s) {
+    return ((size_t)N * ((H - 1) * s + 1) * ((W - 1) * s + 1) * C * 4 + 255) & ~(size_t)255;
+}
+
 size_t acimg_conv2d_dgrad_workspace(const AcimgConvDesc* d) {
-    const bool patch = d->stride > 1;
-    if (patch) return igemm_ws_bytes(d->N * d->OH * d->OW, d->R * d->S * d->C, cdiv(up4(d->K), 32));
+    if (dgrad_is_patch(d)) return igemm_ws_bytes(d->N * d->OH * d->OW, d->R * d->S * d->C, cdiv(up4(d->K), 32));
     const int ca = up4(d->K);
+    if (d->stride > 1)   // zero-inserted copy of gy, then the stride-1 path
+        return dilated_bytes(d->N, d->OH, d->OW, ca, d->stride) +
+               igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * d->S * cdiv(ca, 32)) +
+               igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * cdiv(d->S * ca, 32));
     // rowrun depends on ldgy, unknown here: per-tap kiters is the larger bound for splits
     return igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * d->S * cdiv(ca, 32)) +
            igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * cdiv(d->S * ca, 32));
@@ -558,6 +589,23 @@ int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
     if (lddx < d->C) return fail(ACIMG_EINVAL, "conv2d_dgrad: lddx < C");
     p.e.Y = dx; p.e.ldy = lddx; p.e.res = residual; p.e.ldres = ldres; p.e.mask = mask; p.e.ldmask = ldmask;
     p.e.act = ACIMG_ACT_NONE;
+    if (d->stride > 1 && !dgrad_is_patch(d)) {
+        // general stride: the strided conv is a subsampled stride-1 conv, so its data gradient is the stride-1
+        // data gradient of the zero-inserted gy
+        const size_t db = dilated_bytes(d->N, d->OH, d->OW, ca, d->stride);
+        if (ws_bytes < db || !ws) return fail(ACIMG_EWORKSPACE, "conv2d_dgrad: workspace too small for the dilated gradient");
+        const int OH1 = (d->OH - 1) * d->stride + 1, OW1 = (d->OW - 1) * d->stride + 1;
+        const long opix = (long)d->N * OH1 * OW1;
+        if (opix * ca >= (1L << 31)) return fail(ACIMG_EINVAL, "conv2d_dgrad: dilated gradient exceeds 2^31 elements");
+        hipLaunchKernelGGL(dilate2d_kernel, dim3(cdiv(opix * (ca / 4), 256)), dim3(256), 0, (hipStream_t)stream, gy, ldgy,
+                           static_cast<float*>(ws), opix, d->OH, d->OW, OH1, OW1, ca, d->stride);
+        rc = check_launch("dilate2d");
+        if (rc) return rc;
+        AcimgConvDesc d1 = *d;
+        d1.stride = 1; d1.OH = OH1; d1.OW = OW1;
+        return acimg_conv2d_dgrad(&d1, static_cast<const float*>(ws), ca, w, dx, lddx, residual, ldres, mask, ldmask,
+                                  static_cast<char*>(ws) + db, ws_bytes - db, stream);
+    }
     if (d->stride == 1) {
         // dx[h,w,c] = sum_{r',s',k} gy[h-(R-1-pt)+r', w-(S-1-pl)+s', k] * W[R-1-r'][S-1-s'][c][k]
         p.H = d->OH; p.W = d->OW; p.OH = d->H; p.OW = d->W;
@@ -569,9 +617,6 @@ int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
         p.Ngemm = d->C;
         p.e.M = p.M; p.e.Nstore = d->C;
     } else {
-        if (d->stride != d->R || d->stride != d->S || d->pad_t || d->pad_l || d->OH * d->stride != d->H ||
-            d->OW * d->stride != d->W)
-            return fail(ACIMG_EINVAL, "conv2d_dgrad: stride>1 needs kernel==stride, no padding, exact tiling");
         // patch scatter: rows = output pixels, columns = (tap, c)
         p.H = d->OH; p.W = d->OW; p.OH = d->OH; p.OW = d->OW;
         p.R = 1; p.S = 1; p.stride = 1; p.pad_t = 0; p.pad_l = 0;
@@ -608,16 +653,47 @@ size_t acimg_deconv_workspace(const AcimgConvDesc* d) {
     size_t b = igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * d->S * cdiv(up4(d->K), 32));
     size_t c = wgrad_ws_bytes(d->N * d->H * d->W, d->R * d->S * up4(d->K), d->C, d->ldw) + colsum_ws_bytes(up4(d->K));
     size_t m = a > b ? a : b;
-    return m > c ? m : c;
+    m = m > c ? m : c;
+    if (d->R > d->stride || d->S > d->stride)   // forward goes through a zero-inserted copy of x
+        m += dilated_bytes(d->N, d->H, d->W, d->C, d->stride) +
+             igemm_ws_bytes(d->N * d->OH * d->OW, d->K, d->R * d->S * cdiv(d->C, 32)) +
+             igemm_ws_bytes(d->N * d->OH * d->OW, d->K, d->R * cdiv(d->S * d->C, 32));
+    return m;
 }
 
 int acimg_deconv_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
                      float* y, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_desc(d, "deconv_fwd");
     if (rc) return rc;
-    if (d->R > d->stride || d->S > d->stride || d->OH != d->H * d->stride || d->OW != d->W * d->stride)
-        return fail(ACIMG_EINVAL, "deconv_fwd: needs kernel<=stride and OH=H*stride");
     if (d->ldw < d->C || (d->K & 3)) return fail(ACIMG_EINVAL, "deconv_fwd: ldw<C or K%%4");
+    if (d->R > d->stride || d->S > d->stride) {
+        // overlapping patches (tf conv2d_transpose VALID: OH = (H-1)*stride + R): y = stride-1 "full" correlation
+        // of the zero-inserted x with the flipped kernel = the data gradient of the stride-1 VALID conv
+        // [OH,OW,K] -> [(H-1)s+1, (W-1)s+1, C] whose HWIO kernel is this layer's [R][S][K][C]
+        if (d->OH != (d->H - 1) * d->stride + d->R || d->OW != (d->W - 1) * d->stride + d->S)
+            return fail(ACIMG_EINVAL, "deconv_fwd: kernel>stride needs OH=(H-1)*stride+R");
+        const size_t db = dilated_bytes(d->N, d->H, d->W, d->C, d->stride);
+        if (ws_bytes < db || !ws) return fail(ACIMG_EWORKSPACE, "deconv_fwd: workspace too small for the dilated input");
+        const int H1 = (d->H - 1) * d->stride + 1, W1 = (d->W - 1) * d->stride + 1;
+        const long opix = (long)d->N * H1 * W1;
+        hipLaunchKernelGGL(dilate2d_kernel, dim3(cdiv(opix * (d->C / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, d->ldx,
+                           static_cast<float*>(ws), opix, d->H, d->W, H1, W1, d->C, d->stride);
+        rc = check_launch("dilate2d");
+        if (rc) return rc;
+        IgemmParams p{};
+        p.A = static_cast<const float*>(ws); p.C = d->C; p.lda = d->C;
+        p.B = w; p.ldb = d->ldw;
+        p.H = H1; p.W = W1; p.OH = d->OH; p.OW = d->OW;
+        p.R = d->R; p.S = d->S; p.stride = 1; p.pad_t = d->R - 1; p.pad_l = d->S - 1;
+        p.M = d->N * d->OH * d->OW;
+        p.rowrun = d->S > 1 ? 1 : 0;
+        p.tap_stride = (long)d->K * d->ldw; p.flip = 1;
+        p.Ngemm = d->K;
+        p.e.Y = y; p.e.ldy = d->ldy; p.e.M = p.M; p.e.Nstore = d->K; p.e.bias = bias; p.e.act = d->act;
+        return launch_igemm(p, true, static_cast<char*>(ws) + db, ws_bytes - db, (hipStream_t)stream);
+    }
+    if (d->OH != d->H * d->stride || d->OW != d->W * d->stride)
+        return fail(ACIMG_EINVAL, "deconv_fwd: kernel<=stride needs OH=H*stride");
     IgemmParams p{};
     p.A = x; p.H = d->H; p.W = d->W; p.C = d->C; p.lda = d->ldx; p.OH = d->H; p.OW = d->W;
     p.R = 1; p.S = 1; p.stride = 1; p.M = d->N * d->H * d->W; p.rowrun = 0;

@@ -268,15 +268,22 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
             bh[j] = *reinterpret_cast<const V8*>(st + off);
             bl[j] = *reinterpret_cast<const V8*>(st + B_BYTES + off);
         }
+        // rows of D = output channels (weights in the A slot), columns = pixels; small terms first.  All fragment
+        // reads are issued before the first MFMA and the three terms of a product are a whole sweep apart, so no
+        // MFMA waits on its predecessor's accumulator (per-accumulator order unchanged).
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                // rows of D = output channels (weights in the A slot), columns = pixels; small terms first
-                acc[i][j] = TR::mfma(bl[j], ah[i], acc[i][j]);
-                acc[i][j] = TR::mfma(bh[j], al[i], acc[i][j]);
-                acc[i][j] = TR::mfma(bh[j], ah[i], acc[i][j]);
-            }
+            for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(bl[j], ah[i], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(bh[j], al[i], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(bh[j], ah[i], acc[i][j]);
     };
 
     if (it_end > 0) {

@@ -384,6 +384,11 @@ DGRAD_CASES = [
     (3, 1, 1, 152, 2304, 1, 1, 1, "VALID"),
     (2, 36, 48, 16, 32, 3, 3, 3, "SAME"),
     (2, 18, 24, 256, 128, 3, 3, 1, "SAME"),
+    # general stride (the strided-conv "pool" layers of the RGB / spectrogram U-Nets)
+    (2, 17, 23, 8, 8, 3, 3, 2, "SAME"),
+    (2, 12, 15, 32, 32, 2, 3, 2, "VALID"),
+    (2, 15, 18, 8, 16, 3, 2, 2, "VALID"),
+    (1, 16, 20, 64, 64, 3, 3, 2, "SAME"),
 ]
 
 
@@ -449,35 +454,40 @@ def test_dgrad_slice_input(device):
     close(dw, w.grad, what="wgrad slice")
 
 
-@pytest.mark.parametrize("case", [(2, 12, 16, 128, 128, 2, 3), (3, 5, 4, 32, 64, 2, 2), (2, 6, 7, 64, 32, 3, 3)])
+@pytest.mark.parametrize("case", [(2, 12, 16, 128, 128, 2, 2, 3), (3, 5, 4, 32, 64, 2, 2, 2), (2, 6, 7, 64, 32, 3, 3, 3),
+                                  # kernel > stride (overlapping patches): unet_architecture.py upsample_6/8 [2,3],
+                                  # unet_sound.py upsample_8 [3,2] and upsample_9 [3,3]
+                                  (2, 7, 9, 64, 32, 2, 3, 2), (2, 6, 8, 32, 8, 3, 3, 2), (2, 5, 6, 8, 8, 3, 2, 2)])
 def test_deconv(device, case):
     from acimg import ops
 
-    N, H, W, Cc, K, R, s = case
+    N, H, W, Cc, K, R, S, s = case
     g = torch.Generator().manual_seed(77)
     x = rnd(g, N, H, W, Cc).requires_grad_(True)
-    w = (rnd(g, R, R, K, Cc) * 0.1).requires_grad_(True)  # TF layout [kh, kw, out, in]
+    w = (rnd(g, R, S, K, Cc) * 0.1).requires_grad_(True)  # TF layout [kh, kw, out, in]
     b = rnd(g, K).requires_grad_(True)
     y = F.conv_transpose2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, stride=s,
-                           output_padding=s - R).permute(0, 2, 3, 1)
-    assert y.shape[1] == H * s and y.shape[2] == W * s
+                           output_padding=(max(s - R, 0), max(s - S, 0))).permute(0, 2, 3, 1)
+    OH, OW = H * s + max(R - s, 0), W * s + max(S - s, 0)
+    assert y.shape[1] == OH and y.shape[2] == OW
     gy = rnd(g, *y.shape)
     y.backward(gy)
-    d = ops.deconv_desc(N, H, W, Cc, K, R, R, s, ldy=2 * K)
-    ybuf = torch.zeros(N, H * s, W * s, 2 * K, device=device)
+    d = ops.deconv_desc(N, H, W, Cc, K, R, S, s, ldy=2 * K)
+    assert (d.OH, d.OW) == (OH, OW)
+    ybuf = torch.zeros(N, OH, OW, 2 * K, device=device)
     plan = ops.Plan(device, eager=True)
     wd = dev(w.detach(), device)
     ops.deconv_fwd(plan, d, dev(x.detach(), device), wd, dev(b.detach(), device), ybuf)
     torch.cuda.synchronize()
     close(ybuf[..., :K], y, what="deconv fwd")
     assert (ybuf[..., K:] == 0).all()
-    gywide = torch.zeros(N, H * s, W * s, 2 * K, dtype=torch.float64)
+    gywide = torch.zeros(N, OH, OW, 2 * K, dtype=torch.float64)
     gywide[..., :K] = gy
     gyd = dev(gywide, device)
     maskt = rnd(g, N, H, W, Cc)
     dx = torch.empty(N, H, W, Cc, device=device)
     ops.deconv_dgrad(plan, d, gyd, 2 * K, wd, dx, dev(maskt, device), Cc)
-    dw = torch.empty(R, R, K, Cc, device=device)
+    dw = torch.empty(R, S, K, Cc, device=device)
     db = torch.empty(K, device=device)
     ops.deconv_wgrad(plan, d, dev(x.detach(), device), gyd, 2 * K, dw, db)
     torch.cuda.synchronize()
