@@ -71,6 +71,10 @@ PROTOTYPES = {
     "acimg_minmax_bwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "acimg_latent_fwd": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "acimg_latent_bwd": (_I, [_P, _P, _P, _P, _I, _F, _P, _I, _I, _P]),
+    "acimg_latent_linear_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _P]),
+    "acimg_latent_linear_bwd": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _P]),
+    "acimg_bn_bwd_workspace": (_SZ, [_L, _I]),
+    "acimg_bn_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _I, _P, _I, _P, _P, _P, _SZ, _P]),
     "acimg_recon_loss": (_I, [_P, _P, _P, _P, _L, _F, _F, _P]),
     "acimg_grad_slice": (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _I, _P]),
     "acimg_loss_finalize": (_I, [_P, _P, _I, _D, _F, _F, _F, _F, _P, _P]),

@@ -398,6 +398,22 @@ def latent_bwd(plan, heads, eps, sigma, gz, ldgz, kl_weight, g_heads, N, Z):
              g_heads, N, Z)
 
 
+def latent_linear_fwd(plan, heads, eps, z, ldz, kl, N, Z):
+    plan.add("latent_linear_fwd", _L().acimg_latent_linear_fwd, heads, eps, z, int(ldz), kl, N, Z)
+
+
+def latent_linear_bwd(plan, heads, eps, gz, ldgz, kl_weight, g_heads, N, Z):
+    plan.add("latent_linear_bwd", _L().acimg_latent_linear_bwd, heads, eps, gz, int(ldgz), float(kl_weight), g_heads,
+             N, Z)
+
+
+def bn_bwd(plan, x, ldx, gy, ldgy, scale, shift, save_mean, save_invstd, gamma, rows, Cn, gx, ldgx, dgamma, dbeta):
+    L = _L()
+    plan.ws.require(L.acimg_bn_bwd_workspace(int(rows), int(Cn)))
+    plan.add("bn_bwd", L.acimg_bn_bwd, x, int(ldx), gy, int(ldgy), scale, shift, save_mean, save_invstd, gamma,
+             int(rows), int(Cn), gx, int(ldgx), dgamma, dbeta, _WsPtr(plan.ws), _WsBytes(plan.ws))
+
+
 def recon_loss(plan, yhat, target, g_logit, sums, count, w_mse=1.0, w_huber=1.0):
     plan.add("recon_loss", _L().acimg_recon_loss, yhat, target, g_logit, sums, int(count),
              float(w_mse), float(w_huber))

@@ -62,34 +62,39 @@ class FusedHeads(object):
     [12*16*148, 300] (columns 0..149 = mean, 150..299 = std) so both heads are a single pass over
     the 145-channel feature map.  In auto-encoder mode (:64) only `mean` exists: [.., 152]."""
 
-    def __init__(self, scope, cin, z, with_std):
+    def __init__(self, scope, cin, z, with_std, hw=(12, 16), names=("mean", "std")):
+        """hw: the VALID kernel size = the whole feature map; names: TF layer names of the two heads
+        (('mean', 'variance') with a 14x18 / 6x16 map in models/unet_architecture.py:62-65, unet_sound.py:65-68)"""
         self.scope = scope
+        self.hh, self.hw = hw
+        self.n0, self.n1 = names
         self.cin, self.cp, self.z, self.with_std = cin, up4(cin), z, with_std
         self.ncols = 2 * z if with_std else up4(z)
-        self.kernel = Var(scope + "/heads/kernel", (12 * 16 * self.cp, self.ncols), "dense", "train")
+        self.kernel = Var(scope + "/heads/kernel", (self.hh * self.hw * self.cp, self.ncols), "dense", "train")
         self.bias = Var(scope + "/heads/bias", (self.ncols,), "vec", "train")
-        self.tf_names = [scope + "/mean/kernel", scope + "/mean/bias"]
+        self.tf_names = ["%s/%s/kernel" % (scope, self.n0), "%s/%s/bias" % (scope, self.n0)]
         if with_std:
-            self.tf_names += [scope + "/std/kernel", scope + "/std/bias"]
+            self.tf_names += ["%s/%s/kernel" % (scope, self.n1), "%s/%s/bias" % (scope, self.n1)]
 
     def pack(self, tf):
-        k = torch.zeros(12, 16, self.cp, self.ncols)
+        f32 = lambda n: torch.as_tensor(np.asarray(tf[n]), dtype=torch.float32)  # noqa: E731
+        k = torch.zeros(self.hh, self.hw, self.cp, self.ncols)
         b = torch.zeros(self.ncols)
-        k[:, :, :self.cin, :self.z] = torch.as_tensor(np.asarray(tf[self.scope + "/mean/kernel"]), dtype=torch.float32)
-        b[:self.z] = torch.as_tensor(np.asarray(tf[self.scope + "/mean/bias"]), dtype=torch.float32)
+        k[:, :, :self.cin, :self.z] = f32("%s/%s/kernel" % (self.scope, self.n0))
+        b[:self.z] = f32("%s/%s/bias" % (self.scope, self.n0))
         if self.with_std:
-            k[:, :, :self.cin, self.z:2 * self.z] = torch.as_tensor(np.asarray(tf[self.scope + "/std/kernel"]), dtype=torch.float32)
-            b[self.z:2 * self.z] = torch.as_tensor(np.asarray(tf[self.scope + "/std/bias"]), dtype=torch.float32)
-        return k.reshape(12 * 16 * self.cp, self.ncols), b
+            k[:, :, :self.cin, self.z:2 * self.z] = f32("%s/%s/kernel" % (self.scope, self.n1))
+            b[self.z:2 * self.z] = f32("%s/%s/bias" % (self.scope, self.n1))
+        return k.reshape(self.hh * self.hw * self.cp, self.ncols), b
 
     def unpack(self, k, b):
-        k = k.reshape(12, 16, self.cp, self.ncols)
+        k = k.reshape(self.hh, self.hw, self.cp, self.ncols)
         out = OrderedDict()
-        out[self.scope + "/mean/kernel"] = k[:, :, :self.cin, :self.z].contiguous()
-        out[self.scope + "/mean/bias"] = b[:self.z].contiguous()
+        out["%s/%s/kernel" % (self.scope, self.n0)] = k[:, :, :self.cin, :self.z].contiguous()
+        out["%s/%s/bias" % (self.scope, self.n0)] = b[:self.z].contiguous()
         if self.with_std:
-            out[self.scope + "/std/kernel"] = k[:, :, :self.cin, self.z:2 * self.z].contiguous()
-            out[self.scope + "/std/bias"] = b[self.z:2 * self.z].contiguous()
+            out["%s/%s/kernel" % (self.scope, self.n1)] = k[:, :, :self.cin, self.z:2 * self.z].contiguous()
+            out["%s/%s/bias" % (self.scope, self.n1)] = b[self.z:2 * self.z].contiguous()
         return out
 
 

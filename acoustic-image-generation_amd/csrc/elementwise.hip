@@ -186,6 +186,103 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* x, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Training-mode batch-norm backward for the conv-BN-ReLU stacks of the RGB / spectrogram U-Nets
+// (models/unet_architecture.py:161-166): many row blocks per launch, float4 over channels.
+//   g   = gy * [raw*scale + shift > 0]                    (ReLU mask recomputed, y is not re-read)
+//   s1  = sum_rows g = dbeta,   s2 = sum_rows g * xhat = dgamma,   xhat = (raw - mean) * invstd
+//   gx  = gamma * invstd * (g - s1/n - xhat * s2/n)
+// pass 1 leaves per-block partials [blocks][2][C]; pass 2 (one block) adds them in block order
+// (deterministic) and writes dgamma/dbeta; pass 3 is elementwise.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* x, int ldx, const float* gy, int ldgy,
+                                                            const float* scale, const float* shift,
+                                                            const float* mean, const float* invstd, long rows,
+                                                            int C, long rows_per_block, float* partial) {
+    extern __shared__ float sm[];                 // [256][8]
+    const int c4n = C >> 2;
+    const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+    const int rstep = 256 / c4n;                  // rows covered per sweep (threads beyond rstep*c4n idle)
+    const int c = tc * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tr < rstep) {
+        const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+        const long r0 = (long)blockIdx.x * rows_per_block;
+        const long r1 = min(rows, r0 + rows_per_block);
+        for (long r = r0 + tr; r < r1; r += rstep) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+            const float4 gv = *reinterpret_cast<const float4*>(gy + r * ldgy + c);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+            const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
+            const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, iss[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float g = xs[k] * scs[k] + shs[k] > 0.f ? gs[k] : 0.f;
+                s1[k] += g;
+                s2[k] += g * (xs[k] - mus[k]) * iss[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sm[threadIdx.x * 8 + k] = s1[k];
+        sm[threadIdx.x * 8 + 4 + k] = s2[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < c4n) {                      // thread tc sums its column group over the row slots, in order
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < rstep; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] += sm[(j * c4n + threadIdx.x) * 8 + k];
+        float* dst = partial + (long)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dst[c + k] = a[k];
+            dst[C + c + k] = a[4 + k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int blocks, int C,
+                                                              float* dgamma, float* dbeta, float* sums) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < blocks; ++j) {
+            a += partial[(long)j * 2 * C + c];
+            b += partial[(long)j * 2 * C + C + c];
+        }
+        dbeta[c] = a;
+        dgamma[c] = b;
+        sums[c] = a;
+        sums[C + c] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* x, int ldx, const float* gy, int ldgy,
+                                                           const float* scale, const float* shift,
+                                                           const float* mean, const float* invstd,
+                                                           const float* gamma, const float* sums, long rows, int C,
+                                                           float* gx, int ldgx) {
+    const int c4n = C >> 2;
+    const float inv_n = 1.f / (float)rows;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < rows * c4n; idx += (long)gridDim.x * 256) {
+        const long r = idx / c4n;
+        const int c = (int)(idx - r * c4n) * 4;
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        const float4 gv = *reinterpret_cast<const float4*>(gy + r * ldgy + c);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g = xs[k] * scale[c + k] + shift[c + k] > 0.f ? gs[k] : 0.f;
+            const float xh = (xs[k] - mean[c + k]) * invstd[c + k];
+            o[k] = gamma[c + k] * invstd[c + k] * (g - sums[c + k] * inv_n - xh * sums[C + c + k] * inv_n);
+        }
+        *reinterpret_cast<float4*>(gx + r * ldgx + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void pad_channels_kernel(const float* x, float* y, long pixels,
                                                            int C, int Cp) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < pixels * Cp; idx += (long)gridDim.x * 256) {
@@ -326,6 +423,36 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* heads, con
     const float dsp = 1.f / (1.f + expf(-sraw));  // d softplus
     gheads[(long)n * 2 * Z + j] = dmu;
     gheads[(long)n * 2 * Z + Z + j] = dsg * dsp;
+}
+
+// the RGB / spectrogram U-Nets use the second head as sigma directly (models/unet_architecture.py:66-69):
+// z = mean + variance * eps, kl[n] = 0.5 * sum_j (mu^2 + s^2 - log(1e-8 + s^2) - 1)
+__global__ __launch_bounds__(256) void latent_linear_fwd_kernel(const float* heads, const float* eps, float* z,
+                                                                int ldz, float* kl, int Z) {
+    __shared__ float sm[32];
+    const int n = blockIdx.x;
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < Z; j += 256) {
+        const float mu = heads[(long)n * 2 * Z + j];
+        const float sg = heads[(long)n * 2 * Z + Z + j];
+        z[(long)n * ldz + j] = mu + sg * eps[(long)n * Z + j];
+        acc += mu * mu + sg * sg - logf(1e-8f + sg * sg) - 1.f;
+    }
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) kl[n] = 0.5f * acc;
+}
+
+__global__ __launch_bounds__(256) void latent_linear_bwd_kernel(const float* heads, const float* eps,
+                                                                const float* gz, int ldgz, float klw,
+                                                                float* gheads, int N, int Z) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * Z) return;
+    const int n = idx / Z, j = idx - n * Z;
+    const float mu = heads[(long)n * 2 * Z + j];
+    const float sg = heads[(long)n * 2 * Z + Z + j];
+    const float g = gz[(long)n * ldgz + j];
+    gheads[(long)n * 2 * Z + j] = g + klw * mu;
+    gheads[(long)n * 2 * Z + Z + j] = g * eps[idx] + klw * (sg - sg / (1e-8f + sg * sg));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -751,6 +878,48 @@ int acimg_latent_bwd(const float* heads, const float* eps, const float* sigma, c
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(cdiv((long)N * Z, 256)), dim3(256), 0, (hipStream_t)stream,
                        heads, eps, sigma, gz, ldgz, kl_weight, g_heads, N, Z);
     return check_launch("latent_bwd");
+}
+
+int acimg_latent_linear_fwd(const float* heads, const float* eps, float* z, int ldz, float* kl, int N, int Z,
+                            void* stream) {
+    hipLaunchKernelGGL(latent_linear_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, heads, eps, z, ldz, kl, Z);
+    return check_launch("latent_linear_fwd");
+}
+
+int acimg_latent_linear_bwd(const float* heads, const float* eps, const float* gz, int ldgz, float kl_weight,
+                            float* g_heads, int N, int Z, void* stream) {
+    hipLaunchKernelGGL(latent_linear_bwd_kernel, dim3(cdiv((long)N * Z, 256)), dim3(256), 0, (hipStream_t)stream,
+                       heads, eps, gz, ldgz, kl_weight, g_heads, N, Z);
+    return check_launch("latent_linear_bwd");
+}
+
+size_t acimg_bn_bwd_workspace(long rows, int C) {
+    long blocks = (rows + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return (size_t)(blocks + 1) * 2 * C * sizeof(float);
+}
+
+int acimg_bn_bwd(const float* x, int ldx, const float* gy, int ldgy, const float* scale, const float* shift,
+                 const float* save_mean, const float* save_invstd, const float* gamma, long rows, int C,
+                 float* gx, int ldgx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream) {
+    if ((C & 3) || C > 1024 || (ldx & 3) || (ldgy & 3) || (ldgx & 3) || !aligned16(x) || !aligned16(gy) ||
+        !aligned16(gx))
+        return fail(ACIMG_EINVAL, "bn_bwd: C=%d must be a multiple of 4 (<= 1024), buffers 16-byte aligned", C);
+    if (ws_bytes < acimg_bn_bwd_workspace(rows, C) || !ws) return fail(ACIMG_EWORKSPACE, "bn_bwd: workspace too small");
+    long blocks = (rows + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    const long rpb = (rows + blocks - 1) / blocks;
+    float* partial = static_cast<float*>(ws);
+    float* sums = partial + blocks * 2 * C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(256), 256 * 8 * sizeof(float), st, x, ldx, gy, ldgy,
+                       scale, shift, save_mean, save_invstd, rows, C, rpb, partial);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, st, x, ldx, gy, ldgy, scale, shift,
+                       save_mean, save_invstd, gamma, sums, rows, C, gx, ldgx);
+    return check_launch("bn_bwd");
 }
 
 int acimg_recon_loss(const float* yhat, const float* target, float* g_logit, float* sums,

@@ -369,8 +369,9 @@ static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipSt
     p.splits = pick_splits(p.M, p.Ngemm, c, p.kiters);
     float* stats_after = nullptr;  // split-K + BN statistics: a small pass over y afterwards
     if (e.stats && p.splits > 1) {
-        if (e.scatter || e.bias || e.res || e.mask || e.act != ACIMG_ACT_NONE)
-            return fail(ACIMG_EINVAL, "igemm: statistics with split-K need a plain raw output");
+        // (a bias is fine: the statistics pass reads y = acc + bias, which is what the batch norm normalises)
+        if (e.scatter || e.res || e.mask || e.act != ACIMG_ACT_NONE)
+            return fail(ACIMG_EINVAL, "igemm: statistics with split-K need a raw (conv + bias) output");
         stats_after = e.stats;
         e.stats = nullptr;
     }

@@ -130,17 +130,26 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 
     if (e.stats) {
         // per-channel sum / sum of squares of the raw accumulators over this block's rows (rows past
-        // M were zero-filled on load and add nothing): reduce over the 16 pixel lanes, then over waves
+        // M were zero-filled on load and add nothing): reduce over the 16 pixel lanes, then over waves.
+        // With a bias (tf.layers.conv2d + batch_normalization: the normalised tensor is conv + bias) the
+        // statistics are those of acc + bias over the valid rows.
         __syncthreads();
         float* red = smem;  // [WGM][2][BN]
+        const bool with_bias = e.bias != nullptr;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 float s1 = 0.f, s2 = 0.f;
+                float bv = 0.f;
+                if (with_bias) {
+                    const int n = n0 + wn * WTN + j * 16 + 4 * g + rg;
+                    bv = n < e.Nstore ? e.bias[n] : 0.f;
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const float v = acc[i][j][rg];
+                    float v = acc[i][j][rg];
+                    if (with_bias) v = (m0 + wm * WTM + i * 16 + li < e.M) ? v + bv : 0.f;
                     s1 += v;
                     s2 += v * v;
                 }

@@ -131,8 +131,10 @@ int acimg_bn_relu_maxpool_split(const float* x, const float* scale, const float*
  * stride ldres) is another gradient flowing into x (fan-out), `mask` (optional, pixel stride
  * ldmask) is the saved post-ReLU activation x itself: dx is zeroed where mask <= 0, so dx is
  * the pre-activation gradient of the producing layer.  dx has pixel stride lddx (0 = d->ldx: the
- * gradient of a concat-slice input usually lives in its own, narrower buffer).  Supported geometries: stride 1, and
- * stride == R == S with zero padding (non-overlapping patches, layer1/pool_2).
+ * gradient of a concat-slice input usually lives in its own, narrower buffer).  Geometries: stride 1 (direct),
+ * stride == R == S with zero padding (non-overlapping patches, layer1/pool_2: scatter form), and any other
+ * stride (the strided "pool" convs of models/unet_architecture.py:168-176, models/unet_sound.py:162-170) via a
+ * zero-inserted copy of gy in the workspace followed by the stride-1 form.
  * Replaces: the Conv2DBackpropInput ops tf.gradients emits for the calls above
  *           (trainer/mfcctrainer.py:72-79). */
 int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
@@ -151,8 +153,11 @@ size_t acimg_conv2d_wgrad_workspace(const AcimgConvDesc* d);
 int acimg_conv2d_wgrad_split3(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
                               float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
 
-/* Transposed convolution with kernel <= stride, VALID (TF output = in*stride):
- *   x : [N,H,W,C] low-res input, y : [N,H*stride,W*stride,K], w : [R][S][K][ldw>=C].
+/* Transposed convolution, VALID (TF output = in*stride + max(kernel - stride, 0)):
+ *   x : [N,H,W,C] low-res input, y : [N,OH,OW,K], w : [R][S][K][ldw>=C].
+ *   kernel <= stride in both directions (unet_acresnet.py:210-217): scatter form, gaps receive the bias;
+ *   kernel >= stride with overlap (unet_architecture.py:72,78 kernel [2,3]; unet_sound.py:82,85 kernels [3,2],
+ *   [3,3]): zero-inserted copy of x in the workspace, then a stride-1 full correlation with the flipped kernel.
  * Every input pixel writes a disjoint RxS patch; the remaining positions get the bias only.
  * Replaces: tf.layers.conv2d_transpose  models/unet_acresnet.py:210-217 (call :86). */
 int acimg_deconv_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
@@ -177,6 +182,17 @@ int acimg_bn_finalize(const float* stats, int rows, int C, int ldstats, double c
                       const float* gamma, const float* beta, float* moving_mean,
                       float* moving_var, float decay, float eps, int training, float* scale,
                       float* shift, float* save_mean, float* save_invstd, void* stream);
+
+/* Training-mode batch-norm + ReLU backward for the conv-BN-ReLU stacks of the RGB / spectrogram U-Nets
+ * (tf.layers.batch_normalization(training=True) + relu, models/unet_architecture.py:161-166,
+ * models/unet_sound.py:155-160).  x = the pre-BN conv output (bias included), gy = gradient w.r.t. the ReLU
+ * output; the ReLU mask is recomputed as x*scale+shift > 0 (scale/shift/save_* from acimg_bn_finalize):
+ *   dbeta = sum g, dgamma = sum g*xhat, gx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n).
+ * gx may alias gy.  C % 4 == 0, C <= 1024.  Deterministic (ordered partial sums). */
+size_t acimg_bn_bwd_workspace(long rows, int C);
+int acimg_bn_bwd(const float* x, int ldx, const float* gy, int ldgy, const float* scale, const float* shift,
+                 const float* save_mean, const float* save_invstd, const float* gamma, long rows, int C,
+                 float* gx, int ldgx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
 
 /* out = relu(a*sa[c]+ta[c] + shortcut), shortcut = b*sb[c]+tb[c] (sb given) or b (identity),
  * b read with spatial subsampling `bstride` (resnet_utils.subsample, models/resnet50.py:107).
@@ -229,6 +245,15 @@ int acimg_latent_fwd(const float* heads, const float* eps, float* z, int ldz, fl
 /* g_heads from gz (row stride ldgz) and the KL term weighted by kl_weight (= latent_loss / N) */
 int acimg_latent_bwd(const float* heads, const float* eps, const float* sigma, const float* gz,
                      int ldgz, float kl_weight, float* g_heads, int N, int Z, void* stream);
+
+/* Same without the softplus: the second head IS sigma (models/unet_architecture.py:62-69,
+ * models/unet_sound.py:65-72: guessed_z = mean + variance * samples).  heads = [N][2Z] = [mean | sigma];
+ * kl[n] = 0.5 * sum_j (mu^2 + s^2 - log(1e-8 + s^2) - 1)  (trainer/trainer.py:61-62 takes the mean over j:
+ * fold 1/Z into the weights). */
+int acimg_latent_linear_fwd(const float* heads, const float* eps, float* z, int ldz, float* kl, int N, int Z,
+                            void* stream);
+int acimg_latent_linear_bwd(const float* heads, const float* eps, const float* gz, int ldgz, float kl_weight,
+                            float* g_heads, int N, int Z, void* stream);
 
 /* Reconstruction loss on yhat = sigmoid output and its gradient w.r.t. the PRE-sigmoid logits:
  *   sums[0] += sum (yhat-y)^2, sums[1] += sum huber_1(yhat-y)   (caller zeroes sums)

@@ -47,8 +47,7 @@ def conv2d_transpose_valid(x, w, bias, stride):
     """tf.layers.conv2d_transpose, padding VALID.  w is [kh, kw, out, in]; TF output size is
     in*stride + max(k - stride, 0) (App. B.2), i.e. PyTorch's size plus output_padding = stride-k
     when k < stride."""
-    k = w.shape[0]
-    op = max(stride - k, 0)
+    op = (max(stride - w.shape[0], 0), max(stride - w.shape[1], 0))
     y = F.conv_transpose2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), bias, stride=stride,
                            output_padding=op)
     return y.permute(0, 2, 3, 1)

@@ -151,3 +151,53 @@ def test_oracle_step_shapes_and_learning(num_skip, embedding):
     assert r["mse"] < r0["mse"]
     e = o.eval_step(ac, mf, vid, eps)
     assert abs(np.mean([e["mse%d" % i] for i in range(4)]) - e["mse"]) < 1e-6
+
+
+# ---- RGB / spectrogram U-Net VAEs (BASELINE configs[0]/[1]) ---------------------------------
+def test_unet_vae_oracle_inventory_and_shapes():
+    from oracle import unet_vae as ouv
+
+    # parameter counts of models/unet_architecture.py and models/unet_sound.py
+    for model, want in (("UNet", 8.87e6), ("UNetSound", 3.68e6)):
+        n = sum(int(torch.tensor(s).prod()) for k, s in ouv.param_shapes(model).items() if ouv.trainable(k))
+        assert abs(n - want) / want < 2e-3, (model, n)
+    names = ouv.param_shapes("UNet")
+    # tf.layers names incl. the `pool_2` / `bn_pool_2` quirk (the loop index is reused, unet_architecture.py:171-178)
+    for k in ("UNet/layer1/conv_1/kernel", "UNet/layer1/bn_2/moving_variance", "UNet/layer4/pool_2/kernel",
+              "UNet/layer4/bn_pool_2/gamma", "UNet/mean/kernel", "UNet/variance/bias", "UNet/dense/kernel",
+              "UNet/conv2d/kernel", "UNet/upsample_6/kernel", "UNet/final/bias"):
+        assert k in names, k
+    assert names["UNet/upsample_6/kernel"] == (2, 3, 64, 128) and names["UNet/mean/kernel"] == (14, 18, 128, 128)
+    assert ouv.param_shapes("UNetSound")["UNetAudio/upsample_9/kernel"] == (3, 3, 8, 8)
+    for model in ("UNet", "UNetSound"):
+        p = ouv.init_params(model, dtype=torch.float64)
+        x, eps = ouv.synthetic_batch(model, 1, dtype=torch.float64)
+        fw, stats = ouv.forward(p, x, eps, model, True)
+        assert fw["output"].shape == x.shape and fw["mean"].shape == (1, 128)
+        ls = ouv.losses(p, x, fw, model)
+        # trainer/trainer.py:58-73: total = MSE + Huber + regularisers + KL/1e6
+        assert abs(float(ls["loss"]) - float(ls["mse"] + ls["huber"] + ls["reg"] + ls["latent"])) < 1e-12
+        # moving variance advances with the UNBIASED batch variance, momentum 0.99
+        k = [n for n in stats if n.endswith("layer1/bn_1/moving_variance")][0]
+        assert float((stats[k] - 1.0).abs().max()) < 0.011
+
+
+def test_unet_vae_host_graph_builds_on_cpu():
+    """the recorded plan (no launches) and the TF-named state dict of the HIP host model agree with the oracle"""
+    from acimg.session import Session
+    from acimg.trainer_vae import TrainerVAE
+    from acimg.unet_vae import UNet, UNetSound
+    from oracle import unet_vae as ouv
+
+    for cls, model in ((UNet, "UNet"), (UNetSound, "UNetSound")):
+        sess = Session(torch.device("cpu"))
+        tr = TrainerVAE(cls(), session=sess)
+        g = tr._build_functions(batch_size=2)
+        assert len(g.plan_train) > 100
+        tr.model.initialize(seed=1)
+        sd = sess.store.state_dict()
+        want = ouv.param_shapes(model)
+        assert set(sd) == set(want)
+        for k, shape in want.items():
+            assert tuple(sd[k].shape) == tuple(shape), k
+        assert sorted(tr.model.train_vars) == sorted(k for k in want if ouv.trainable(k))
