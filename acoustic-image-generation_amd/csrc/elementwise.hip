@@ -244,18 +244,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* x, int 
     }
 }
 
+// one workgroup per 32 channels x {dbeta, dgamma}: 8 row groups of 32 lanes walk the blocks, fixed-order tree
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int blocks, int C,
                                                               float* dgamma, float* dbeta, float* sums) {
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a = 0.f, b = 0.f;
-        for (int j = 0; j < blocks; ++j) {
-            a += partial[(long)j * 2 * C + c];
-            b += partial[(long)j * 2 * C + C + c];
-        }
-        dbeta[c] = a;
-        dgamma[c] = b;
-        sums[c] = a;
-        sums[C + c] = b;
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int which = blockIdx.y;                       // 0: sum g (dbeta), 1: sum g*xhat (dgamma)
+    const int c = blockIdx.x * 32 + cl;
+    float a = 0.f;
+    if (c < C)
+        for (int j = rg; j < blocks; j += 8) a += partial[(long)j * 2 * C + which * C + c];
+    red[rg][cl] = a;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][cl];
+        (which ? dgamma : dbeta)[c] = t;
+        sums[which * C + c] = t;
     }
 }
 
@@ -916,7 +922,7 @@ int acimg_bn_bwd(const float* x, int ldx, const float* gy, int ldgy, const float
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(256), 256 * 8 * sizeof(float), st, x, ldx, gy, ldgy,
                        scale, shift, save_mean, save_invstd, rows, C, rpb, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32), 2), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, st, x, ldx, gy, ldgy, scale, shift,
                        save_mean, save_invstd, gamma, sums, rows, C, gx, ldgx);
     return check_launch("bn_bwd");

@@ -192,6 +192,39 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int
     out[row * ld + col] = v;
 }
 
+// the same for many slabs (few-channel weight gradients use up to 2048 pixel splits): 32 outputs per workgroup,
+// 8 lane groups walk the slabs with four loads in flight each, fixed-order combine -> deterministic
+__global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float* slab, int splits, long rows,
+                                                               int ncols, int ld, float* out) {
+    __shared__ float red[8][32];
+    const int ol = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const long idx = (long)blockIdx.x * 32 + ol;
+    const bool ok = idx < rows * ncols;
+    const long row = ok ? idx / ncols : 0;
+    const int col = ok ? (int)(idx - row * ncols) : 0;
+    const float* src = slab + row * ld + col;
+    const long zs = rows * ld;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (ok) {
+        int z = rg;
+        for (; z + 24 < splits; z += 32) {
+            v0 += src[(long)z * zs];
+            v1 += src[(long)(z + 8) * zs];
+            v2 += src[(long)(z + 16) * zs];
+            v3 += src[(long)(z + 24) * zs];
+        }
+        for (; z < splits; z += 8) v0 += src[(long)z * zs];
+    }
+    red[rg][ol] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    if (rg == 0 && ok) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][ol];
+        out[row * ld + col] = t;
+    }
+}
+
 // column sums of G[rows][ld] (cols < ncols) -> out[ncols]; one block per 64 columns, 256 threads
 // = 4 row-groups x 64 columns.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* G, long rows, int ncols,
@@ -408,8 +441,13 @@ static int pick_wgrad_splits(int M, int KK, int Ngemm, int bmo, int bn) {
     const long tiles = (long)cdiv(KK, bmo) * cdiv(Ngemm, bn);
     long s = (512 + tiles - 1) / tiles;   // ~2 workgroups per CU; every split costs a KK x N slab round trip
     const long maxs = (M + 255) / 256;  // at least 256 pixels per split
+    long cap = 128;
+    if ((long)KK * Ngemm <= 8192) {       // few-channel layers (the RGB / spectrogram U-Nets: 72 x 8 ... 288 x 32
+        s = (2048 + tiles - 1) / tiles;   // weights, millions of pixels): slabs are a few KB, the pixel stream is
+        cap = 2048;                       // everything -> ~8 workgroups per CU
+    }
     if (s > maxs) s = maxs;
-    if (s > 128) s = 128;
+    if (s > cap) s = cap;
     if (s < 1) s = 1;
     return (int)s;
 }
@@ -462,11 +500,19 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
     if (rc) return rc;
     if (p.splits > 1) {
         const long total = (long)p.KK * p.Ngemm;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p.out,
-                           p.splits, (long)p.KK, p.Ngemm, p.ldo, dw);
-        if (db)
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(p.Ngemm, 256)), dim3(256), 0, st, db_slab, p.splits,
-                               1L, p.Ngemm, p.ldo, db);
+        if (p.splits > 32) {
+            hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, p.out,
+                               p.splits, (long)p.KK, p.Ngemm, p.ldo, dw);
+            if (db)
+                hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(cdiv(p.Ngemm, 32)), dim3(256), 0, st, db_slab,
+                                   p.splits, 1L, p.Ngemm, p.ldo, db);
+        } else {
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p.out,
+                               p.splits, (long)p.KK, p.Ngemm, p.ldo, dw);
+            if (db)
+                hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(p.Ngemm, 256)), dim3(256), 0, st, db_slab, p.splits,
+                                   1L, p.Ngemm, p.ldo, db);
+        }
         rc = check_launch("wgrad_reduce");
     }
     return rc;
