@@ -73,6 +73,11 @@ PROTOTYPES = {
     "acimg_latent_bwd": (_I, [_P, _P, _P, _P, _I, _F, _P, _I, _I, _P]),
     "acimg_latent_linear_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _P]),
     "acimg_latent_linear_bwd": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _P]),
+    "acimg_maxpool_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "acimg_maxpool_relu_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "acimg_spatial_sum": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "acimg_spatial_sum_relu_bwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "acimg_clip_softmax_ce": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "acimg_bn_bwd_workspace": (_SZ, [_L, _I]),
     "acimg_bn_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _I, _P, _I, _P, _P, _P, _SZ, _P]),
     "acimg_recon_loss": (_I, [_P, _P, _P, _P, _L, _F, _F, _P]),

@@ -414,6 +414,27 @@ def bn_bwd(plan, x, ldx, gy, ldgy, scale, shift, save_mean, save_invstd, gamma, 
              int(rows), int(Cn), gx, int(ldgx), dgamma, dbeta, _WsPtr(plan.ws), _WsBytes(plan.ws))
 
 
+def maxpool_fwd(plan, x, ldx, y, ldy, N, H, W, Cn, k):
+    plan.add("maxpool_fwd", _L().acimg_maxpool_fwd, x, int(ldx), y, int(ldy), N, H, W, Cn, k)
+
+
+def maxpool_relu_bwd(plan, x, ldx, gy, ldgy, gx, ldgx, N, H, W, Cn, k):
+    plan.add("maxpool_relu_bwd", _L().acimg_maxpool_relu_bwd, x, int(ldx), gy, int(ldgy), gx, int(ldgx), N, H, W, Cn, k)
+
+
+def spatial_sum(plan, x, ldx, y, N, P, Cn):
+    plan.add("spatial_sum", _L().acimg_spatial_sum, x, int(ldx), y, N, P, Cn)
+
+
+def spatial_sum_relu_bwd(plan, x, ldx, gy, gx, ldgx, N, P, Cn):
+    plan.add("spatial_sum_relu_bwd", _L().acimg_spatial_sum_relu_bwd, x, int(ldx), gy, gx, int(ldgx), N, P, Cn)
+
+
+def clip_softmax_ce(plan, logits, ldl, clips, F, K, labels, out, g_logits, ldg):
+    plan.add("clip_softmax_ce", _L().acimg_clip_softmax_ce, logits, int(ldl), clips, F, K, labels, out, g_logits,
+             int(ldg))
+
+
 def recon_loss(plan, yhat, target, g_logit, sums, count, w_mse=1.0, w_huber=1.0):
     plan.add("recon_loss", _L().acimg_recon_loss, yhat, target, g_logit, sums, int(count),
              float(w_mse), float(w_huber))

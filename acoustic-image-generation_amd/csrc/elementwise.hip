@@ -462,6 +462,111 @@ __global__ __launch_bounds__(256) void latent_linear_bwd_kernel(const float* hea
 }
 
 // ------------------------------------------------------------------------------------------
+// DualCamNet classifier pieces (models/dualcamnet.py:82-106, models/base.py:34-38): non-overlapping VALID max
+// pooling, the spatial reduce_sum, and the clip-level softmax cross-entropy of
+// trainer/trainer_reconstructed_class.py:49-56 (logits averaged over the clip's frames).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* x, int ldx, float* y, int ldy, int H, int W,
+                                                          int C, int OH, int OW, int k, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        long t = idx / C;
+        const int ow = (int)(t % OW);
+        t /= OW;
+        const int oh = (int)(t % OH);
+        const long n = t / OH;
+        float m = -INFINITY;
+        for (int r = 0; r < k; ++r)
+            for (int q = 0; q < k; ++q)
+                m = fmaxf(m, x[((n * H + oh * k + r) * W + ow * k + q) * ldx + c]);
+        y[((n * OH + oh) * OW + ow) * ldy + c] = m;
+    }
+}
+
+// gx = gradient w.r.t. the PRE-activation of the ReLU layer that feeds the pool: the window's gradient goes to
+// its first maximum (tf.nn.max_pool's argmax) and only where the activation is positive
+__global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const float* x, int ldx, const float* gy, int ldgy,
+                                                               float* gx, int ldgx, int H, int W, int C, int OH,
+                                                               int OW, int k, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        long t = idx / C;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const long n = t / H;
+        const int oh = h / k, ow = w / k;
+        float g = 0.f;
+        const float v = x[((n * H + h) * W + w) * ldx + c];
+        if (oh < OH && ow < OW && v > 0.f) {
+            bool take = true;
+            for (int r = 0; r < k; ++r)
+                for (int q = 0; q < k; ++q) {
+                    const int hh = oh * k + r, ww = ow * k + q;
+                    const float u = x[((n * H + hh) * W + ww) * ldx + c];
+                    const bool before = hh < h || (hh == h && ww < w);
+                    if (u > v || (u == v && before)) take = false;
+                }
+            if (take) g = gy[((n * OH + oh) * OW + ow) * ldgy + c];
+        }
+        gx[((n * H + h) * W + w) * ldgx + c] = g;
+    }
+}
+
+// y[n][c] = sum_p x[n][p][c]; one workgroup per (sample, 64-channel group)
+__global__ __launch_bounds__(256) void spatial_sum_kernel(const float* x, int ldx, float* y, int P, int C) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (int p = rg; p < P; p += 4) s += x[((long)n * P + p) * ldx + c];
+    red[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0 && c < C) y[(long)n * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void spatial_sum_relu_bwd_kernel(const float* x, int ldx, const float* gy, float* gx,
+                                                                   int ldgx, int P, int C, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const long np = idx / C;
+        const long n = np / P;
+        gx[np * ldgx + c] = x[np * ldx + c] > 0.f ? gy[n * C + c] : 0.f;
+    }
+}
+
+// one workgroup per clip: logits averaged over the F frames, softmax cross-entropy against `label`;
+// out[0] += loss / clips, out[1] += (argmax == label); g[n*F+f][c] = (p_c - [c == label]) / (clips * F)
+__global__ __launch_bounds__(64) void clip_softmax_ce_kernel(const float* logits, int ldl, int F, int K,
+                                                             const int* labels, int clips, float* out, float* g,
+                                                             int ldg) {
+    const int n = blockIdx.x, c = threadIdx.x;
+    float m = -INFINITY;
+    if (c < K) {
+        float a = 0.f;
+        for (int f = 0; f < F; ++f) a += logits[((long)n * F + f) * ldl + c];
+        m = a / (float)F;
+    }
+    const float mx = wave_max(m);
+    const float e = c < K ? expf(m - mx) : 0.f;
+    const float se = wave_sum(e);
+    const float p = e / se;
+    const int lab = labels[n];
+    // argmax with the lowest index among ties (tf.argmax)
+    int am = c < K && m == mx ? c : 1 << 20;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) am = min(am, __shfl_xor(am, o, 64));
+    if (c == lab) {
+        atomicAdd(out, -(m - mx - logf(se)) / (float)clips);
+        if (am == lab) atomicAdd(out + 1, 1.f);
+    }
+    if (g && c < K) {
+        const float gv = (p - (c == lab ? 1.f : 0.f)) / ((float)clips * (float)F);
+        for (int f = 0; f < F; ++f) g[((long)n * F + f) * ldg + c] = gv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // reconstruction loss (MSE + Huber delta=1) and gradient w.r.t. pre-sigmoid logits
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void recon_loss_kernel(const float* yhat, const float* target,
@@ -897,6 +1002,45 @@ int acimg_latent_linear_bwd(const float* heads, const float* eps, const float* g
     hipLaunchKernelGGL(latent_linear_bwd_kernel, dim3(cdiv((long)N * Z, 256)), dim3(256), 0, (hipStream_t)stream,
                        heads, eps, gz, ldgz, kl_weight, g_heads, N, Z);
     return check_launch("latent_linear_bwd");
+}
+
+int acimg_maxpool_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int k, void* stream) {
+    if (k <= 0 || H < k || W < k) return fail(ACIMG_EINVAL, "maxpool_fwd: window %d does not fit %dx%d", k, H, W);
+    const int OH = H / k, OW = W / k;
+    const long total = (long)N * OH * OW * C;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, H, W,
+                       C, OH, OW, k, total);
+    return check_launch("maxpool_fwd");
+}
+
+int acimg_maxpool_relu_bwd(const float* x, int ldx, const float* gy, int ldgy, float* gx, int ldgx, int N, int H,
+                           int W, int C, int k, void* stream) {
+    if (k <= 0 || H < k || W < k) return fail(ACIMG_EINVAL, "maxpool_relu_bwd: window %d does not fit %dx%d", k, H, W);
+    const long total = (long)N * H * W * C;
+    hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, gy, ldgy,
+                       gx, ldgx, H, W, C, H / k, W / k, k, total);
+    return check_launch("maxpool_relu_bwd");
+}
+
+int acimg_spatial_sum(const float* x, int ldx, float* y, int N, int P, int C, void* stream) {
+    hipLaunchKernelGGL(spatial_sum_kernel, dim3(N, cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, P, C);
+    return check_launch("spatial_sum");
+}
+
+int acimg_spatial_sum_relu_bwd(const float* x, int ldx, const float* gy, float* gx, int ldgx, int N, int P, int C,
+                               void* stream) {
+    const long total = (long)N * P * C;
+    hipLaunchKernelGGL(spatial_sum_relu_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, ldx, gy,
+                       gx, ldgx, P, C, total);
+    return check_launch("spatial_sum_relu_bwd");
+}
+
+int acimg_clip_softmax_ce(const float* logits, int ldl, int clips, int F, int K, const int* labels, float* out,
+                          float* g_logits, int ldg, void* stream) {
+    if (K <= 0 || K > 64 || F <= 0) return fail(ACIMG_EINVAL, "clip_softmax_ce: classes must be in 1..64 (got %d)", K);
+    hipLaunchKernelGGL(clip_softmax_ce_kernel, dim3(clips), dim3(64), 0, (hipStream_t)stream, logits, ldl, F, K, labels,
+                       clips, out, g_logits, ldg);
+    return check_launch("clip_softmax_ce");
 }
 
 size_t acimg_bn_bwd_workspace(long rows, int C) {

@@ -244,6 +244,35 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* G, lon
         partial[(long)blockIdx.y * ncols + col] = red[0][threadIdx.x] + red[1][threadIdx.x] +
                                                   red[2][threadIdx.x] + red[3][threadIdx.x];
 }
+// narrow variant (ncols <= 64, multiple of 4, ld % 4 == 0): a workgroup sweeps rows_per_block rows with float4
+// loads, (ncols/4) lanes per row; partial sums are combined in lane order -> deterministic
+__global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* G, long rows, int ncols, int ld,
+                                                            long rows_per_block, float* partial) {
+    __shared__ float sm[256 * 4];
+    const int c4n = ncols >> 2;
+    const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+    const int rstep = 256 / c4n;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tr < rstep) {
+        const long r0 = (long)blockIdx.x * rows_per_block;
+        const long r1 = min(rows, r0 + rows_per_block);
+        for (long r = r0 + tr; r < r1; r += rstep) {
+            const float4 v = *reinterpret_cast<const float4*>(G + r * ld + tc * 4);
+            a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sm[threadIdx.x * 4 + k] = a[k];
+    __syncthreads();
+    if (threadIdx.x < c4n) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < rstep; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] += sm[(j * c4n + threadIdx.x) * 4 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) partial[(long)blockIdx.x * ncols + threadIdx.x * 4 + k] = t[k];
+    }
+}
 __global__ void colsum_final_kernel(const float* partial, int parts, int ncols, float* out) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= ncols) return;
@@ -528,8 +557,11 @@ static int launch_colsum(const float* G, long rows, int ncols, int ld, float* ou
     const size_t need = (size_t)parts * ncols * sizeof(float);
     if (ws == nullptr || ws_bytes < need) return fail(ACIMG_EWORKSPACE, "colsum: workspace %zu < %zu", ws_bytes, need);
     float* partial = static_cast<float*>(ws);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(ncols, 64), parts), dim3(256), 0, st, G, rows,
-                       ncols, ld, rpb, partial);
+    if (ncols <= 64 && (ncols & 3) == 0 && (ld & 3) == 0 && aligned16(G))
+        hipLaunchKernelGGL(colsum_narrow_kernel, dim3(parts), dim3(256), 0, st, G, rows, ncols, ld, rpb, partial);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(ncols, 64), parts), dim3(256), 0, st, G, rows,
+                           ncols, ld, rpb, partial);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(ncols, 64)), dim3(64), 0, st, partial, parts, ncols, out);
     return check_launch("colsum");
 }

@@ -183,6 +183,28 @@ int acimg_bn_finalize(const float* stats, int rows, int C, int ldstats, double c
                       float* moving_var, float decay, float eps, int training, float* scale,
                       float* shift, float* save_mean, float* save_invstd, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * DualCamNet classifier head on generated acoustic images (models/dualcamnet.py:82-106,
+ * trainer/trainer_reconstructed_class.py:44-56).  The convs / FCs are acimg_conv2d_* (the temporal
+ * 12x1x1 conv3d is a 12x1 conv over a [clips, 12, 36*48, 12] view).
+ * ---------------------------------------------------------------------------------------- */
+/* tf.nn.max_pool k x k, stride k, VALID (models/base.py:34-38): y [N, H/k, W/k, C]. */
+int acimg_maxpool_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int k, void* stream);
+/* gx[N,H,W,C] = gradient w.r.t. the PRE-activation of the ReLU that produced x: gy of the window at its first
+ * maximum if x > 0, else 0 (positions outside every window get 0). */
+int acimg_maxpool_relu_bwd(const float* x, int ldx, const float* gy, int ldgy, float* gx, int ldgx, int N, int H,
+                           int W, int C, int k, void* stream);
+/* tf.reduce_sum(x, axis=[1,2]) (dualcamnet.py:96): y[n][c] = sum_p x[n][p][c]; and its backward through the ReLU
+ * that produced x: gx[n][p][c] = x > 0 ? gy[n][c] : 0. */
+int acimg_spatial_sum(const float* x, int ldx, float* y, int N, int P, int C, void* stream);
+int acimg_spatial_sum_relu_bwd(const float* x, int ldx, const float* gy, float* gx, int ldgx, int N, int P, int C,
+                               void* stream);
+/* logits [clips*F, ldl] -> mean over the F frames of a clip -> tf.losses.softmax_cross_entropy (mean over clips)
+ * and tf.argmax accuracy (trainer_reconstructed_class.py:49-56): out[0] += loss, out[1] += #correct (zero them
+ * first); g_logits (optional) = d loss / d logits.  labels: int32 class per clip.  classes <= 64. */
+int acimg_clip_softmax_ce(const float* logits, int ldl, int clips, int F, int K, const int* labels, float* out,
+                          float* g_logits, int ldg, void* stream);
+
 /* Training-mode batch-norm + ReLU backward for the conv-BN-ReLU stacks of the RGB / spectrogram U-Nets
  * (tf.layers.batch_normalization(training=True) + relu, models/unet_architecture.py:161-166,
  * models/unet_sound.py:155-160).  x = the pre-BN conv output (bias included), gy = gradient w.r.t. the ReLU

@@ -201,3 +201,34 @@ def test_unet_vae_host_graph_builds_on_cpu():
         for k, shape in want.items():
             assert tuple(sd[k].shape) == tuple(shape), k
         assert sorted(tr.model.train_vars) == sorted(k for k in want if ouv.trainable(k))
+
+
+def test_dualcamnet_oracle_and_host_graph():
+    """0.25 M parameters, conv3d SAME temporal padding 5/6, clip-mean logits; host graph builds on CPU"""
+    from acimg.dualcamnet import DualCamHybridModel
+    from acimg.session import Session
+    from oracle import dualcamnet as odc
+
+    shapes = odc.param_shapes(14)
+    n = sum(int(torch.tensor(s).prod()) for s in shapes.values())
+    assert abs(n - 0.25e6) / 0.25e6 < 0.05, n
+    p = odc.init_params(14, dtype=torch.float64, std=0.05)
+    x = torch.rand(24, 36, 48, 12, dtype=torch.float64)
+    fl, _ = odc.forward(p, x)
+    assert fl.shape == (24, 14)
+    # temporal SAME padding: frame f of the output sees frames f-5 .. f+6 -> changing frame 11 of clip 0 cannot
+    # reach output frame 5-6=... of clip 1, and reaches clip 0's frames 5..11 only
+    x2 = x.clone()
+    x2[11] += 1.0
+    fl2, _ = odc.forward(p, x2)
+    changed = (fl2 - fl).abs().amax(1) > 1e-12
+    assert changed[5:12].all() and not changed[:5].any() and not changed[12:].any()
+    loss, acc, logits = odc.loss_and_accuracy(fl, torch.tensor([1, 2]))
+    assert logits.shape == (2, 14) and torch.allclose(logits[0], fl[:12].mean(0))
+    sess = Session(torch.device("cpu"))
+    m = DualCamHybridModel(input_shape=[36, 48, 12], num_classes=14)
+    m._build_model(torch.zeros(24, 36, 48, 12), session=sess)
+    sess.finalize()
+    m.initialize()
+    sd = m.state_dict_tf()
+    assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
