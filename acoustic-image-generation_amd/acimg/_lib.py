@@ -91,6 +91,8 @@ PROTOTYPES = {
     "acimg_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
     "acimg_mfcc_frontend": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "acimg_find_logen": (_I, [_P, _P, _P, _L, _P]),
+    "acimg_mask_iou": (_I, [_P, _P, _I, _I, _P, _P]),
+    "acimg_crc32c": (C.c_uint32, [_P, _SZ, C.c_uint32]),
 }
 
 _lib = None

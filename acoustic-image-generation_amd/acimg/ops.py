@@ -485,6 +485,10 @@ def find_logen(plan, mfcc_img, idct, out, pixels):
     plan.add("find_logen", _L().acimg_find_logen, mfcc_img, idct, out, int(pixels))
 
 
+def mask_iou(plan, map_a, map_b, N, P, iou):
+    plan.add("mask_iou", _L().acimg_mask_iou, map_a, map_b, int(N), int(P), iou)
+
+
 def adam_lr_t(lr, step, beta1=0.9, beta2=0.999):
     """TF-1 Adam effective step size for 1-based step t."""
     return lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)

@@ -14,6 +14,7 @@ A tile, so normalised activations are never written to HBM.  Only the unit outpu
 0.8 GB at batch 32), so consecutive layers hit the 256 MiB Infinity Cache instead of streaming
 6.5 GB of distinct tensors.
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -388,9 +389,14 @@ class ResNet50Model(object):
 
 
 def load_state_file(f):
-    """{TF variable name: array}: a dict, an .npz, or a torch-saved dict (possibly under 'model')."""
+    """{TF variable name: array}: a dict, a TensorFlow checkpoint prefix, an .npz, or a torch-saved dict (possibly
+    under 'model')."""
     if isinstance(f, dict):
         return f.get("model", f)
+    if os.path.exists(str(f) + ".index"):
+        # a TensorFlow Saver-V2 bundle prefix (the reference's own checkpoints: trainer/mfcctrainer.py:214-247)
+        from . import tfio
+        return tfio.read_checkpoint(str(f))
     if str(f).endswith(".npz"):
         return dict(np.load(f))
     obj = torch.load(f, map_location="cpu", weights_only=False)

@@ -98,6 +98,50 @@ __global__ __launch_bounds__(256) void find_logen_kernel(const float* mfcc, cons
     out[p] = (float)(1.0 / s);
 }
 
+// iouenergythreshold.py:213-229: per sample, mask = map > mean(map) for the real and the generated energy map,
+// IoU = |m & m2| / |m | m2| (float64 means like NumPy's on float64 maps; 0/0 -> NaN as in the reference).
+// One workgroup per sample.
+__global__ __launch_bounds__(256) void mask_iou_kernel(const float* a, const float* b, int P, float* iou) {
+    __shared__ double sm[8];
+    __shared__ double means[2];
+    const float* pa = a + (long)blockIdx.x * P;
+    const float* pb = b + (long)blockIdx.x * P;
+    double sa = 0.0, sb = 0.0;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        sa += (double)pa[i];
+        sb += (double)pb[i];
+    }
+    sa = wave_sum_d(sa);
+    sb = wave_sum_d(sb);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        sm[wid] = sa;
+        sm[4 + wid] = sb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        means[0] = (sm[0] + sm[1] + sm[2] + sm[3]) / (double)P;
+        means[1] = (sm[4] + sm[5] + sm[6] + sm[7]) / (double)P;
+    }
+    __syncthreads();
+    double inter = 0.0, uni = 0.0;
+    for (int i = threadIdx.x; i < P; i += 256) {
+        const bool m1 = (double)pa[i] > means[0], m2 = (double)pb[i] > means[1];
+        inter += (m1 && m2) ? 1.0 : 0.0;
+        uni += (m1 || m2) ? 1.0 : 0.0;
+    }
+    inter = wave_sum_d(inter);
+    uni = wave_sum_d(uni);
+    __syncthreads();
+    if (lane == 0) {
+        sm[wid] = inter;
+        sm[4 + wid] = uni;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        iou[blockIdx.x] = (float)((sm[0] + sm[1] + sm[2] + sm[3]) / (sm[4] + sm[5] + sm[6] + sm[7]));
+}
+
 }  // namespace acimg
 
 using namespace acimg;
@@ -117,6 +161,12 @@ int acimg_find_logen(const float* mfcc_img, const double* idct, float* out, long
     hipLaunchKernelGGL(find_logen_kernel, dim3(cdiv(pixels, 256)), dim3(256), 0, (hipStream_t)stream,
                        mfcc_img, idct, out, pixels);
     return check_launch("find_logen");
+}
+
+int acimg_mask_iou(const float* map_a, const float* map_b, int N, int P, float* iou, void* stream) {
+    if (N <= 0 || P <= 0) return fail(ACIMG_EINVAL, "mask_iou: N and P must be positive");
+    hipLaunchKernelGGL(mask_iou_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, map_a, map_b, P, iou);
+    return check_launch("mask_iou");
 }
 
 }  // extern "C"

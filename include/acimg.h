@@ -333,6 +333,18 @@ int acimg_mfcc_frontend(const int32_t* frames, const double* window, const doubl
 int acimg_find_logen(const float* mfcc_img, const double* idct /*12x24*/, float* out, long pixels,
                      void* stream);
 
+/* Mean-threshold IoU of two energy maps per sample (iouenergythreshold.py:213-229): m = map > mean(map),
+ * iou[n] = |m_a & m_b| / |m_a | m_b|.  map_a, map_b: [N][P] float32 (acimg_find_logen outputs). */
+int acimg_mask_iou(const float* map_a, const float* map_b, int N, int P, float* iou, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side helper (no GPU): CRC-32C (Castagnoli) of a byte range, continuing from `crc` (0 to start) — the
+ * checksum of TensorFlow checkpoint bundles and TFRecord files, used by the checkpoint / TFRecord readers
+ * that stand where trainer/mfcctrainer.py:214-247 calls tf.train.Saver and
+ * dataloader/outdoor_data_mfcc.py:558-575 reads TFRecords.
+ * ---------------------------------------------------------------------------------------- */
+uint32_t acimg_crc32c(const void* data, size_t n, uint32_t crc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,3 +91,12 @@ def find_logen(mfcc_img):
     m *= MFNORM
     melspec = np.exp(np.dot(m, np.transpose(dct_base())))
     return 1 / np.sum(melspec, -1)
+
+
+def mask_iou(real_img, gen_img):
+    """iouenergythreshold.py:213-229 for one sample: [36,48,12] x 2 -> IoU of the mean-threshold masks"""
+    m1 = find_logen(real_img)
+    m2 = find_logen(gen_img)
+    a = m1 > np.mean(m1)
+    b = m2 > np.mean(m2)
+    return np.sum(np.logical_and(a, b)) / np.sum(np.logical_or(a, b))

@@ -52,3 +52,23 @@ def test_find_logen_matches_reference_golden(device):
     np.testing.assert_allclose(got, GOLD["logen32"], rtol=2e-6)
     img64 = torch.tensor(GOLD["img64"].astype(np.float32), device=device)
     np.testing.assert_allclose(fe.find_logen(img64).cpu().numpy(), GOLD["logen64"], rtol=5e-6)
+
+
+def test_energy_iou_vs_oracle(device):
+    """find_logen on real + generated image, mean-threshold masks, IoU (iouenergythreshold.py:213-229)"""
+    from acimg import evaluate
+    from oracle import frontend as ofe
+
+    g = torch.Generator().manual_seed(31)
+    N = 6
+    real = torch.rand(N, 36, 48, 12, generator=g) * 4 - 2
+    gen = real + 0.8 * torch.randn(N, 36, 48, 12, generator=g)
+    gen[5] = real[5]                                  # identical maps -> IoU exactly 1
+    ev = evaluate.EnergyIoU(device)
+    iou = ev.iou(real.to(device), gen.to(device)).cpu().numpy()
+    want = np.array([ofe.mask_iou(real[i].double().numpy(), gen[i].double().numpy()) for i in range(N)])
+    assert iou[5] == 1.0
+    # masks are thresholded at the mean: a pixel within float32 rounding of it may flip -> allow 2 pixels of 1728
+    assert np.all(np.abs(iou - want) <= 2.5 / (36 * 48 * want.clip(0.05))), (iou, want)
+    acc = evaluate.accuracy_curve(iou)
+    assert acc[0] == 1.0 and acc[-1] == 0.0 and np.all(np.diff(acc) <= 0)

@@ -1,0 +1,148 @@
+"""TensorFlow file formats without TensorFlow: Saver-V2 checkpoint bundles and GZIP
+TFRecords of SequenceExamples.  Known answers pin the checksum (RFC 3720 CRC-32C vectors), the leveldb masking
+constant and the SSTable magic; everything else is round-tripped and checked at the byte level where the format
+fixes the bytes."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "acoustic-image-generation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from acimg import tfio  # noqa: E402
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 B.4 test patterns + the classic check value
+    assert tfio.crc32c(b"123456789") == 0xE3069283
+    assert tfio.crc32c(bytes(32)) == 0x8A9136AA
+    assert tfio.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert tfio.crc32c(bytes(range(32))) == 0x46DD794E
+    assert tfio.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    # incremental = one shot; unaligned starts
+    data = bytes((i * 7 + 3) & 0xFF for i in range(1000))
+    assert tfio.crc32c(data[500:], tfio.crc32c(data[:500])) == tfio.crc32c(data)
+    assert tfio.crc32c_array(np.frombuffer(data, np.uint8)[3:]) == tfio.crc32c(data[3:])
+    # leveldb masking: rotate right 15, add 0xa282ead8 (crc32c.h); self-inverse pair
+    assert tfio.mask_crc(0) == 0xA282EAD8
+    for v in (0, 1, 0xDEADBEEF, 0xFFFFFFFF):
+        assert tfio.unmask_crc(tfio.mask_crc(v)) == v
+
+
+def test_checkpoint_roundtrip_and_layout(tmp_path):
+    rng = np.random.RandomState(0)
+    tensors = {
+        "UNetAcRes/layer1/conv_1/kernel": rng.randn(3, 3, 12, 128).astype(np.float32),
+        "UNetAcRes/layer1/conv_1/bias": rng.randn(128).astype(np.float32),
+        "resnet_v1_50/conv1/BatchNorm/moving_variance": rng.rand(64).astype(np.float32),
+        "global_step": np.array(1234, dtype=np.int64),
+        "UNetAcRes/mean/kernel": rng.randn(12, 16, 145, 150).astype(np.float32),   # 16.7 MB: many index entries
+    }
+    for i in range(300):   # enough keys for several SSTable data blocks (prefix compression + restarts exercised)
+        tensors["resnet_v1_50/block%d/unit_%d/bottleneck_v1/conv%d/weights" % (i % 4, i // 4, i % 3)] = \
+            rng.randn(2, 3).astype(np.float32)
+    prefix = str(tmp_path / "epoch_7.ckpt")
+    tfio.write_checkpoint(prefix, tensors)
+    assert os.path.exists(prefix + ".index") and os.path.exists(prefix + ".data-00000-of-00001")
+    raw = open(prefix + ".index", "rb").read()
+    assert raw[-8:] == bytes.fromhex("57fb808b247547db")          # kTableMagicNumber, little endian
+    back = tfio.read_checkpoint(prefix, verify=True)
+    assert set(back) == set(tensors)
+    for k, v in tensors.items():
+        assert back[k].dtype == v.dtype and back[k].shape == v.shape and np.array_equal(back[k], v), k
+    # keys come back sorted (an SSTable is ordered) with the header under the empty key
+    listing = tfio.list_checkpoint(prefix)
+    keys = list(listing)
+    assert keys[0] == "" and keys[1:] == sorted(keys[1:]) and listing[""]["num_shards"] == 1
+    e = listing["UNetAcRes/layer1/conv_1/kernel"]
+    assert e["dtype"] == 1 and e["shape"] == (3, 3, 12, 128) and e["size"] == 3 * 3 * 12 * 128 * 4
+    # selective read
+    only = tfio.read_checkpoint(prefix, names=lambda n: n.startswith("UNetAcRes/"))
+    assert set(only) == {k for k in tensors if k.startswith("UNetAcRes/")}
+    # corruption is detected: flip one byte of a data block / of a tensor
+    bad = bytearray(raw)
+    bad[10] ^= 0x40
+    open(prefix + ".index", "wb").write(bytes(bad))
+    with pytest.raises(IOError):
+        tfio.read_checkpoint(prefix)
+    open(prefix + ".index", "wb").write(raw)
+    with open(prefix + ".data-00000-of-00001", "r+b") as f:
+        f.seek(5)
+        f.write(b"\x99")
+    with pytest.raises(IOError):
+        tfio.read_checkpoint(prefix, verify=True)
+
+
+def test_checkpoint_feeds_the_model_state(tmp_path):
+    """a TF-named bundle initialises the HIP host model through the same entry the reference uses
+    (models/unet_acresnet.py:33-41 init_model -> assign_from_checkpoint_fn)"""
+    import torch
+    from acimg.session import Session
+    from acimg.unet_vae import UNetSound
+    from oracle import unet_vae as ouv
+
+    params = ouv.init_params("UNetSound", seed=3, bias_std=0.1, bn_jitter=0.1)
+    prefix = str(tmp_path / "model.ckpt")
+    tfio.write_checkpoint(prefix, {k: v.numpy() for k, v in params.items()})
+    sess = Session(torch.device("cpu"))
+    m = UNetSound()
+    m._build_model(torch.zeros(1, 99, 257, 1), session=sess)
+    sess.finalize()
+    loaded = m.init_model(sess, prefix)
+    assert len(loaded) == len(params)
+    sd = sess.store.state_dict()
+    for k, v in params.items():
+        assert torch.equal(sd[k], v), k
+
+
+def test_tfrecord_sequence_example_roundtrip(tmp_path):
+    """the dataset record of convert_data.py:247-279 / outdoor_data_mfcc.py:263-343"""
+    rng = np.random.RandomState(1)
+    context = {"classes": np.array([3], np.int64), "location": np.array([1], np.int64),
+               "audio_image/height": np.array([36], np.int64), "audio_image/width": np.array([48], np.int64),
+               "audio_image/depth": np.array([12], np.int64), "audio_data/mics": np.array([128], np.int64),
+               "audio_data/samples": np.array([1024], np.int64), "video/height": np.array([224], np.int64),
+               "video/width": np.array([298], np.int64), "video/depth": np.array([3], np.int64)}
+    steps = 2
+    lists = {"audio/image": [rng.rand(36 * 48 * 12).astype(np.float32) for _ in range(steps)],
+             "audio/data": [rng.randint(-2 ** 31, 2 ** 31 - 1, size=1024).astype(np.int64) for _ in range(steps)],
+             "video/image": [bytes(rng.randint(0, 256, size=224 * 298 * 3).astype(np.uint8)) for _ in range(steps)]}
+    rec = tfio.build_sequence_example(context, lists)
+    for comp in (None, "GZIP"):
+        path = str(tmp_path / ("data_%s.tfrecord" % comp))
+        tfio.write_tfrecord(path, [rec, rec[:100] + rec[100:]], compression=comp)
+        got = list(tfio.read_tfrecord(path))          # compression auto-detected from the gzip magic
+        assert got == [rec, rec]
+        ctx, fl = tfio.parse_sequence_example(got[0])
+        assert set(ctx) == set(context) and all(np.array_equal(ctx[k], context[k]) for k in context)
+        assert np.array_equal(fl["audio/image"][1], lists["audio/image"][1])
+        assert np.array_equal(fl["audio/data"][0], lists["audio/data"][0])      # negative int64 varints
+        assert fl["video/image"][1] == [lists["video/image"][1]]
+    # framing bytes: [len u64][masked crc(len)][payload][masked crc(payload)]
+    raw = open(str(tmp_path / "data_None.tfrecord"), "rb").read()
+    n = struct.unpack("<Q", raw[:8])[0]
+    assert n == len(rec)
+    assert struct.unpack("<I", raw[8:12])[0] == tfio.mask_crc(tfio.crc32c(raw[:8]))
+    assert struct.unpack("<I", raw[12 + n:16 + n])[0] == tfio.mask_crc(tfio.crc32c(rec))
+    bad = bytearray(raw)
+    bad[40] ^= 1
+    open(str(tmp_path / "bad.tfrecord"), "wb").write(bytes(bad))
+    with pytest.raises(IOError):
+        list(tfio.read_tfrecord(str(tmp_path / "bad.tfrecord")))
+
+
+def test_iou_curve_host_arithmetic():
+    """accuracy(tau) and the trapezoid area (iouenergythreshold.py:226-236, areaundercurve.py:26-40)"""
+    from acimg import evaluate
+    from sklearn import metrics
+
+    ious = np.array([0.05, 0.15, 0.55, 0.95, 1.0, 0.3])
+    acc = evaluate.accuracy_curve(ious)
+    assert acc[0] == 1.0 and acc[-1] == 0.0 and abs(acc[5] - 0.5) < 1e-12      # IoU > 0.5: 3 of 6
+    want = metrics.auc(evaluate.THRESHOLDS[::-1], list(acc[::-1]))
+    assert abs(evaluate.area_under_curve(acc) - want) < 1e-12
