@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--num-skip", type=int, default=1)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
                     help="trunk conv arithmetic: split-fp16 MFMA (fp32-class results) or exact-f32 MFMA")
+    ap.add_argument("--workload", default="trainer_mask", choices=["trainer_mask", "unet_rgb", "unet_sound", "classifier"],
+                    help="trainer_mask (default: the north-star path, BASELINE configs[2]/[3]); unet_rgb / unet_sound: the "
+                         "single-modality U-Net VAEs of configs[1] / [0]; classifier: DualCamNet on generated images, "
+                         "configs[4]'s head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -70,8 +74,72 @@ def cpu_baseline(args):
                       "same train step, batch %d, %d timed steps after 1 warm-up" % (args.cpu_batch, args.cpu_steps)}
 
 
+def other_workload(args):
+    """single-GPU timing of the other train steps (same JSON contract, no roofline probe: these steps have no
+    single dominant kernel; HBM-bound few-channel layers)"""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    from acimg.session import Session
+    B = args.batch
+    sess = Session(dev)
+    gen = torch.Generator().manual_seed(1234)
+    if args.workload in ("unet_rgb", "unet_sound"):
+        from acimg.trainer_vae import TrainerVAE
+        from acimg.unet_vae import UNet, UNetSound
+        cls = UNet if args.workload == "unet_rgb" else UNetSound
+        tr = TrainerVAE(cls(), learning_rate=1e-4, session=sess)
+        g = tr._build_functions(batch_size=B)
+        tr.model.initialize(seed=1240)
+        g.images.copy_(torch.rand(*g.images.shape, generator=gen))
+        step = lambda: tr.train_step(sync=False)  # noqa: E731
+        name = ("%s VAE train step (%s, %dx%dx%d, conv-BN-ReLU U-Net, MSE+Huber+KL+L2, backward, TF-1 Adam)" %
+                (cls.__name__, "models/unet_architecture.py" if cls is UNet else "models/unet_sound.py",
+                 tr.model.height, tr.model.width, tr.model.channels))
+        last = lambda: dict(zip(("mse", "huber", "latent", "reg", "loss"), g.losses[:5].tolist()))  # noqa: E731
+        launches = len(g.plan_train) + 1
+    else:
+        from acimg.dualcamnet import DualCamHybridModel
+        from acimg.flags import FLAGS
+        from acimg.trainer_class import TrainerClass
+        from acimg.unet_acresnet import UNetAc
+        from acimg.vision import ResNet50Model
+        FLAGS.model = "DualCamNet"
+        B = (B // 12) * 12 or 12
+        tr = TrainerClass(DualCamHybridModel(input_shape=[36, 48, 12], num_classes=14),
+                          ResNet50Model(input_shape=[224, 298, 3], num_classes=None, precision=args.precision),
+                          UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=args.num_skip), session=sess)
+        g = tr._build_functions(batch_size=B)
+        tr.model_encoder_images.initialize(seed=1238)
+        tr.model_encoder_acoustic.initialize(seed=1239)
+        tr.model.initialize(seed=1241)
+        g.video.copy_(torch.rand(B, 224, 298, 3, generator=gen))
+        g.mfcc.copy_(torch.rand(B, 12, generator=gen))
+        step = lambda: tr.train_step()  # noqa: E731
+        name = ("DualCamNet classifier on generated images (trainer_reconstructed_class.py): ResNet-50-mod + UNetAcRes "
+                "forward (inference mode) + DualCamNet forward/backward + Adam, %d clips of 12 frames" % (B // 12))
+        last = lambda: dict(zip(("loss", "correct"), g.out[:2].tolist()))  # noqa: E731
+        launches = len(g.plan_train) + 1
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "train-step images/sec", "value": B * args.steps / dt, "unit": "images/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": name, "per_gpu_batch": B, "global_batch": B, "parallelism": "dp1",
+                   "launches_per_step": launches},
+        "final": last(), "roofline": None}))
+
+
 def main():
     args = parse()
+    if args.workload != "trainer_mask":
+        return other_workload(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
