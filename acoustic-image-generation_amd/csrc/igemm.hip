@@ -39,12 +39,16 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float* s
 // ------------------------------------------------------------------------------------------
 // weight gradient kernel: dW[kk][n] = sum_m A(m,kk) G[m][n]
 // ------------------------------------------------------------------------------------------
-template <int BMO, int BN>
+// WGM x WGN = 4 waves: 2 x 2, or 4 x 1 for the 16-column tile of the few-column problems (N <= 16: conv_map's 12
+// outputs, the 8-channel layers of the RGB / spectrogram U-Nets) where a 32-wide tile would be mostly padding
+template <int BMO, int BN, int WGM = 2>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
     constexpr int BKR = 16;  // pixels per step
     constexpr int LDA_S = BMO + 4;
     constexpr int LDB_S = BN + 4;
-    constexpr int WTM = BMO / 2, WTN = BN / 2;
+    constexpr int WGN = 4 / WGM;
+    constexpr int WTM = BMO / WGM, WTN = BN / WGN;
+    static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile");
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int AQ = BMO / 4;               // float4 per A row
     constexpr int ARPP = 256 / AQ;            // A rows per pass
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WGN, wn = wid % WGN;
     const int li = lane & 15, g = lane >> 4;
     const int kk0 = blockIdx.x * BMO, n0 = blockIdx.y * BN;
 
@@ -84,6 +88,18 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
     const bool nb_ok = nb < p.Nld;
     const int ohw = p.OH * p.OW;
 
+    // pixel coordinates of this thread's A rows, advanced incrementally by BKR pixels per step (two integer
+    // divisions per load were the bulk of this kernel's time on the few-channel layers: no hardware divider)
+    int x_img[NA], x_oh[NA], x_ow[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int m = m_begin + arow0 + j * ARPP;
+        x_img[j] = m / ohw;
+        const int rem = m - x_img[j] * ohw;
+        x_oh[j] = rem / p.OW;
+        x_ow[j] = rem - x_oh[j] * p.OW;
+    }
+
     float4 ra[NA], rb[NB];
     auto load_tiles = [&](int mb) {
 #pragma unroll
@@ -93,17 +109,21 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < BKR && kk_ones && m < m_end) v.x = 1.f;
             if (row < BKR && kk_ok && m < m_end) {
-                const int img = m / ohw;
-                const int rem = m - img * ohw;
-                const int oh = rem / p.OW;
-                const int ow = rem - oh * p.OW;
-                const int ih = oh * p.stride - p.pad_t + r;
-                const int iw = ow * p.stride - p.pad_l + s;
+                const int ih = x_oh[j] * p.stride - p.pad_t + r;
+                const int iw = x_ow[j] * p.stride - p.pad_l + s;
                 if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
                     v = *reinterpret_cast<const float4*>(
-                        p.X + ((long)(img * p.H + ih) * p.W + iw) * p.ldx + c);
+                        p.X + ((long)(x_img[j] * p.H + ih) * p.W + iw) * p.ldx + c);
             }
             ra[j] = v;
+            x_ow[j] += BKR;                    // this row slot moves BKR pixels ahead for the next call
+            while (x_ow[j] >= p.OW) {
+                x_ow[j] -= p.OW;
+                if (++x_oh[j] == p.OH) {
+                    x_oh[j] = 0;
+                    ++x_img[j];
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -353,6 +373,94 @@ __global__ __launch_bounds__(256) void dilate2d_kernel(const float* in, int ldin
 }
 
 // ------------------------------------------------------------------------------------------
+// Direct convolution for FEW-CHANNEL layers (C*K <= 512: the 4/8/16-channel full-resolution layers of the RGB /
+// spectrogram U-Nets, models/unet_architecture.py:55-60,78-85).  There the implicit GEMM is a bad fit: a
+// workgroup runs 3 K steps on tiles that are mostly padding and never amortises its prologue.  Here a lane owns
+// one output pixel and 8 output channels, walks the taps with 16-byte loads (neighbouring lanes hit the same
+// lines) and takes the weights as wave-uniform LDS broadcasts: 8 FMAs per input value, the work is VALU- and
+// HBM-shaped.  mode 0: forward, weights HWIO w[tap][c][k]; mode 1: stride-1 data gradient read as a forward
+// conv over gy with flipped taps, weights w[ntaps-1-tap][kout][cin].
+// ------------------------------------------------------------------------------------------
+struct DirectParams {
+    const float* x; int ldx, H, W, C;
+    float* y; int ldy, OH, OW, K;
+    int R, S, stride, pad_t, pad_l;
+    const float* w; int ldw, mode, wrows;   // wrows: rows per tap of the weight tensor (C fwd, Kout dgrad)
+    const float* bias; int act;
+    const float* res; int ldres;
+    long M;
+};
+
+__global__ __launch_bounds__(256) void direct_conv_kernel(const DirectParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [ntaps][C][8]
+    const int kg = blockIdx.y * 8;
+    const int ntaps = p.R * p.S;
+    for (int i = threadIdx.x; i < ntaps * p.C * 8; i += 256) {
+        const int k = i & 7, c = (i >> 3) % p.C, tap = (i >> 3) / p.C;
+        float v = 0.f;
+        if (kg + k < p.K)
+            v = p.mode == 0 ? p.w[((long)tap * p.wrows + c) * p.ldw + kg + k]
+                            : p.w[((long)(ntaps - 1 - tap) * p.wrows + kg + k) * p.ldw + c];
+        wl[i] = v;
+    }
+    __syncthreads();
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= p.M) return;
+    const int ow = (int)(m % p.OW);
+    const long t = m / p.OW;
+    const int oh = (int)(t % p.OH);
+    const long n = t / p.OH;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
+    for (int r = 0; r < p.R; ++r) {
+        const int ih = ih0 + r;
+        for (int q = 0; q < p.S; ++q) {
+            const int iw = iw0 + q;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const float* src = p.x + ((n * p.H + ih) * p.W + iw) * p.ldx;
+            const float* wt = wl + (r * p.S + q) * p.C * 8;
+            for (int c = 0; c < p.C; c += 4) {
+                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) xv = *reinterpret_cast<const float4*>(src + c);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(wt + (c + i) * 8);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wt + (c + i) * 8 + 4);
+                    acc[0] = fmaf(xs[i], w0.x, acc[0]);
+                    acc[1] = fmaf(xs[i], w0.y, acc[1]);
+                    acc[2] = fmaf(xs[i], w0.z, acc[2]);
+                    acc[3] = fmaf(xs[i], w0.w, acc[3]);
+                    acc[4] = fmaf(xs[i], w1.x, acc[4]);
+                    acc[5] = fmaf(xs[i], w1.y, acc[5]);
+                    acc[6] = fmaf(xs[i], w1.z, acc[6]);
+                    acc[7] = fmaf(xs[i], w1.w, acc[7]);
+                }
+            }
+        }
+    }
+    float* dst = p.y + m * p.ldy + kg;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (kg + 4 * h >= p.K) break;
+        float4 o = make_float4(acc[4 * h], acc[4 * h + 1], acc[4 * h + 2], acc[4 * h + 3]);
+        if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + kg + 4 * h);
+            o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+        }
+        if (p.res) {
+            const float4 rr = *reinterpret_cast<const float4*>(p.res + m * p.ldres + kg + 4 * h);
+            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        }
+        o.x = apply_act(o.x, p.act); o.y = apply_act(o.y, p.act);
+        o.z = apply_act(o.z, p.act); o.w = apply_act(o.w, p.act);
+        *reinterpret_cast<float4*>(dst + 4 * h) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side: configuration choice and launch
 // ------------------------------------------------------------------------------------------
 struct TileCfg {
@@ -482,7 +590,7 @@ static int pick_wgrad_splits(int M, int KK, int Ngemm, int bmo, int bn) {
 }
 static void wgrad_tile(int Ngemm, int& bmo, int& bn) {
     bmo = 128;
-    bn = Ngemm <= 32 ? 32 : (Ngemm <= 64 ? 64 : 128);
+    bn = Ngemm <= 16 ? 16 : (Ngemm <= 32 ? 32 : (Ngemm <= 64 ? 64 : 128));
 }
 static size_t wgrad_ws_bytes(int M, int KK, int Ngemm, int ldo) {
     int bmo, bn;
@@ -524,7 +632,8 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
     else if (split3) hipLaunchKernelGGL((wgrad_split3_kernel<64>), grid, dim3(256), 65536, st, p);
     else if (bn == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, st, p);
     else if (bn == 64) hipLaunchKernelGGL((wgrad_f32_kernel<128, 64>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((wgrad_f32_kernel<128, 32>), grid, dim3(256), 0, st, p);
+    else if (bn == 32) hipLaunchKernelGGL((wgrad_f32_kernel<128, 32>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_f32_kernel<128, 16, 4>), grid, dim3(256), 0, st, p);
     int rc = check_launch("wgrad");
     if (rc) return rc;
     if (p.splits > 1) {
@@ -589,6 +698,19 @@ using namespace acimg;
 // ==========================================================================================
 extern "C" {
 
+// few-channel direct path: C*K <= 512, K <= 32 and a multiple of 8, plain 16-byte-aligned operands
+static bool direct_ok(int C, int K, int ldy, int ldres, const float* y, const float* bias, const float* res,
+                      bool affine, const float* mask) {
+    return !affine && !mask && (long)C * K <= 512 && K <= 32 && (K & 7) == 0 && (C & 3) == 0 && (ldy & 3) == 0 &&
+           (!res || ((ldres & 3) == 0 && aligned16(res))) && aligned16(y) && (!bias || aligned16(bias));
+}
+static int launch_direct(const DirectParams& q, hipStream_t st) {
+    if (!aligned16(q.x) || (q.ldx & 3)) return fail(ACIMG_EINVAL, "direct conv: input must be 16-byte aligned");
+    const size_t lds = (size_t)q.R * q.S * q.C * 8 * sizeof(float);
+    hipLaunchKernelGGL(direct_conv_kernel, dim3(cdiv(q.M, 256), q.K / 8), dim3(256), lds, st, q);
+    return check_launch("direct_conv");
+}
+
 static int fwd_kiters(const AcimgConvDesc* d) {
     const bool rowrun = d->S > 1 && d->ldx == d->C;
     const int L = rowrun ? d->S * d->C : d->C;
@@ -598,7 +720,10 @@ static int fwd_kiters(const AcimgConvDesc* d) {
 int acimg_conv2d_stats_rows(const AcimgConvDesc* d) {
     const int M = d->N * d->OH * d->OW;
     TileCfg c = pick_cfg(M, d->K);
-    return pick_splits(M, d->K, c, fwd_kiters(d)) > 1 ? cdiv(M, 256) : cdiv(M, c.bm);
+    // upper bound over the paths acimg_conv2d_fwd may take (direct few-channel conv and split-K: 256-row partials;
+    // unused rows stay zero and add nothing in acimg_bn_finalize)
+    const int r256 = cdiv(M, 256), rt = cdiv(M, c.bm);
+    return r256 > rt ? r256 : rt;
 }
 
 int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
@@ -621,6 +746,22 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
     int rc = check_desc(d, "conv2d_fwd");
     if (rc) return rc;
     if (d->ldw < d->K) return fail(ACIMG_EINVAL, "conv2d_fwd: ldw < K");
+    if (direct_ok(d->C, d->K, d->ldy, 0, y, bias, nullptr, in_scale != nullptr, nullptr) &&
+        (long)d->N * d->OH * d->OW >= 65536) {
+        DirectParams q{};
+        q.x = x; q.ldx = d->ldx; q.H = d->H; q.W = d->W; q.C = d->C;
+        q.y = y; q.ldy = d->ldy; q.OH = d->OH; q.OW = d->OW; q.K = d->K;
+        q.R = d->R; q.S = d->S; q.stride = d->stride; q.pad_t = d->pad_t; q.pad_l = d->pad_l;
+        q.w = w; q.ldw = d->ldw; q.mode = 0; q.wrows = d->C; q.bias = bias; q.act = d->act;
+        q.M = (long)d->N * d->OH * d->OW;
+        rc = launch_direct(q, (hipStream_t)stream);
+        if (!rc && stats) {   // batch-norm partials of y = conv + bias, as after a split-K conv
+            hipLaunchKernelGGL(partial_stats_kernel, dim3(cdiv(q.M, 256)), dim3(256), 0, (hipStream_t)stream, y, d->ldy,
+                               (int)q.M, d->K, stats, d->ldw);
+            rc = check_launch("partial_stats");
+        }
+        return rc;
+    }
     IgemmParams p{};
     p.A = x; p.H = d->H; p.W = d->W; p.C = d->C; p.lda = d->ldx;
     p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride;
@@ -684,6 +825,17 @@ int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
         d1.stride = 1; d1.OH = OH1; d1.OW = OW1;
         return acimg_conv2d_dgrad(&d1, static_cast<const float*>(ws), ca, w, dx, lddx, residual, ldres, mask, ldmask,
                                   static_cast<char*>(ws) + db, ws_bytes - db, stream);
+    }
+    if (d->stride == 1 && direct_ok(ca, d->C, lddx, ldres, dx, nullptr, residual, false, mask) &&
+        (long)d->N * d->H * d->W >= 65536) {
+        DirectParams q{};
+        q.x = gy; q.ldx = ldgy; q.H = d->OH; q.W = d->OW; q.C = ca;
+        q.y = dx; q.ldy = lddx; q.OH = d->H; q.OW = d->W; q.K = d->C;
+        q.R = d->R; q.S = d->S; q.stride = 1; q.pad_t = d->R - 1 - d->pad_t; q.pad_l = d->S - 1 - d->pad_l;
+        q.w = w; q.ldw = d->ldw; q.mode = 1; q.wrows = d->C; q.act = ACIMG_ACT_NONE;
+        q.res = residual; q.ldres = ldres;
+        q.M = (long)d->N * d->H * d->W;
+        return launch_direct(q, (hipStream_t)stream);
     }
     if (d->stride == 1) {
         // dx[h,w,c] = sum_{r',s',k} gy[h-(R-1-pt)+r', w-(S-1-pl)+s', k] * W[R-1-r'][S-1-s'][c][k]

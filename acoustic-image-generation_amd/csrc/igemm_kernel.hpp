@@ -224,16 +224,28 @@ __global__ __launch_bounds__(NTHR) void igemm_f32_kernel(const IgemmParams p) {
     const int arow0 = tid / KQ;
     int a_off[NA], a_ih0[NA], a_iw0[NA];
     {
+        // (img, oh, ow) of the first row by division, of the following rows by carrying RPP pixels forward:
+        // few-channel layers run 3 K steps per workgroup, 2*NA integer divisions would outweigh them
         const int ohw = p.OH * p.OW;
+        int img = (m0 + arow0) / ohw;
+        int rem0 = (m0 + arow0) - img * ohw;
+        int oh = rem0 / p.OW;
+        int ow = rem0 - oh * p.OW;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int row = arow0 + j * RPP;
             const int m = m0 + row;
+            if (j > 0) {
+                ow += RPP;
+                while (ow >= p.OW) {
+                    ow -= p.OW;
+                    if (++oh == p.OH) {
+                        oh = 0;
+                        ++img;
+                    }
+                }
+            }
             if (row < BM && m < p.M) {
-                const int img = m / ohw;
-                const int rem = m - img * ohw;
-                const int oh = rem / p.OW;
-                const int ow = rem - oh * p.OW;
                 a_ih0[j] = oh * p.stride - p.pad_t;
                 a_iw0[j] = ow * p.stride - p.pad_l;
                 a_off[j] = ((img * p.H + a_ih0[j]) * p.W + a_iw0[j]) * p.lda * 4;

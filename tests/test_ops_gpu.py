@@ -688,3 +688,45 @@ def test_error_reporting(device):
     with pytest.raises(_lib.AcimgError) as ei:
         ops.conv2d_fwd(ops.Plan(device, eager=True), d, x, w, None, y)
     assert "multiples of 4" in str(ei.value)
+
+
+@pytest.mark.parametrize("case", [(2, 200, 180, 8, 8, 3, 3, 1, "SAME"), (2, 190, 200, 4, 8, 3, 3, 1, "SAME"),
+                                  (2, 200, 190, 16, 8, 3, 3, 1, "SAME"), (3, 224, 298, 8, 8, 3, 3, 2, "SAME"),
+                                  (2, 150, 240, 8, 32, 2, 3, 2, "VALID"), (2, 180, 200, 8, 16, 3, 3, 1, "SAME")])
+def test_few_channel_direct_conv(device, case):
+    """the direct few-channel path (>= 65536 output pixels, C*K <= 512): forward with bias + ReLU + BN statistics,
+    and the data gradient with a residual, vs fp64"""
+    from acimg import ops
+
+    N, H, W, Cc, K, R, S, stride, padding = case
+    g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)) + 5)
+    x = rnd(g, N, H, W, Cc).requires_grad_(True)
+    w = (rnd(g, R, S, Cc, K) * 0.2).requires_grad_(True)
+    b = rnd(g, K)
+    OH, OW, pads = _conv_geom(H, W, R, S, stride, padding)
+    raw = tf_conv_ref(x, w, stride, pads, b)
+    d = ops.conv_desc(N, H, W, Cc, K, R, S, stride, padding, act=1)
+    plan = ops.Plan(device, eager=True)
+    y = torch.zeros(N, OH, OW, K, device=device)
+    srows = ops.conv2d_stats_rows(d)
+    stats = torch.zeros(srows, 2, K, device=device)
+    wd = dev(w.detach(), device)
+    ops.conv2d_fwd(plan, d, dev(x.detach(), device), wd, dev(b, device), y, stats=stats)
+    torch.cuda.synchronize()
+    close(y, torch.relu(raw.detach()), what="direct fwd %s" % (case,))
+    # (statistics are those of the stored tensor = conv + bias with the activation applied here; BN layers use act NONE)
+    d0 = ops.conv_desc(N, H, W, Cc, K, R, S, stride, padding, act=0)
+    stats.zero_()
+    ops.conv2d_fwd(plan, d0, dev(x.detach(), device), wd, dev(b, device), y, stats=stats)
+    torch.cuda.synchronize()
+    flat = raw.detach().reshape(-1, K)
+    close(stats[:, 0].sum(0), flat.sum(0), tol=2e-4, what="direct stats sum")
+    close(stats[:, 1].sum(0), (flat * flat).sum(0), tol=2e-4, what="direct stats sumsq")
+    gy = rnd(g, N, OH, OW, K)
+    raw.backward(gy)
+    res = rnd(g, N, H, W, Cc)
+    dx = torch.full((N, H, W, Cc), 3.0, device=device)
+    if Cc % 8 == 0:
+        ops.conv2d_dgrad(plan, d0, dev(gy, device), K, wd, dx, dev(res, device), Cc)
+        torch.cuda.synchronize()
+        close(dx, x.grad + res, what="direct dgrad %s" % (case,))
