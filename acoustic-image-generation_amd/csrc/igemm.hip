@@ -391,19 +391,26 @@ struct DirectParams {
     long M;
 };
 
-__global__ __launch_bounds__(256) void direct_conv_kernel(const DirectParams p) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [ntaps][C][8]
-    const int kg = blockIdx.y * 8;
+// weights -> [K/8][ntaps][C][8] (8 consecutive output channels innermost), zero beyond K
+__global__ __launch_bounds__(256) void direct_prepare_kernel(const DirectParams p, float* wprep, int total) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
     const int ntaps = p.R * p.S;
-    for (int i = threadIdx.x; i < ntaps * p.C * 8; i += 256) {
-        const int k = i & 7, c = (i >> 3) % p.C, tap = (i >> 3) / p.C;
-        float v = 0.f;
-        if (kg + k < p.K)
-            v = p.mode == 0 ? p.w[((long)tap * p.wrows + c) * p.ldw + kg + k]
-                            : p.w[((long)(ntaps - 1 - tap) * p.wrows + kg + k) * p.ldw + c];
-        wl[i] = v;
-    }
-    __syncthreads();
+    const int k = i & 7, c = (i >> 3) % p.C, tap = ((i >> 3) / p.C) % ntaps, kg = ((i >> 3) / p.C) / ntaps;
+    const int ko = kg * 8 + k;
+    float v = 0.f;
+    if (ko < p.K)
+        v = p.mode == 0 ? p.w[((long)tap * p.wrows + c) * p.ldw + ko]
+                        : p.w[((long)(ntaps - 1 - tap) * p.wrows + ko) * p.ldw + c];
+    wprep[i] = v;
+}
+
+__global__ __launch_bounds__(256) void direct_conv_kernel(const DirectParams p, const float* __restrict__ wprep) {
+    // the weight addresses below are wave-uniform: they become scalar loads (s_load_dwordx8), the FMAs take the
+    // weights from SGPRs, no LDS and no vector-memory traffic for them
+    const int ntaps = p.R * p.S;
+    const int kg = blockIdx.y * 8;
+    const float* __restrict__ wl = wprep + (long)blockIdx.y * ntaps * p.C * 8;
     const long m = (long)blockIdx.x * 256 + threadIdx.x;
     if (m >= p.M) return;
     const int ow = (int)(m % p.OW);
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectParams p) 
             const int iw = iw0 + q;
             const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
             const float* src = p.x + ((n * p.H + ih) * p.W + iw) * p.ldx;
-            const float* wt = wl + (r * p.S + q) * p.C * 8;
+            const float* __restrict__ wt = wl + (r * p.S + q) * p.C * 8;
             for (int c = 0; c < p.C; c += 4) {
                 float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ok) xv = *reinterpret_cast<const float4*>(src + c);
@@ -698,16 +705,20 @@ using namespace acimg;
 // ==========================================================================================
 extern "C" {
 
-// few-channel direct path: C*K <= 512, K <= 32 and a multiple of 8, plain 16-byte-aligned operands
+// few-channel direct path: C <= 16 (wider pixels stop coalescing across lanes), K <= 32 and a multiple of 8
 static bool direct_ok(int C, int K, int ldy, int ldres, const float* y, const float* bias, const float* res,
                       bool affine, const float* mask) {
-    return !affine && !mask && (long)C * K <= 512 && K <= 32 && (K & 7) == 0 && (C & 3) == 0 && (ldy & 3) == 0 &&
+    return !affine && !mask && C <= 16 && K <= 32 && (K & 7) == 0 && (C & 3) == 0 && (ldy & 3) == 0 &&
            (!res || ((ldres & 3) == 0 && aligned16(res))) && aligned16(y) && (!bias || aligned16(bias));
 }
-static int launch_direct(const DirectParams& q, hipStream_t st) {
+static size_t direct_ws_bytes(int R, int S, int C, int K) { return ((size_t)R * S * C * K * sizeof(float) + 255) & ~(size_t)255; }
+static int launch_direct(const DirectParams& q, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!aligned16(q.x) || (q.ldx & 3)) return fail(ACIMG_EINVAL, "direct conv: input must be 16-byte aligned");
-    const size_t lds = (size_t)q.R * q.S * q.C * 8 * sizeof(float);
-    hipLaunchKernelGGL(direct_conv_kernel, dim3(cdiv(q.M, 256), q.K / 8), dim3(256), lds, st, q);
+    const int total = q.R * q.S * q.C * q.K;
+    if (!ws || ws_bytes < (size_t)total * sizeof(float)) return fail(ACIMG_EWORKSPACE, "direct conv: workspace too small");
+    float* wprep = static_cast<float*>(ws);
+    hipLaunchKernelGGL(direct_prepare_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, q, wprep, total);
+    hipLaunchKernelGGL(direct_conv_kernel, dim3(cdiv(q.M, 256), q.K / 8), dim3(256), 0, st, q, wprep);
     return check_launch("direct_conv");
 }
 
@@ -737,7 +748,9 @@ int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
 }
 
 size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d) {
-    return igemm_ws_bytes(d->N * d->OH * d->OW, d->K, fwd_kiters(d));
+    const size_t a = igemm_ws_bytes(d->N * d->OH * d->OW, d->K, fwd_kiters(d));
+    const size_t b = d->C <= 16 && d->K <= 32 ? direct_ws_bytes(d->R, d->S, d->C, (d->K + 7) & ~7) : 0;
+    return a > b ? a : b;
 }
 
 int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
@@ -754,7 +767,7 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
         q.R = d->R; q.S = d->S; q.stride = d->stride; q.pad_t = d->pad_t; q.pad_l = d->pad_l;
         q.w = w; q.ldw = d->ldw; q.mode = 0; q.wrows = d->C; q.bias = bias; q.act = d->act;
         q.M = (long)d->N * d->OH * d->OW;
-        rc = launch_direct(q, (hipStream_t)stream);
+        rc = launch_direct(q, ws, ws_bytes, (hipStream_t)stream);
         if (!rc && stats) {   // batch-norm partials of y = conv + bias, as after a split-K conv
             hipLaunchKernelGGL(partial_stats_kernel, dim3(cdiv(q.M, 256)), dim3(256), 0, (hipStream_t)stream, y, d->ldy,
                                (int)q.M, d->K, stats, d->ldw);
@@ -789,10 +802,12 @@ size_t acimg_conv2d_dgrad_workspace(const AcimgConvDesc* d) {
     if (d->stride > 1)   // zero-inserted copy of gy, then the stride-1 path
         return dilated_bytes(d->N, d->OH, d->OW, ca, d->stride) +
                igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * d->S * cdiv(ca, 32)) +
-               igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * cdiv(d->S * ca, 32));
+               igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * cdiv(d->S * ca, 32)) +
+               (ca <= 16 && d->C <= 32 ? direct_ws_bytes(d->R, d->S, ca, (d->C + 7) & ~7) : 0);
     // rowrun depends on ldgy, unknown here: per-tap kiters is the larger bound for splits
     return igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * d->S * cdiv(ca, 32)) +
-           igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * cdiv(d->S * ca, 32));
+           igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * cdiv(d->S * ca, 32)) +
+           (ca <= 16 && d->C <= 32 ? direct_ws_bytes(d->R, d->S, ca, (d->C + 7) & ~7) : 0);
 }
 
 int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
@@ -835,7 +850,7 @@ int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
         q.w = w; q.ldw = d->ldw; q.mode = 1; q.wrows = d->C; q.act = ACIMG_ACT_NONE;
         q.res = residual; q.ldres = ldres;
         q.M = (long)d->N * d->H * d->W;
-        return launch_direct(q, (hipStream_t)stream);
+        return launch_direct(q, ws, ws_bytes, (hipStream_t)stream);
     }
     if (d->stride == 1) {
         // dx[h,w,c] = sum_{r',s',k} gy[h-(R-1-pt)+r', w-(S-1-pl)+s', k] * W[R-1-r'][S-1-s'][c][k]
