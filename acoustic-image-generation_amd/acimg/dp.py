@@ -41,7 +41,10 @@ class GradComm(object):
         self.flat = flat_grad
         self.buckets = [(int(a), int(b)) for a, b, *_ in buckets]
         self.group = group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # ACIMG_DP_FORCE=1 keeps the exchange on at world size 1 (rehearses the RCCL path on a one-GPU box)
+        import os
+        force = os.environ.get("ACIMG_DP_FORCE") == "1"
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.cuda = flat_grad.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grad.device) if (self.cuda and self.enabled) else None

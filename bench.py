@@ -149,7 +149,8 @@ def main():
                              % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dp = os.environ.get("ACIMG_DP_FORCE") == "1" and "RANK" in os.environ   # one-rank RCCL rehearsal
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -169,7 +170,7 @@ def main():
     g = tr._build_functions(batch_size=B)
     tr.modelimages.initialize(seed=1238)
     tr.modelac.initialize(seed=1239)
-    if world > 1:
+    if world > 1 or force_dp:
         tr.enable_data_parallel()
     # synthetic inputs, resident in HBM before the timed region (seed differs per rank)
     gen = torch.Generator().manual_seed(1234 + rank)
@@ -260,7 +261,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
 
