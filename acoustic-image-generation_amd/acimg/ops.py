@@ -284,9 +284,15 @@ def conv2d_dgrad_split3(plan, d, gy, ldgy, wsplit_t, dx, residual=None, ldres=0,
              int(lddx), residual, int(ldres), mask, int(ldmask))
 
 
-def conv2d_fwd_split3p(plan, d, x_planes, x_lo_off, wsplit, y, stats=None):
+def conv2d_fwd_split3p_workspace(d):
+    return int(_L().acimg_conv2d_fwd_split3p_workspace(C.byref(d)))
+
+
+def conv2d_fwd_split3p(plan, d, x_planes, x_lo_off, wsplit, y, stats=None, tail_ws=None):
+    """tail_ws: a uint8 buffer DEDICATED to split3p calls (tickets in its first 4 KiB must start, and stay, zero)"""
+    nbytes = 0 if tail_ws is None else (tail_ws.numel() * tail_ws.element_size() if hasattr(tail_ws, "numel") else 0)
     plan.add("conv2d_fwd_split3p", _L().acimg_conv2d_fwd_split3p, C.byref(d), x_planes, int(x_lo_off), wsplit, y,
-             stats)
+             stats, tail_ws, int(nbytes))
 
 
 def bn_relu_split(plan, x, scale, shift, relu, out, lo_off, rows, Cn):

@@ -258,8 +258,13 @@ class ResNet50Model(object):
             ops.conv2d_split3_prepare(self.plan_prepare, d, P(scope + "/weights"),
                                       ops.LazyPtr(lambda off=off: self.wsplit[off:]))
         off = self._sp3[scope]
+        if getattr(self, "_tail_ws", None) is None:
+            # partial sums + tile tickets of the trunk kernel's tail split; used by nothing else, zero at start
+            self._tail_ws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8,
+                                        device=self.session.device)
         ops.conv2d_fwd_split3p(plan, d, xplanes, self._lo_off(self.N * hw[0] * hw[1], cin),
-                               ops.LazyPtr(lambda off=off: self.wsplit[off:]), out, stats if training else None)
+                               ops.LazyPtr(lambda off=off: self.wsplit[off:]), out, stats if training else None,
+                               tail_ws=self._tail_ws)
         if not hasattr(self, "_aff_cache"):
             self._aff_cache = {}
         if scope not in self._aff_cache:

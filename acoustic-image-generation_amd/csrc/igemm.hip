@@ -304,11 +304,11 @@ __global__ void colsum_final_kernel(const float* partial, int parts, int ncols, 
 // per-256-row-block column sums / sums of squares of y[M][K] (pixel stride ldy) -> stats[blk][2][ld]:
 // the batch-norm partials for convs that ran split-K (their epilogue never sees a full accumulator)
 __global__ __launch_bounds__(256) void partial_stats_kernel(const float* y, int ldy, int M, int K,
-                                                            float* stats, int ld) {
+                                                            float* stats, int ld, int rows_per_block) {
     __shared__ float red[2][8][32];
     const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int r0 = blockIdx.x * 256;
-    const int r1 = min(M, r0 + 256);
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
     for (int cb = 0; cb < K; cb += 32) {
         const int c = cb + cl;
         float s1 = 0.f, s2 = 0.f;
@@ -574,7 +574,7 @@ static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipSt
         rc = check_launch("igemm_splitk_reduce");
         if (!rc && stats_after) {
             hipLaunchKernelGGL(partial_stats_kernel, dim3(cdiv(p.M, 256)), dim3(256), 0, st, e.Y, e.ldy, p.M,
-                               e.Nstore, stats_after, e.stats_ld);
+                               e.Nstore, stats_after, e.stats_ld, 256);
             rc = check_launch("partial_stats");
         }
     }
@@ -728,13 +728,14 @@ static int fwd_kiters(const AcimgConvDesc* d) {
     return (rowrun ? d->R : d->R * d->S) * cdiv(L, 32);
 }
 
-int acimg_conv2d_stats_rows(const AcimgConvDesc* d) {
+// rows of y covered by one statistics partial: the implicit-GEMM tile height, or 256 after split-K
+static int stats_block_rows(const AcimgConvDesc* d) {
     const int M = d->N * d->OH * d->OW;
     TileCfg c = pick_cfg(M, d->K);
-    // upper bound over the paths acimg_conv2d_fwd may take (direct few-channel conv and split-K: 256-row partials;
-    // unused rows stay zero and add nothing in acimg_bn_finalize)
-    const int r256 = cdiv(M, 256), rt = cdiv(M, c.bm);
-    return r256 > rt ? r256 : rt;
+    return pick_splits(M, d->K, c, fwd_kiters(d)) > 1 ? 256 : c.bm;
+}
+int acimg_conv2d_stats_rows(const AcimgConvDesc* d) {
+    return cdiv((long)d->N * d->OH * d->OW, stats_block_rows(d));
 }
 
 int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
@@ -768,9 +769,9 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
         q.w = w; q.ldw = d->ldw; q.mode = 0; q.wrows = d->C; q.bias = bias; q.act = d->act;
         q.M = (long)d->N * d->OH * d->OW;
         rc = launch_direct(q, ws, ws_bytes, (hipStream_t)stream);
-        if (!rc && stats) {   // batch-norm partials of y = conv + bias, as after a split-K conv
-            hipLaunchKernelGGL(partial_stats_kernel, dim3(cdiv(q.M, 256)), dim3(256), 0, (hipStream_t)stream, y, d->ldy,
-                               (int)q.M, d->K, stats, d->ldw);
+        if (!rc && stats) {   // batch-norm partials of y = conv + bias, in acimg_conv2d_stats_rows(d) row blocks
+            hipLaunchKernelGGL(partial_stats_kernel, dim3(acimg_conv2d_stats_rows(d)), dim3(256), 0, (hipStream_t)stream,
+                               y, d->ldy, (int)q.M, d->K, stats, d->ldw, stats_block_rows(d));
             rc = check_launch("partial_stats");
         }
         return rc;
@@ -1135,8 +1136,57 @@ int acimg_conv2d_dgrad_split3(const AcimgConvDesc* d, const float* gy, int ldgy,
     return launch_split3<SplitBF16>(p, (hipStream_t)stream);
 }
 
+// ---- tail split of the trunk kernel: which tiles to cut, and into how many K ranges ------------------------
+struct TailPlan { int whole, s, rem; };
+static int resident_slots(int which, const void* fn, int threads, size_t lds) {
+    static int cache[3] = {0, 0, 0};
+    if (!cache[which]) {
+        int dev = 0, ncu = 0, per = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, threads, lds) != hipSuccess || ncu <= 0 || per <= 0) {
+            (void)hipGetLastError();
+            ncu = 256;                    // MI355X; no device (CPU-side sizing queries): same answer
+            per = which == 0 ? 2 : 3;
+        }
+        cache[which] = ncu * per;
+    }
+    return cache[which];
+}
+static TailPlan pick_tail(int T, int P, int KI, int max_units) {
+    const int rem = T % P;
+    TailPlan best{T, 1, 0};
+    if (rem == 0 || getenv("ACIMG_NO_TAIL_SPLIT")) return best;
+    if (const char* f = getenv("ACIMG_TAIL_S")) {   // experiments only: force the number of K ranges
+        const int s = atoi(f);
+        if (s > 1 && KI / s >= 1 && (long)rem * s <= max_units) return TailPlan{T - rem, s, rem};
+        return best;
+    }
+    // cost in K steps of the last round: whole tiles = KI; s ranges = rounds(rem*s) * ceil(KI/s) + hand-off
+    double best_cost = KI;
+    static const int cand[] = {2, 3, 4, 6, 8, 12, 16};
+    for (int s : cand) {
+        if (KI / s < 2 || (long)rem * s > max_units) break;
+        // hand-off calibrated on the trunk shapes (tools/tune_dma.py): partial store + ticket + the last arriver's
+        // s x 64 KiB of sc1 loads cost about 8 + s K steps, so 1x1 layers with few K steps are left whole
+        const double cost = (double)cdiv((long)rem * s, P) * cdiv(KI, s) + 8.0 + 1.0 * s;
+        if (cost < 0.9 * best_cost) {
+            best_cost = cost;
+            best = TailPlan{T - rem, s, rem};
+        }
+    }
+    return best;
+}
+static constexpr int TS_MAX_UNITS = 1024;      // partial slots (64 KiB each for a 128x128 tile)
+static constexpr size_t TS_COUNTER_BYTES = 4096;
+
+size_t acimg_conv2d_fwd_split3p_workspace(const AcimgConvDesc* d) {
+    (void)d;
+    return TS_COUNTER_BYTES + (size_t)TS_MAX_UNITS * 128 * 128 * sizeof(float);
+}
+
 int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
-                             float* y, float* stats, void* stream) {
+                             float* y, float* stats, void* ws, size_t ws_bytes, void* stream) {
     int rc = check_desc(d, "conv2d_fwd_split3p");
     if (rc) return rc;
     if (d->C % 32) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: C=%d must be a multiple of 32", d->C);
@@ -1168,11 +1218,22 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
     p.ras_tiles_n = cdiv(d->K, c.bn);
     p.ras_gn = std::min(p.ras_tiles_n, 8);
     p.ras_gm = std::max(1, 64 / p.ras_gn);
-    const dim3 grid(p.ras_tiles_m * p.ras_tiles_n);
     const size_t lds_bytes = (size_t)2 * 2 * (c.bm + c.bn) * 64;   // 2 stages x (hi, lo) x 64-byte rows
-    if (c.bm == 128 && c.bn == 128)
+    const int T = p.ras_tiles_m * p.ras_tiles_n;
+    const int which = (c.bm == 128 && c.bn == 128) ? 0 : (c.bm == 64 ? 1 : 2);
+    const void* fn = which == 0 ? (const void*)igemm_split3d_kernel<128, 128, 2, 4, 512, 2, 2>
+                   : which == 1 ? (const void*)igemm_split3d_kernel<64, 128, 1, 4, 256, 2, 2>
+                                : (const void*)igemm_split3d_kernel<128, 64, 2, 2, 256, 2, 2>;
+    TailPlan tp{T, 1, 0};
+    if (ws && ws_bytes >= acimg_conv2d_fwd_split3p_workspace(d) && which == 0)
+        tp = pick_tail(T, resident_slots(which, fn, 512, lds_bytes), p.kiters, TS_MAX_UNITS);
+    p.ts_whole = tp.whole; p.ts_s = tp.s;
+    p.ts_counters = static_cast<int*>(ws);
+    p.ts_partial = ws ? reinterpret_cast<float*>(static_cast<char*>(ws) + TS_COUNTER_BYTES) : nullptr;
+    const dim3 grid(tp.whole + tp.rem * tp.s);
+    if (which == 0)
         hipLaunchKernelGGL((igemm_split3d_kernel<128, 128, 2, 4, 512, 2, 2>), grid, dim3(512), lds_bytes, st, p);
-    else if (c.bm == 64 && c.bn == 128)
+    else if (which == 1)
         hipLaunchKernelGGL((igemm_split3d_kernel<64, 128, 1, 4, 256, 2, 2>), grid, dim3(256), lds_bytes, st, p);
     else
         hipLaunchKernelGGL((igemm_split3d_kernel<128, 64, 2, 2, 256, 2, 2>), grid, dim3(256), lds_bytes, st, p);

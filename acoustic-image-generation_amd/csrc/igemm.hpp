@@ -56,6 +56,11 @@ struct IgemmParams {
     // (bands of ras_gm row tiles) x (groups of ras_gn column tiles) x (rows) x (columns), so the ~64 tiles
     // resident on an XCD at a time form a ras_gm x ras_gn rectangle that shares A and B tiles through its L2
     int ras_tiles_m, ras_tiles_n, ras_gm, ras_gn;
+    // tail split of igemm_split3d_kernel: workgroups >= ts_whole handle one of ts_s K ranges of a tile of the
+    // last partial round; partial sums in ts_partial[tile - ts_whole][range][BM*BN], tickets in ts_counters
+    int ts_whole, ts_s;
+    float* ts_partial;
+    int* ts_counters;
     // split-K
     int splits;
     float* slab;  // [splits][M][slab_ld]

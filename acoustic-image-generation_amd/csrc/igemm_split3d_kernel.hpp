@@ -87,8 +87,18 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
     const int li = lane & 15, g = lane >> 4;
+    // Tail split (p.ts_s > 1): workgroups [0, ts_whole) own whole tiles; the tiles of the last, partial round are
+    // cut into ts_s K ranges each, so that round costs kiters / ts_s steps instead of idling most of the chip
+    // for kiters steps.  Ranges of one tile meet in the workspace: see the end of the kernel.
+    int vt = blockIdx.x, chunk = 0;
+    if (p.ts_s > 1 && (int)blockIdx.x >= p.ts_whole) {
+        const int u = blockIdx.x - p.ts_whole;
+        vt = p.ts_whole + u / p.ts_s;
+        chunk = u - (u / p.ts_s) * p.ts_s;
+    }
+    const bool split = p.ts_s > 1 && vt >= p.ts_whole;
     int mt, nt;
-    raster_tile(p, blockIdx.x, mt, nt);
+    raster_tile(p, vt, mt, nt);
     const int m0 = mt * BM, n0 = nt * BN;
 
     const __amdgpu_buffer_rsrc_t rsA =
@@ -96,7 +106,12 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
     const __amdgpu_buffer_rsrc_t rsB =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
 
-    const int it_end = p.kiters;
+    int it_begin = 0, it_end = p.kiters;
+    if (split) {                                   // balanced K ranges: the first (kiters % s) get one step more
+        const int base = p.kiters / p.ts_s, extra = p.kiters - base * p.ts_s;
+        it_begin = chunk * base + min(chunk, extra);
+        it_end = it_begin + base + (chunk < extra ? 1 : 0);
+    }
     const int Ktot = p.ntaps * p.C;
 
     // ---- this lane's slot in a piece: tile row (lane>>2) of the 16-row block, physical chunk (lane&3) -------
@@ -135,8 +150,15 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
     const unsigned b_lo_off = (unsigned)((long)p.Nld * Ktot * 2);
 
     // request cursors: A walks (tap row, tap column, channel chunk); B's k offset is linear in the step
-    int qa = 0, sa = 0, st_r = 0, st_s = 0, st_c0 = 0;     // next A tile to request, its LDS slot
-    int qb = 0, sb = 0;
+    int qa = it_begin, sa = 0, st_r = 0, st_s = 0, st_c0 = 0;     // next A tile to request, its LDS slot
+    int qb = it_begin, sb = 0;
+    if (it_begin > 0) {
+        const int cpk = p.C / BK;
+        const int tap = it_begin / cpk;
+        st_c0 = (it_begin - tap * cpk) * BK;
+        st_r = tap / p.S;
+        st_s = tap - st_r * p.S;
+    }
 
     auto issue_a = [&]() {
         char* st = lds + sa * (2 * A_BYTES);
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
     }
 
     int ca = 0, cb = 0;                 // LDS slots of the tile being multiplied
-    for (int it = 0; it < it_end; ++it) {
+    for (int it = it_begin; it < it_end; ++it) {
         // oldest-first the queue holds ... B(it) A(it+NSA-NSB) | B(it+1) A(..) ...: everything up to B(it) must
         // have landed, INFLIGHT younger pieces may stay in flight; near the tail fewer exist -> drain
         if (it + NSA - 1 <= it_end) wait_vmcnt<INFLIGHT>();
@@ -247,6 +269,51 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] *= SPLIT3_OUTSCALE;
+    if (split) {
+        // every range parks its partial sums (write-through sc1 stores: visible to the other XCDs without an L2
+        // write-back fence) and takes a ticket; the last arriver adds the ts_s partials IN RANGE ORDER (its own
+        // included, from memory: the result does not depend on who came last) and runs the epilogue.  Nobody waits.
+        const int tl = vt - p.ts_whole;
+        float* const slot0 = p.ts_partial + (long)tl * p.ts_s * (BM * BN);
+        const __amdgpu_buffer_rsrc_t rsP =
+            __builtin_amdgcn_make_buffer_rsrc(slot0 + (long)chunk * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsP,
+                                                       ((i * TN + j) * NTHR + tid) * 16, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* const flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const int ticket = __hip_atomic_fetch_add(p.ts_counters + tl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == p.ts_s - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.ts_counters + tl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        __syncthreads();                           // everyone has read the flag before the LDS is reused below
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < p.ts_s; ++c) {
+            const __amdgpu_buffer_rsrc_t rsQ =
+                __builtin_amdgcn_make_buffer_rsrc(slot0 + (long)c * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)     // sc1 loads: never a stale L1 / L2 copy
+                    acc[i][j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                               rsQ, ((i * TN + j) * NTHR + tid) * 16, 0, 16));
+        }
+    }
     igemm_epilogue<BM, BN, WGM, WGN, NTHR, TM, TN>(p, acc, smem, m0, n0, wm, wn, li, g, tid, mt);
 }
 

@@ -114,8 +114,13 @@ int acimg_conv2d_dgrad_split3(const AcimgConvDesc* d, const float* gy, int ldgy,
  *   acimg_bn_add_relu_split:     planes (+ optional fp32) = relu(a*sa+ta + shortcut); shortcut = b32*sb+tb
  *                                (projection) or the previous unit's planes (identity / subsample)   (resnet50.py:104-123)
  *   acimg_bn_relu_maxpool_split: planes = maxpool3x3/s2(relu(x*scale+shift))                        (resnet50.py:207-208) */
+/* `ws` (optional, acimg_conv2d_fwd_split3p_workspace bytes, DEDICATED to these calls: its first 4 KiB are tile
+ * tickets that must be zero before the first call and are left zero by every call) lets the kernel cut the tiles of
+ * the last, partially filled round of workgroups into K ranges that meet in the workspace (deterministic: fixed
+ * range order).  Without it every tile is computed by one workgroup. */
+size_t acimg_conv2d_fwd_split3p_workspace(const AcimgConvDesc* d);
 int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
-                             float* y, float* stats, void* stream);
+                             float* y, float* stats, void* ws, size_t ws_bytes, void* stream);
 int acimg_bn_relu_split(const float* x, const float* scale, const float* shift, int relu, void* out,
                         size_t lo_off, long rows, int C, void* stream);
 int acimg_bn_add_relu_split(const float* a, const float* sa, const float* ta, const float* b32,

@@ -294,8 +294,9 @@ def unsplit(planes, lo_off, rows, Cc):
     return ((hi + lo) * 4.0).reshape(rows, Cc).cpu()
 
 
-@pytest.mark.parametrize("case", SPLIT3_CASES[:4])
-def test_presplit_activation_path(device, case):
+@pytest.mark.parametrize("tail", [False, True])
+@pytest.mark.parametrize("case", SPLIT3_CASES[:4] + [(8, 56, 75, 128, 128, 3, 3, 1, "SAME")])
+def test_presplit_activation_path(device, case, tail):
     """pre-split activation format: bn_relu_split producer + split3p conv (with statistics) vs fp64, and
     the planes themselves vs the values they encode (22 mantissa bits: 5e-7 relative to max)"""
     from acimg import ops
@@ -321,9 +322,18 @@ def test_presplit_activation_path(device, case):
     y = torch.full((N, OH, OW, K), 7.0, device=device)
     srows = ops.conv2d_fwd_split3_stats_rows(d)
     stats = torch.zeros(srows, 2, K, device=device)
-    ops.conv2d_fwd_split3p(plan, d, planes, lo_off, wsplit, y, stats)
+    # tail=True: the tiles of the last partial round of workgroups are cut into K ranges (partials + tickets in a
+    # dedicated workspace); run twice — the tickets must be back at zero, and the result must not change at all
+    tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=device) if tail else None
+    ops.conv2d_fwd_split3p(plan, d, planes, lo_off, wsplit, y, stats, tail_ws=tws)
     torch.cuda.synchronize()
     close(y, ref, tol=2e-6, what="split3p conv %s" % (case,))
+    if tail:
+        assert int(tws[:4096].view(torch.int32).abs().sum()) == 0
+        y2 = torch.full_like(y, 3.0)
+        ops.conv2d_fwd_split3p(plan, d, planes, lo_off, wsplit, y2, stats, tail_ws=tws)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y2), "tail split must be deterministic"
     flat = ref.reshape(-1, K)
     close(stats[:, 0].sum(0), flat.sum(0), tol=2e-4, what="split3p stats sum")
     close(stats[:, 1].sum(0), (flat * flat).sum(0), tol=2e-4, what="split3p stats sumsq")

@@ -28,11 +28,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         ops.conv2d_split3_prepare(plan, d, w, wsplit)
         y = torch.empty(N, d.OH, d.OW, K, device=dev)
         stats = torch.zeros(4096*2*K, device=dev)
-        for _ in range(3): ops.conv2d_fwd_split3p(plan, d, planes, lo, wsplit, y, stats)
+        tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=dev)
+        for _ in range(3): ops.conv2d_fwd_split3p(plan, d, planes, lo, wsplit, y, stats, tail_ws=tws)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(10): ops.conv2d_fwd_split3p(plan, d, planes, lo, wsplit, y, stats)
+        for _ in range(10): ops.conv2d_fwd_split3p(plan, d, planes, lo, wsplit, y, stats, tail_ws=tws)
         e1.record(); torch.cuda.synchronize()
         res["%dx%d %d->%d %dx%d/%d" % (H,W,C,K,R,R,s)] = (e0.elapsed_time(e1) / 10 * 1e3, float(y.double().abs().sum().item()))
     print(json.dumps(res))
