@@ -46,11 +46,26 @@ class UNetVAE(object):
     DEC = None
     COUT = None
 
-    def __init__(self, input_shape=None):
+    def __init__(self, input_shape=None, precision="split"):
+        """precision: "split" = layers with >= 32 channels on both sides run on the split-MFMA kernels (forward
+        f16x3, gradients bf16x3: fp32-class results at 5x the fp32-MFMA rate), "f32" = exact-f32 MFMA everywhere"""
+        assert precision in ("split", "f32")
+        self.precision = precision
         self.scope = self.SCOPE
         self.height, self.width, self.channels = input_shape
         assert self.channels == self.CIN
         self.session = None
+        self._wsplit_bufs = {}
+
+    def _use_split(self, d):
+        return (self.precision == "split" and d.stride == 1 and d.C % 32 == 0 and d.K % 32 == 0 and
+                d.N * d.OH * d.OW >= 16384)
+
+    def _wsplit(self, name, nbytes, kind):
+        key = (name, kind)
+        if key not in self._wsplit_bufs:
+            self._wsplit_bufs[key] = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.session.device)
+        return self._wsplit_bufs[key]
 
     # ---- variables --------------------------------------------------------------------------------------
     def _layer_table(self):
@@ -226,8 +241,16 @@ class UNetVAE(object):
         L.rows = ops.conv2d_stats_rows(L.d)
         L.stats = z(L.rows, 2, kp)
         L.scale, L.shift, L.save_mean, L.save_invstd = z(kp), z(kp), z(kp), z(kp)
-        ops.conv2d_fwd(plan, L.d, x.ptr, self._P(name + "/kernel"), self._P(name + "/bias"), L.raw.ptr,
-                       stats=L.stats if self.training else None)
+        if self._use_split(L.d):
+            L.rows = ops.conv2d_fwd_split3_stats_rows(L.d)
+            L.stats = z(L.rows, 2, kp)
+            ws = self._wsplit(name, ops.conv2d_split3_weight_bytes(L.d), "fwd")
+            ops.conv2d_split3_prepare(plan, L.d, self._P(name + "/kernel"), ws)     # the kernel changes every step
+            ops.conv2d_fwd_split3(plan, L.d, x.ptr, ws, L.raw.ptr, stats=L.stats if self.training else None,
+                                  bias=self._P(name + "/bias"))
+        else:
+            ops.conv2d_fwd(plan, L.d, x.ptr, self._P(name + "/kernel"), self._P(name + "/bias"), L.raw.ptr,
+                           stats=L.stats if self.training else None)
         ops.bn_finalize(plan, L.stats if self.training else None, L.rows if self.training else 0, K, kp,
                         out.pixels if self.training else 0, self._P(bn + "/gamma"), self._P(bn + "/beta"),
                         self._P(bn + "/moving_mean"), self._P(bn + "/moving_variance"), L.scale, L.shift,
@@ -328,8 +351,15 @@ class UNetVAE(object):
             ops.bn_bwd(plan, L.raw.ptr, L.raw.ld, gy.ptr, gy.ld, L.scale, L.shift, L.save_mean, L.save_invstd,
                        self._P(L.bn + "/gamma"), L.y.pixels, up4(K), gy.ptr, gy.ld, self._G(L.bn + "/gamma"),
                        self._G(L.bn + "/beta"))
-            ops.conv2d_wgrad(plan, L.d, L.x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
-            if dx is not None:
+            wg = ops.conv2d_wgrad_split3 if (self._use_split(L.d) and K % 64 == 0) else ops.conv2d_wgrad
+            wg(plan, L.d, L.x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
+            if dx is not None and self._use_split(L.d):
+                wt = self._wsplit(name, ops.conv2d_split3_dgrad_weight_bytes(L.d), "dgrad")
+                ops.conv2d_split3_prepare_dgrad(plan, L.d, self._P(name + "/kernel"), wt)
+                ops.conv2d_dgrad_split3(plan, L.d, gy.ptr, gy.ld, wt, dx.ptr,
+                                        res.ptr if res is not None else None, res.ld if res is not None else 0,
+                                        None, 0, lddx=dx.ld)
+            elif dx is not None:
                 ops.conv2d_dgrad(plan, L.d, gy.ptr, gy.ld, self._P(name + "/kernel"), dx.ptr,
                                  res.ptr if res is not None else None, res.ld if res is not None else 0,
                                  None, 0, lddx=dx.ld)
@@ -399,8 +429,8 @@ class UNet(UNetVAE):
            ("4", 64, (2, 3), "VALID"), ("5", 128, None, None)]
     DEC = [("6", 64, (2, 3), "4"), ("7", 32, (2, 2), "3"), ("8", 32, (2, 3), "2"), ("9", 8, (2, 2), "1")]
 
-    def __init__(self, input_shape=None):
-        super(UNet, self).__init__(input_shape or [224, 298, 3])
+    def __init__(self, input_shape=None, precision="split"):
+        super(UNet, self).__init__(input_shape or [224, 298, 3], precision)
 
 
 class UNetSound(UNetVAE):
@@ -410,5 +440,5 @@ class UNetSound(UNetVAE):
            ("4", 64, (3, 3), "SAME"), ("5", 128, None, None)]
     DEC = [("6", 64, (2, 2), "4"), ("7", 32, (2, 2), "3"), ("8", 8, (3, 2), "2"), ("9", 8, (3, 3), "1")]
 
-    def __init__(self, input_shape=None):
-        super(UNetSound, self).__init__(input_shape or [99, 257, 1])
+    def __init__(self, input_shape=None, precision="split"):
+        super(UNetSound, self).__init__(input_shape or [99, 257, 1], precision)

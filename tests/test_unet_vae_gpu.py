@@ -20,8 +20,8 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("model", ["UNet", "UNetSound"])
-def test_unet_vae_train_step(model):
+@pytest.mark.parametrize("model,precision", [("UNet", "split"), ("UNetSound", "split"), ("UNetSound", "f32")])
+def test_unet_vae_train_step(model, precision):
     from acimg.session import Session
     from acimg.trainer_vae import TrainerVAE
     from acimg import unet_vae
@@ -32,7 +32,7 @@ def test_unet_vae_train_step(model):
     N = 2
     cls = getattr(unet_vae, model)
     sess = Session(dev)
-    tr = TrainerVAE(cls(), learning_rate=1e-3, session=sess)
+    tr = TrainerVAE(cls(precision=precision), learning_rate=1e-3, session=sess)
     g = tr._build_functions(batch_size=N)
     # same parameters on both sides; biases / gamma / beta randomised so those paths carry signal
     params = ouv.init_params(model, seed=7, dtype=torch.float64, bias_std=0.05, bn_jitter=0.1)
