@@ -698,6 +698,32 @@ def test_error_reporting(device):
     with pytest.raises(_lib.AcimgError) as ei:
         ops.conv2d_fwd(ops.Plan(device, eager=True), d, x, w, None, y)
     assert "multiples of 4" in str(ei.value)
+    L = _lib.load()
+    import ctypes as C
+    st = ops.current_stream_handle(device)
+    # a workspace that is too small is refused, not overrun (general-stride data gradient needs the dilated copy)
+    d2 = ops.conv_desc(1, 17, 23, 8, 8, 3, 3, 2, "SAME")
+    gy = torch.zeros(1, d2.OH, d2.OW, 8, device=device)
+    w2 = torch.zeros(3, 3, 8, 8, device=device)
+    dx = torch.zeros(1, 17, 23, 8, device=device)
+    tiny = torch.zeros(64, device=device)
+    rc = L.acimg_conv2d_dgrad(C.byref(d2), gy.data_ptr(), 8, w2.data_ptr(), dx.data_ptr(), 8, None, 0, None, 0,
+                              tiny.data_ptr(), 256, st)
+    assert rc == -2 and "workspace" in _lib.last_error()
+    # transposed conv: kernel > stride needs the matching TF output size
+    d3 = ops.deconv_desc(1, 5, 6, 8, 8, 3, 3, 2)
+    d3.OH = 10
+    rc = L.acimg_deconv_fwd(C.byref(d3), dx.data_ptr(), w2.data_ptr(), None, dx.data_ptr(), tiny.data_ptr(), 256, st)
+    assert rc == -1 and "OH" in _lib.last_error()
+    # batch-norm backward: channel count not a multiple of 4; clip cross-entropy: too many classes
+    rc = L.acimg_bn_bwd(dx.data_ptr(), 6, dx.data_ptr(), 6, None, None, None, None, None, 10, 6, dx.data_ptr(), 6,
+                        None, None, tiny.data_ptr(), 256, st)
+    assert rc == -1
+    rc = L.acimg_clip_softmax_ce(dx.data_ptr(), 100, 1, 12, 100, None, None, None, 0, st)
+    assert rc == -1 and "classes" in _lib.last_error()
+    rc = L.acimg_maxpool_fwd(dx.data_ptr(), 8, dx.data_ptr(), 8, 1, 2, 2, 8, 3, st)
+    assert rc == -1
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("case", [(2, 200, 180, 8, 8, 3, 3, 1, "SAME"), (2, 190, 200, 4, 8, 3, 3, 1, "SAME"),
