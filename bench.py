@@ -239,7 +239,11 @@ def main():
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "mfma_dtype": "f16 (3-term hi/lo split of fp32 operands, fp32 accumulate)" if f16 else "f32",
                 "hw_flop_factor": 3 if f16 else 1,
-                "traffic": None, "launches_per_step": len(probe_idx),
+                # HBM bytes per launch of this kernel from the PMC pass committed under profiles/ (FETCH_SIZE x2 per
+                # the gfx950 correction + WRITE_SIZE, batch 32, f16x3): not re-measured by this run
+                "traffic": 252.5e6 if (f16 and B == 32 and tile[:2] == (128, 128)) else None,
+                "traffic_source": "profiles/r01/hbm_traffic_v7.txt" if (f16 and B == 32 and tile[:2] == (128, 128)) else None,
+                "launches_per_step": len(probe_idx),
                 "avg_launch_ms": ms / len(events), "avg_launch_gflop": fl / len(events) / 1e9,
                 "share_of_step_time": (ms / args.steps) / (dt / args.steps * 1e3)}
 
