@@ -52,6 +52,7 @@ def parse():
                          "single-modality U-Net VAEs of configs[1] / [0]; classifier: DualCamNet on generated images, "
                          "configs[4]'s head")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] (UNet RGB VAE) side measurement")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
@@ -72,6 +73,27 @@ def cpu_baseline(args):
     return {"value": args.cpu_batch * args.cpu_steps / dt, "unit": "images/s", "cores": n, "kind": "port",
             "sample": "CPU oracle (PyTorch fp32 restatement of the TF-1 graph; TF-1 unavailable offline): "
                       "same train step, batch %d, %d timed steps after 1 warm-up" % (args.cpu_batch, args.cpu_steps)}
+
+
+def secondary_unet_rgb(args):
+    from acimg.session import Session
+    from acimg.trainer_vae import TrainerVAE
+    from acimg.unet_vae import UNet
+    dev = torch.device("cuda", torch.cuda.current_device())
+    tr = TrainerVAE(UNet(), learning_rate=1e-4, session=Session(dev))
+    g = tr._build_functions(batch_size=32)
+    tr.model.initialize(seed=1240)
+    g.images.copy_(torch.rand(*g.images.shape, generator=torch.Generator().manual_seed(1234)))
+    for _ in range(3):
+        tr.train_step(sync=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        tr.train_step(sync=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    return {"workload": "BASELINE configs[1]: UNet RGB VAE train step (models/unet_architecture.py + trainer/trainer.py), "
+                        "224x298x3, batch 32", "value": 32 / dt, "unit": "images/s", "ms_per_step": dt * 1e3, "dtype": "f32"}
 
 
 def other_workload(args):
@@ -264,6 +286,12 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
+        if world == 1 and not args.no_secondary:
+            # BASELINE configs[1] (the RGB U-Net VAE at batch 32) timed next to the north-star path, for reference
+            try:
+                out["secondary"] = secondary_unet_rgb(args)
+            except Exception as e:   # never lose the primary line
+                out["secondary"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1 or force_dp:
         dist.barrier()
