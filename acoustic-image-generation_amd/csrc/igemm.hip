@@ -1218,7 +1218,9 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
     p.ras_tiles_n = cdiv(d->K, c.bn);
     p.ras_gn = std::min(p.ras_tiles_n, 8);
     p.ras_gm = std::max(1, 64 / p.ras_gn);
-    const size_t lds_bytes = (size_t)2 * 2 * (c.bm + c.bn) * 64;   // 2 stages x (hi, lo) x 64-byte rows
+    // 2 stages x (hi, lo) x 64-byte rows; the epilogue restages the fp32 output tile there (+ 2 x WGM x BN floats
+    // of statistics scratch behind it)
+    const size_t lds_bytes = std::max((size_t)2 * 2 * (c.bm + c.bn) * 64, (size_t)c.bm * c.bn * 4) + 4 * 2 * c.bn * 4;
     const int T = p.ras_tiles_m * p.ras_tiles_n;
     const int which = (c.bm == 128 && c.bn == 128) ? 0 : (c.bm == 64 ? 1 : 2);
     const void* fn = which == 0 ? (const void*)igemm_split3d_kernel<128, 128, 2, 4, 512, 2, 2>

@@ -89,7 +89,7 @@ __device__ __forceinline__ void epi_store4(const EpiParams& e, long opix, int cn
 template <int BM, int BN, int WGM, int WGN, int NTHR, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[TM][TN], float* smem, int m0,
                                                int n0, int wm, int wn, int li, int g, int tid,
-                                               int stat_row = -1) {
+                                               int stat_row = -1, bool stats_only = false) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     if (stat_row < 0) stat_row = blockIdx.x;
     if (p.splits > 1) {
@@ -116,7 +116,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WTM + i * 16 + li;
-        if (m >= e.M) continue;
+        if (m >= e.M || stats_only) continue;
         const long rp = epi_row_pix(e, m);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
