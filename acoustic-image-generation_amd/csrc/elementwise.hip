@@ -1045,7 +1045,7 @@ int acimg_clip_softmax_ce(const float* logits, int ldl, int clips, int F, int K,
 
 size_t acimg_bn_bwd_workspace(long rows, int C) {
     long blocks = (rows + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
     return (size_t)(blocks + 1) * 2 * C * sizeof(float);
 }
@@ -1058,7 +1058,7 @@ int acimg_bn_bwd(const float* x, int ldx, const float* gy, int ldgy, const float
         return fail(ACIMG_EINVAL, "bn_bwd: C=%d must be a multiple of 4 (<= 1024), buffers 16-byte aligned", C);
     if (ws_bytes < acimg_bn_bwd_workspace(rows, C) || !ws) return fail(ACIMG_EWORKSPACE, "bn_bwd: workspace too small");
     long blocks = (rows + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 256) blocks = 256;       // one workgroup per CU; the finalize pass walks the partials 8 at a time
     if (blocks < 1) blocks = 1;
     const long rpb = (rows + blocks - 1) / blocks;
     float* partial = static_cast<float*>(ws);

@@ -293,12 +293,17 @@ __global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* G, long
         for (int k = 0; k < 4; ++k) partial[(long)blockIdx.x * ncols + threadIdx.x * 4 + k] = t[k];
     }
 }
-__global__ void colsum_final_kernel(const float* partial, int parts, int ncols, float* out) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols) return;
+// 256 threads = 4 part groups x 64 columns, fixed-order combine
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int parts, int ncols, float* out) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int i = 0; i < parts; ++i) s += partial[(long)i * ncols + col];
-    out[col] = s;
+    if (col < ncols)
+        for (int i = pg; i < parts; i += 4) s += partial[(long)i * ncols + col];
+    red[pg][cl] = s;
+    __syncthreads();
+    if (pg == 0 && col < ncols) out[col] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 // per-256-row-block column sums / sums of squares of y[M][K] (pixel stride ldy) -> stats[blk][2][ld]:
@@ -678,7 +683,7 @@ static int launch_colsum(const float* G, long rows, int ncols, int ld, float* ou
     else
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(ncols, 64), parts), dim3(256), 0, st, G, rows,
                            ncols, ld, rpb, partial);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(ncols, 64)), dim3(64), 0, st, partial, parts, ncols, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(ncols, 64)), dim3(256), 0, st, partial, parts, ncols, out);
     return check_launch("colsum");
 }
 static size_t colsum_ws_bytes(int ncols) { return (size_t)256 * ncols * sizeof(float); }
