@@ -351,7 +351,7 @@ class UNetVAE(object):
             ops.bn_bwd(plan, L.raw.ptr, L.raw.ld, gy.ptr, gy.ld, L.scale, L.shift, L.save_mean, L.save_invstd,
                        self._P(L.bn + "/gamma"), L.y.pixels, up4(K), gy.ptr, gy.ld, self._G(L.bn + "/gamma"),
                        self._G(L.bn + "/beta"))
-            wg = ops.conv2d_wgrad_split3 if (self._use_split(L.d) and K % 64 == 0) else ops.conv2d_wgrad
+            wg = ops.conv2d_wgrad_split3 if self._use_split(L.d) else ops.conv2d_wgrad
             wg(plan, L.d, L.x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
             if dx is not None and self._use_split(L.d):
                 wt = self._wsplit(name, ops.conv2d_split3_dgrad_weight_bytes(L.d), "dgrad")
