@@ -62,10 +62,12 @@ class TrainerVAE(object):
         ops.zero(p, g.sums)
         p.extend(m.plan_fwd)
         ops.recon_loss(p, m.yhat.t, m.xpad.t, g.g_logit, g.sums, padded, ratio, ratio)
-        ops.sumsq(p, wreg, n, ops.Ptr(g.sums, 2))
+        if n > 0:
+            ops.sumsq(p, wreg, n, ops.Ptr(g.sums, 2))
         ops.loss_finalize(p, g.sums, m.kl, N, count, latent_w, 0.5 * m.WD, 1.0, 1.0, g.losses)
         m.record_backward(p, g.g_logit, latent_w / N)
-        ops.axpy(p, m.WD, wreg, greg, n)
+        if n > 0:
+            ops.axpy(p, m.WD, wreg, greg, n)
         g.plan_train = p
         sess.finalize()
         self.primary = g

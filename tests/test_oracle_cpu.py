@@ -232,3 +232,31 @@ def test_dualcamnet_oracle_and_host_graph():
     m.initialize()
     sd = m.state_dict_tf()
     assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+
+
+def test_unet_acoustic_oracle_and_host_graph():
+    """SURVEY A.3 last row: unet_noconc / unet_z, 9.32 M parameters; TF-named state of the HIP host model"""
+    from acimg.session import Session
+    from acimg.trainer_vae import TrainerVAE
+    from acimg.unet_acoustic import UNetAcNoConc, UNetAcZ
+    from oracle import unet_acoustic as oa
+
+    want = oa.param_shapes()
+    n = sum(int(torch.tensor(s).prod()) for s in want.values())
+    assert abs(n - 9.32e6) / 9.32e6 < 2e-3, n
+    p = oa.init_params(dtype=torch.float64)
+    x, eps = torch.rand(2, 36, 48, 12, dtype=torch.float64), torch.randn(2, 150, dtype=torch.float64)
+    own = oa.forward(p, x, eps)
+    ext = oa.forward(p, x, eps, own["mean"], own["std"])          # unet_z fed its own statistics = unet_noconc
+    assert torch.allclose(own["output"], ext["output"], atol=1e-12)
+    sess = Session(torch.device("cpu"))
+    tr = TrainerVAE(UNetAcNoConc(), session=sess)
+    g = tr._build_functions(batch_size=2)
+    tr.model.initialize()
+    sd = sess.store.state_dict()
+    assert set(sd) == set(want) and all(tuple(sd[k].shape) == tuple(want[k]) for k in want)
+    sess2 = Session(torch.device("cpu"))
+    m = UNetAcZ()
+    e = torch.zeros(2, 300)
+    m._build_model(torch.zeros(2, 36, 48, 12), e[:, :150], e[:, 150:], session=sess2)
+    assert len(m.plan_fwd) == len(tr.model.plan_fwd) + 1      # + the external reparameterisation
