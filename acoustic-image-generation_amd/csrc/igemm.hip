@@ -393,6 +393,7 @@ struct DirectParams {
     const float* w; int ldw, mode, wrows;   // wrows: rows per tap of the weight tensor (C fwd, Kout dgrad)
     const float* bias; int act;
     const float* res; int ldres;
+    float* stats; int stats_ld;   // optional: per-256-pixel-block (sum, sum^2) of conv + bias, [blocks][2][stats_ld]
     long M;
 };
 
@@ -416,8 +417,9 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectParams p, 
     const int ntaps = p.R * p.S;
     const int kg = blockIdx.y * 8;
     const float* __restrict__ wl = wprep + (long)blockIdx.y * ntaps * p.C * 8;
-    const long m = (long)blockIdx.x * 256 + threadIdx.x;
-    if (m >= p.M) return;
+    const long m_raw = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = m_raw < p.M;
+    const long m = live ? m_raw : p.M - 1;         // dead lanes recompute the last pixel and contribute nothing
     const int ow = (int)(m % p.OW);
     const long t = m / p.OW;
     const int oh = (int)(t % p.OH);
@@ -453,6 +455,27 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectParams p, 
             }
         }
     }
+    if (p.stats) {
+        // batch-norm partials of this 256-pixel row block (conv + bias, before any activation): lanes -> waves -> LDS
+        __shared__ float sred[4][16];
+        const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = live ? acc[k] + (p.bias && kg + k < p.K ? p.bias[kg + k] : 0.f) : 0.f;
+            const float s1 = wave_sum(v), s2 = wave_sum(v * v);
+            if (lane == 0) {
+                sred[wid][k] = s1;
+                sred[wid][8 + k] = s2;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 16 && kg + (threadIdx.x & 7) < p.K) {
+            const int k = threadIdx.x & 7, which = threadIdx.x >> 3;
+            p.stats[((long)blockIdx.x * 2 + which) * p.stats_ld + kg + k] =
+                (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+        }
+    }
+    if (!live) return;
     float* dst = p.y + m * p.ldy + kg;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -773,8 +796,10 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
         q.R = d->R; q.S = d->S; q.stride = d->stride; q.pad_t = d->pad_t; q.pad_l = d->pad_l;
         q.w = w; q.ldw = d->ldw; q.mode = 0; q.wrows = d->C; q.bias = bias; q.act = d->act;
         q.M = (long)d->N * d->OH * d->OW;
+        const bool fuse_stats = stats && stats_block_rows(d) == 256 && d->act == ACIMG_ACT_NONE;
+        if (fuse_stats) { q.stats = stats; q.stats_ld = d->ldw; }
         rc = launch_direct(q, ws, ws_bytes, (hipStream_t)stream);
-        if (!rc && stats) {   // batch-norm partials of y = conv + bias, in acimg_conv2d_stats_rows(d) row blocks
+        if (!rc && stats && !fuse_stats) {   // batch-norm partials of y = conv + bias, in acimg_conv2d_stats_rows(d) row blocks
             hipLaunchKernelGGL(partial_stats_kernel, dim3(acimg_conv2d_stats_rows(d)), dim3(256), 0, (hipStream_t)stream,
                                y, d->ldy, (int)q.M, d->K, stats, d->ldw, stats_block_rows(d));
             rc = check_launch("partial_stats");
