@@ -72,6 +72,8 @@ PROTOTYPES = {
     "acimg_minmax_bwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "acimg_latent_fwd": (_I, [_P, _P, _P, _I, _P, _P, _I, _I, _P]),
     "acimg_latent_bwd": (_I, [_P, _P, _P, _P, _I, _F, _P, _I, _I, _P]),
+    "acimg_softplus_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "acimg_softplus_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "acimg_latent_linear_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _P]),
     "acimg_latent_linear_bwd": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _P]),
     "acimg_maxpool_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -404,6 +404,14 @@ def latent_bwd(plan, heads, eps, sigma, gz, ldgz, kl_weight, g_heads, N, Z):
              g_heads, N, Z)
 
 
+def softplus_fwd(plan, x, ldx, y, ldy, rows, Cn):
+    plan.add("softplus_fwd", _L().acimg_softplus_fwd, x, int(ldx), y, int(ldy), int(rows), int(Cn))
+
+
+def softplus_bwd(plan, x, ldx, gy, ldgy, gx, ldgx, rows, Cn):
+    plan.add("softplus_bwd", _L().acimg_softplus_bwd, x, int(ldx), gy, int(ldgy), gx, int(ldgx), int(rows), int(Cn))
+
+
 def latent_linear_fwd(plan, heads, eps, z, ldz, kl, N, Z):
     plan.add("latent_linear_fwd", _L().acimg_latent_linear_fwd, heads, eps, z, int(ldz), kl, N, Z)
 

@@ -431,6 +431,21 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* heads, con
     gheads[(long)n * 2 * Z + Z + j] = dsg * dsp;
 }
 
+// softplus and its backward (the std tower of the latent associators, models/multimodal.py:48,107)
+__global__ __launch_bounds__(256) void softplus_fwd_kernel(const float* x, int ldx, float* y, int ldy, int rows, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C) return;
+    const int r = idx / C, c = idx - r * C;
+    y[(long)r * ldy + c] = softplus_f(x[(long)r * ldx + c]);
+}
+__global__ __launch_bounds__(256) void softplus_bwd_kernel(const float* x, int ldx, const float* gy, int ldgy, float* gx,
+                                                           int ldgx, int rows, int C) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * C) return;
+    const int r = idx / C, c = idx - r * C;
+    gx[(long)r * ldgx + c] = gy[(long)r * ldgy + c] / (1.f + expf(-x[(long)r * ldx + c]));
+}
+
 // the RGB / spectrogram U-Nets use the second head as sigma directly (models/unet_architecture.py:66-69):
 // z = mean + variance * eps, kl[n] = 0.5 * sum_j (mu^2 + s^2 - log(1e-8 + s^2) - 1)
 __global__ __launch_bounds__(256) void latent_linear_fwd_kernel(const float* heads, const float* eps, float* z,
@@ -989,6 +1004,19 @@ int acimg_latent_bwd(const float* heads, const float* eps, const float* sigma, c
     hipLaunchKernelGGL(latent_bwd_kernel, dim3(cdiv((long)N * Z, 256)), dim3(256), 0, (hipStream_t)stream,
                        heads, eps, sigma, gz, ldgz, kl_weight, g_heads, N, Z);
     return check_launch("latent_bwd");
+}
+
+int acimg_softplus_fwd(const float* x, int ldx, float* y, int ldy, int rows, int C, void* stream) {
+    hipLaunchKernelGGL(softplus_fwd_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, y,
+                       ldy, rows, C);
+    return check_launch("softplus_fwd");
+}
+
+int acimg_softplus_bwd(const float* x, int ldx, const float* gy, int ldgy, float* gx, int ldgx, int rows, int C,
+                       void* stream) {
+    hipLaunchKernelGGL(softplus_bwd_kernel, dim3(cdiv((long)rows * C, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, gy,
+                       ldgy, gx, ldgx, rows, C);
+    return check_launch("softplus_bwd");
 }
 
 int acimg_latent_linear_fwd(const float* heads, const float* eps, float* z, int ldz, float* kl, int N, int Z,

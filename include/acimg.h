@@ -282,6 +282,12 @@ int acimg_latent_linear_fwd(const float* heads, const float* eps, float* z, int 
 int acimg_latent_linear_bwd(const float* heads, const float* eps, const float* gz, int ldgz, float kl_weight,
                             float* g_heads, int N, int Z, void* stream);
 
+/* y = softplus(x) and gx = gy * sigmoid(x) on [rows][C] tensors with row strides (the std tower of the latent
+ * associators: tf.nn.softplus(tf.layers.dense(...)), models/multimodal.py:47-48,106-107). */
+int acimg_softplus_fwd(const float* x, int ldx, float* y, int ldy, int rows, int C, void* stream);
+int acimg_softplus_bwd(const float* x, int ldx, const float* gy, int ldgy, float* gx, int ldgx, int rows, int C,
+                       void* stream);
+
 /* Reconstruction loss on yhat = sigmoid output and its gradient w.r.t. the PRE-sigmoid logits:
  *   sums[0] += sum (yhat-y)^2, sums[1] += sum huber_1(yhat-y)   (caller zeroes sums)
  *   g_logit = (w_mse*2e + w_huber*clip(e,-1,1)) / count * yhat*(1-yhat)

@@ -260,3 +260,41 @@ def test_unet_acoustic_oracle_and_host_graph():
     e = torch.zeros(2, 300)
     m._build_model(torch.zeros(2, 36, 48, 12), e[:, :150], e[:, 150:], session=sess2)
     assert len(m.plan_fwd) == len(tr.model.plan_fwd) + 1      # + the external reparameterisation
+
+
+@pytest.mark.parametrize("which,n_params", [("AssociatorVideoAc", 2 * (1024 * 512 + 512 * 512 + 512 * 256 + 256 * 256
+                                                                    + 256 * 150 + 150 * 150 + 512 + 512 + 256 + 256
+                                                                    + 150 + 150)),
+                                            ("AssociatorAudioAc", 2 * (256 * 256 + 256 * 256 + 256 * 150 + 256 + 256
+                                                                    + 150))])
+def test_associator_oracle_and_host_graph(which, n_params):
+    """models/multimodal.py:5-137: two dense towers, tf.layers default names in creation order, softplus std;
+    the host graph registers the same TF-named variables and its Adam range covers exactly the associator"""
+    from acimg import multimodal
+    from acimg.session import Session
+    from acimg.trainer_associator import TrainerAssociator
+    from acimg.unet_acoustic import UNetAcZ
+    from oracle import multimodal as om
+
+    want = om.param_shapes(which)
+    assert sum(int(torch.tensor(s).prod()) for s in want.values()) == n_params
+    din, widths = om.TOWERS[which]
+    assert list(want)[0] == which + "/dense/kernel" and list(want)[-1] == "%s/dense_%d/bias" % (which, 2 * len(widths) - 1)
+    p = om.init_params(which, dtype=torch.float64)
+    m, s, raw, masks = om.forward(p, which, torch.randn(3, din, dtype=torch.float64),
+                                  torch.rand(3, din, dtype=torch.float64))
+    assert m.shape == s.shape == (3, 150) and bool((s > 0).all())
+    assert torch.allclose(s, torch.log1p(torch.exp(raw)))
+    assert len(masks) == 2 * (len(widths) - 1)
+    cls = getattr(multimodal, which)
+    sess = Session(torch.device("cpu"))
+    tr = TrainerAssociator(cls(), UNetAcZ(), session=sess)
+    g = tr._build_functions(batch_size=2)
+    tr.modelassociator.initialize()
+    tr.modelac.initialize()
+    sd = {k: v for k, v in sess.store.state_dict().items() if k.startswith(which + "/")}
+    assert set(sd) == set(want) and all(tuple(sd[k].shape) == tuple(want[k]) for k in want)
+    assert tr.modelassociator.train_vars and all(n.startswith(which + "/") for n in tr.modelassociator.train_vars)
+    # the Adam range [off, off + numel) of the flat buffer holds the associator's variables and no others
+    for n, o, c in sess.store.train_ranges():
+        assert (g.off <= o and o + c <= g.off + g.numel) == n.startswith(which + "/"), n
