@@ -75,6 +75,9 @@ PROTOTYPES = {
     "acimg_softplus_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "acimg_softplus_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "acimg_latent_linear_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _P]),
+    "acimg_triplet_loss_workspace": (_SZ, [_I]),
+    "acimg_triplet_loss_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _P, _SZ, _P, _P]),
+    "acimg_triplet_loss_bwd": (_I, [_P, _I, _P, _I, _I, _I, _F, _P, _SZ, _P, _I, _P, _I, _I, _P]),
     "acimg_latent_linear_bwd": (_I, [_P, _P, _P, _I, _F, _P, _I, _I, _P]),
     "acimg_maxpool_fwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "acimg_maxpool_relu_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -127,3 +127,134 @@ class AssociatorVideoAc(_Associator):
 
 class AssociatorAudioAc(_Associator):
     SCOPE, DIN, WIDTHS = "AssociatorAudioAc", 256, [256, 256, 150]
+
+
+class _JointMLP(object):
+    """The joint-latent fusion MLPs (models/multimodal.py:287-465): tf.layers.dense acts on the LAST axis, so on
+    [N, 12, 16, C] feature maps these are per-pixel MLPs = 1x1 convolutions.  concat(inputs) -> 3 x dense 512 (ReLU)
+    -> one ReLU dense head per output modality.  The inputs must be the consecutive channel slices of ONE device
+    buffer [..., Ctot] (the encoders write their feature maps there: the tf.concat costs nothing);
+    `record_backward` takes the gradients w.r.t. the head outputs and leaves d loss / d concat(inputs) in
+    `g_input`."""
+    SCOPE, NIN, HEADS, HIDDEN = None, 3, (), 512
+
+    def __init__(self, input_shape=None):
+        self.scope = self.SCOPE
+        self.session = None
+
+    def _names(self):
+        out, idx, cin = [], 0, self.cin
+        for _ in range(3):
+            out.append(("dense" if idx == 0 else "dense_%d" % idx, cin, self.HIDDEN, None))
+            cin = self.HIDDEN
+            idx += 1
+        for attr, w in self.HEADS:
+            out.append(("dense_%d" % idx, self.HIDDEN, w, attr))
+            idx += 1
+        return out
+
+    def _register(self, store):
+        for name, cin, cout, _ in reversed(self._names()):
+            store.add(Var("%s/%s/kernel" % (self.scope, name), (cin, cout), "dense", "train"))
+            store.add(Var("%s/%s/bias" % (self.scope, name), (cout,), "vec", "train"))
+
+    init_model = _Associator.init_model
+    _P = _Associator._P
+    _G = _Associator._G
+
+    def initialize(self, seed=1249, state=None):
+        if state is None:
+            g = torch.Generator().manual_seed(seed)
+            state = OrderedDict()
+            for name, cin, cout, _ in self._names():
+                lim = np.sqrt(6.0 / (cin + cout))
+                state["%s/%s/kernel" % (self.scope, name)] = (
+                    (torch.rand(cin, cout, generator=g, dtype=torch.float64) * 2 - 1) * lim).float()
+                state["%s/%s/bias" % (self.scope, name)] = torch.zeros(cout)
+        self.session.store.load_state(state, strict=False, only=lambda n: n.startswith(self.scope + "/"))
+
+    def _build_model(self, *inputs, **kw):
+        sess = kw.get("session") or get_default_session()
+        self.session = sess
+        assert len(inputs) == self.NIN, "%s takes %d feature maps" % (self.scope, self.NIN)
+        src = inputs[0]._base
+        assert src is not None and all(t._base is src for t in inputs), "inputs must be slices of one buffer"
+        ctot = src.shape[-1]
+        off = 0
+        for t in inputs:                                     # consecutive channel slices, in order
+            assert t.shape[:-1] == src.shape[:-1] and t.stride() == src.stride()
+            assert t.storage_offset() == src.storage_offset() + off, "inputs must be consecutive channel slices"
+            off += t.shape[-1]
+        assert off == ctot and ctot % 4 == 0, "the slices must cover the buffer; channels a multiple of 4"
+        self.cin, self.src = ctot, src
+        self._register(sess.store)
+        rows = src.numel() // ctot
+        self.rows = rows
+        lead = tuple(src.shape[:-1])
+        z = sess.zeros
+        p = sess.new_plan()
+        self.layers = []
+        x, ldx = src, ctot
+        self.heads = OrderedDict()
+        for name, cin, cout, attr in self._names():
+            if attr is not None:
+                x, ldx = self.net, self.HIDDEN
+            y = z(rows, up4(cout))
+            d = ops.conv_desc(rows, 1, 1, up4(cin), cout, 1, 1, 1, "VALID", ldx=ldx, ldy=up4(cout), ldw=up4(cout),
+                              act=ACT_RELU)
+            ops.conv2d_fwd(p, d, x, self._P(name + "/kernel"), self._P(name + "/bias"), y)
+            self.layers.append((name, d, x, ldx, y, attr))
+            if attr is None:
+                x, ldx = y, up4(cout)
+                self.net = y
+            else:
+                self.heads[attr] = y
+                setattr(self, attr, y.view(*(lead + (up4(cout),)))[..., :cout])
+        self.plan_fwd = p
+        self.network = OrderedDict(("input%s" % ("" if i == 0 else str(i + 1)), t) for i, t in enumerate(inputs))
+        self.train_vars = [n for n in sess.store.tf_names() if n.startswith(self.scope + "/")]
+
+    def record_backward(self, plan, g_heads, need_input_grad=True):
+        """g_heads: {head attribute: (gradient tensor / Ptr, row stride)} for the heads that carry a loss"""
+        rows = self.rows
+        z = self.session.zeros
+        g_net, first = z(rows, self.HIDDEN), True
+        for name, d, x, ldx, y, attr in self.layers:
+            if attr is None or attr not in g_heads:
+                continue
+            g, ldg = g_heads[attr]
+            gm = z(rows, d.ldy)
+            ops.grad_slice(plan, g, int(ldg), gm, d.ldy, y, d.ldy, rows, d.K)         # ReLU of the head
+            ops.conv2d_wgrad(plan, d, x, gm, d.ldy, self._G(name + "/kernel"), self._G(name + "/bias"))
+            ops.conv2d_dgrad(plan, d, gm, d.ldy, self._P(name + "/kernel"), g_net, None if first else g_net,
+                             0 if first else self.HIDDEN, self.net, self.HIDDEN)
+            first = False
+        assert not first, "no head gradient given"
+        gy, ldgy = g_net, self.HIDDEN
+        trunk = [L for L in self.layers if L[5] is None]
+        self.g_input = None
+        for i in (2, 1, 0):
+            name, d, x, ldx, y, _ = trunk[i]
+            ops.conv2d_wgrad(plan, d, x, gy, ldgy, self._G(name + "/kernel"), self._G(name + "/bias"))
+            if i > 0:
+                gx = z(rows, ldx)
+                ops.conv2d_dgrad(plan, d, gy, ldgy, self._P(name + "/kernel"), gx, None, 0, x, ldx)
+                gy, ldgy = gx, ldx
+            elif need_input_grad:
+                self.g_input = z(rows, ldx)
+                ops.conv2d_dgrad(plan, d, gy, ldgy, self._P(name + "/kernel"), self.g_input)
+
+
+class Jointmvae(_JointMLP):
+    """models/multimodal.py:287-347: (acoustic 128, video 512, audio 128 channels at 12x16) -> 133 / 512 / 128"""
+    SCOPE, NIN, HEADS = "Jointmvae", 3, (("outputac", 133), ("outputvideo", 512), ("outputaudio", 128))
+
+
+class JointTwomvae(_JointMLP):
+    """models/multimodal.py:349-404: (video, audio) -> acoustic features only"""
+    SCOPE, NIN, HEADS = "JointTwomvae", 2, (("outputac", 133),)
+
+
+class JointTwomvae2(_JointMLP):
+    """models/multimodal.py:406-465: (video, audio) -> all three modalities"""
+    SCOPE, NIN, HEADS = "JointTwomvae2", 2, (("outputac", 133), ("outputvideo", 512), ("outputaudio", 128))

@@ -412,6 +412,21 @@ def softplus_bwd(plan, x, ldx, gy, ldgy, gx, ldgx, rows, Cn):
     plan.add("softplus_bwd", _L().acimg_softplus_bwd, x, int(ldx), gy, int(ldgy), gx, int(ldgx), int(rows), int(Cn))
 
 
+def triplet_loss_workspace(B):
+    return int(_L().acimg_triplet_loss_workspace(int(B)))
+
+
+def triplet_loss_fwd(plan, e0, lde0, e1, lde1, labels, scenario, B, D, margin, hard, ws, out):
+    """ws: a uint8 / float buffer of triplet_loss_workspace(B) bytes kept for the matching backward"""
+    plan.add("triplet_loss_fwd", _L().acimg_triplet_loss_fwd, e0, int(lde0), e1, int(lde1), labels, scenario, int(B),
+             int(D), float(margin), int(hard), ws, int(ws.numel() * ws.element_size()), out)
+
+
+def triplet_loss_bwd(plan, e0, lde0, e1, lde1, B, D, weight, ws, g0, ldg0, g1, ldg1, accumulate=False):
+    plan.add("triplet_loss_bwd", _L().acimg_triplet_loss_bwd, e0, int(lde0), e1, int(lde1), int(B), int(D),
+             float(weight), ws, int(ws.numel() * ws.element_size()), g0, int(ldg0), g1, int(ldg1), int(accumulate))
+
+
 def latent_linear_fwd(plan, heads, eps, z, ldz, kl, N, Z):
     plan.add("latent_linear_fwd", _L().acimg_latent_linear_fwd, heads, eps, z, int(ldz), kl, N, Z)
 

@@ -288,6 +288,23 @@ int acimg_softplus_fwd(const float* x, int ldx, float* y, int ldy, int rows, int
 int acimg_softplus_bwd(const float* x, int ldx, const float* gy, int ldgy, float* gx, int ldgx, int rows, int C,
                        void* stream);
 
+/* Cross-modal triplet losses over B embedding pairs e0[B][D], e1[B][D] with int32 labels / scenario per sample
+ * (trainer/trainer_three.py): distances as `_pairwise_distances` :551-591 computes them (squared form,
+ * D[i][j] = max(|e0_j|^2 - 2 <e0_i, e1_j> + |e1_i|^2, 0)); a pair (i, j) is "same video" when label and scenario
+ * agree (:593-624); hard = 0: batch-all loss `mix_all` :685-732 (sum over valid triplets of max(D[a][p] - D[a][n] +
+ * margin, 0) / (number of positive ones + 1e-16)); hard = 1: batch-hard loss `mix_data_hard` :648-683.
+ * out[0] = loss, out[1] = fraction of positive triplets, out[2] = positive count, out[3] = valid count.
+ * The forward leaves what the backward needs in ws (acimg_triplet_loss_workspace(B) bytes, B <= 2048);
+ * bwd: g0 / g1 (either may be null) (+)= weight * d loss / d e0, e1, with TensorFlow's gradient conventions
+ * (tf.maximum passes the gradient at equality; reduce_max / reduce_min split it evenly among ties). */
+size_t acimg_triplet_loss_workspace(int B);
+int acimg_triplet_loss_fwd(const float* e0, int lde0, const float* e1, int lde1, const int* labels,
+                           const int* scenario, int B, int D, float margin, int hard, void* ws, size_t ws_bytes,
+                           float* out, void* stream);
+int acimg_triplet_loss_bwd(const float* e0, int lde0, const float* e1, int lde1, int B, int D, float weight,
+                           const void* ws, size_t ws_bytes, float* g0, int ldg0, float* g1, int ldg1,
+                           int accumulate, void* stream);
+
 /* Reconstruction loss on yhat = sigmoid output and its gradient w.r.t. the PRE-sigmoid logits:
  *   sums[0] += sum (yhat-y)^2, sums[1] += sum huber_1(yhat-y)   (caller zeroes sums)
  *   g_logit = (w_mse*2e + w_huber*clip(e,-1,1)) / count * yhat*(1-yhat)

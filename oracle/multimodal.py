@@ -77,3 +77,53 @@ def step_loss(pa, scope, pdec, x, eps, mean_in, std_in, relu_masks_a=None, relu_
     mse, hub = tfsem.mse_loss(x, fw["output"]), tfsem.huber_loss(x, fw["output"])
     return dict(loss=latent + mse + hub, mse=mse, huber=hub, latent=latent, mean=m, std=s, output=fw["output"],
                 masks_a=masks_a, masks_d=fw["masks"])
+
+
+# ---- joint-latent fusion MLPs (models/multimodal.py:287-465) ------------------------------------------------
+JOINT_HEADS = {"Jointmvae": (("outputac", 133), ("outputvideo", 512), ("outputaudio", 128)),
+               "JointTwomvae": (("outputac", 133),),
+               "JointTwomvae2": (("outputac", 133), ("outputvideo", 512), ("outputaudio", 128))}
+
+
+def joint_param_shapes(scope, cin):
+    s = OrderedDict()
+    widths = [(cin, 512), (512, 512), (512, 512)] + [(512, w) for _, w in JOINT_HEADS[scope]]
+    for idx, (a, b) in enumerate(widths):
+        name = "dense" if idx == 0 else "dense_%d" % idx
+        s["%s/%s/kernel" % (scope, name)] = (a, b)
+        s["%s/%s/bias" % (scope, name)] = (b,)
+    return s
+
+
+def joint_init_params(scope, cin, seed=1249, dtype=torch.float32, bias_std=0.0):
+    g = torch.Generator().manual_seed(seed)
+    p = OrderedDict()
+    for name, shape in joint_param_shapes(scope, cin).items():
+        if name.endswith("/bias"):
+            p[name] = (bias_std * torch.randn(*shape, generator=g, dtype=torch.float64)).to(dtype)
+        else:
+            p[name] = tfsem.xavier_uniform(g, shape, shape[0], shape[1], dtype)
+    return p
+
+
+def joint_forward(p, scope, inputs, relu_masks=None):
+    """inputs: feature maps [..., C_i]; tf.concat on the last axis, tf.layers.dense on the last axis (ReLU
+    everywhere, heads included).  -> ({head: tensor}, relu masks by layer name)"""
+    net = torch.cat(list(inputs), dim=-1)
+    masks = OrderedDict()
+
+    def dense(t, idx):
+        name = "dense" if idx == 0 else "dense_%d" % idx
+        t = t @ p["%s/%s/kernel" % (scope, name)] + p["%s/%s/bias" % (scope, name)]
+        if relu_masks is not None and name in relu_masks:
+            return t * relu_masks[name].to(t.dtype)
+        t = torch.relu(t)
+        masks[name] = t > 0
+        return t
+
+    for idx in range(3):
+        net = dense(net, idx)
+    outs = OrderedDict()
+    for k, (attr, _) in enumerate(JOINT_HEADS[scope]):
+        outs[attr] = dense(net, 3 + k)
+    return outs, masks

@@ -1,8 +1,9 @@
-"""Latent associators (models/multimodal.py) and the single-associator step of
-trainer/trainer_proietta.py against the frozen unet_z decoder: outputs, losses and every associator gradient vs
-the fp64 oracle, through the C ABI; only the associator's variables move."""
+"""Latent associators and joint-latent fusion MLPs (models/multimodal.py) and the
+single-associator step of trainer/trainer_proietta.py against the frozen unet_z decoder: outputs, losses and every
+gradient vs the fp64 oracle, through the C ABI; only the associator's variables move."""
 import os
 import sys
+from collections import OrderedDict
 
 import pytest
 import torch
@@ -72,3 +73,65 @@ def test_associator_step(which):
     after = sess.store.state_dict()
     for k in before:
         assert (not torch.equal(before[k], after[k])) == k.startswith(which + "/"), k
+
+
+@pytest.mark.parametrize("which,widths", [("Jointmvae", (128, 512, 128)), ("JointTwomvae", (512, 128)),
+                                          ("JointTwomvae2", (512, 128))])
+def test_joint_mlp(which, widths):
+    """joint-latent fusion MLPs (models/multimodal.py:287-465) on 12x16 feature maps: head outputs, every parameter
+    gradient and the gradient w.r.t. the concatenated inputs vs the fp64 oracle, under a weighted squared-error
+    loss on each head"""
+    from acimg import multimodal
+    from acimg.session import Session
+    from oracle import multimodal as om
+
+    dev = torch.device("cuda:0")
+    N, H, W = 3, 12, 16
+    cls = getattr(multimodal, which)
+    sess = Session(dev)
+    ctot = sum(widths)
+    buf = sess.zeros(N, H, W, ctot)
+    ins, o = [], 0
+    for w in widths:
+        ins.append(buf[..., o:o + w])
+        o += w
+    m = cls()
+    m._build_model(*ins, session=sess)
+    g_bufs = OrderedDict((a, sess.zeros(m.rows, m.heads[a].shape[1])) for a, _ in cls.HEADS)
+    bp = sess.new_plan()
+    m.record_backward(bp, {a: (g, g.shape[1]) for a, g in g_bufs.items()})
+    sess.finalize()
+    pa = om.joint_init_params(which, ctot, seed=31, dtype=torch.float64, bias_std=0.05)
+    m.initialize(state={k: v.float() for k, v in pa.items()})
+    gen = torch.Generator().manual_seed(32)
+    x = torch.rand(N, H, W, ctot, generator=gen, dtype=torch.float64).float().double()
+    buf.copy_(x.float())
+    m.plan_fwd.run()
+    torch.cuda.synchronize()
+    masks = {}
+    for name, d, xx, ldx, y, attr in m.layers:
+        masks[name] = (y[:, :d.K] > 0).cpu().view(N, H, W, d.K)
+    p = {k: v.clone().requires_grad_(True) for k, v in pa.items()}
+    xin = x.clone().requires_grad_(True)
+    parts, o = [], 0
+    for w in widths:
+        parts.append(xin[..., o:o + w])
+        o += w
+    outs, _ = om.joint_forward(p, which, parts, relu_masks=masks)
+    loss = 0
+    for k, (attr, w) in enumerate(cls.HEADS):
+        got = getattr(m, attr)
+        assert got.shape == (N, H, W, w) and rel(got, outs[attr].detach()) < 1e-4
+        tgt = torch.rand(N, H, W, w, generator=gen, dtype=torch.float64)
+        wk = 0.5 + k
+        loss = loss + 0.5 * wk * ((outs[attr] - tgt) ** 2).sum()
+        g_bufs[attr][:, :w] = (wk * (got.double().cpu() - tgt)).float().view(-1, w).to(dev)
+    bp.run()
+    torch.cuda.synchronize()
+    names = list(p.keys())
+    grads = torch.autograd.grad(loss, [p[k] for k in names] + [xin])
+    got = sess.store.grad_dict()
+    worst = max((rel(got[k], v), k) for k, v in zip(names, grads[:-1]))
+    print("%s: worst gradient %s %.2e" % (which, worst[1], worst[0]))
+    assert worst[0] < 1e-3, worst
+    assert rel(m.g_input.view(N, H, W, ctot), grads[-1]) < 1e-3

@@ -298,3 +298,82 @@ def test_associator_oracle_and_host_graph(which, n_params):
     # the Adam range [off, off + numel) of the flat buffer holds the associator's variables and no others
     for n, o, c in sess.store.train_ranges():
         assert (g.off <= o and o + c <= g.off + g.numel) == n.startswith(which + "/"), n
+
+
+def test_triplet_oracle_against_loops():
+    """trainer/trainer_three.py:551-732 restated with broadcasting vs explicit loops over (anchor, positive,
+    negative); the distance keeps the reference's broadcast of the two norms"""
+    from oracle import triplet as ot
+    g = torch.Generator().manual_seed(5)
+    B, D, margin = 9, 4, 0.4
+    e0 = torch.randn(B, D, generator=g, dtype=torch.float64)
+    e1 = torch.randn(B, D, generator=g, dtype=torch.float64)
+    labels = torch.tensor([0, 0, 1, 1, 2, 0, 1, 2, 2])
+    scenario = torch.tensor([0, 0, 0, 1, 1, 0, 1, 1, 0])
+    d = ot.pairwise_distances(e0, e1)
+    same = lambda a, b: bool(labels[a] == labels[b] and scenario[a] == scenario[b])
+    for i in range(B):
+        for j in range(B):
+            want = max(float((e0[j] ** 2).sum() - 2 * (e0[i] * e1[j]).sum() + (e1[i] ** 2).sum()), 0.0)
+            assert abs(float(d[i, j]) - want) < 1e-12
+    s, npos, nvalid = 0.0, 0, 0
+    for a in range(B):
+        for p in range(B):
+            for n in range(B):
+                if same(a, p) and not same(a, n):
+                    nvalid += 1
+                    t = max(float(d[a, p] - d[a, n]) + margin, 0.0)
+                    s += t
+                    npos += t > 1e-16
+    loss, frac, np_, nv_ = ot.mix_all(e0, e1, labels, scenario, margin)
+    assert abs(float(loss) - s / npos) < 1e-12 and int(np_) == npos and int(nv_) == nvalid
+    assert abs(float(frac) - npos / nvalid) < 1e-12
+    tl = []
+    for a in range(B):
+        hp = max(float(d[a, p]) if same(a, p) else 0.0 for p in range(B))
+        rm = float(d[a].max())
+        hn = min(float(d[a, n]) + (rm if same(a, n) else 0.0) for n in range(B))
+        tl.append(max(hp - hn + margin, 0.0))
+    loss_h, frac_h, _, _ = ot.mix_data_hard(e0, e1, labels, scenario, margin)
+    assert abs(float(loss_h) - sum(tl) / B) < 1e-12
+    assert abs(float(frac_h) - sum(t > 1e-16 for t in tl) / nvalid) < 1e-12
+    # tied maxima share the gradient (tf.reduce_max), the hinge passes it at exactly zero (tf.maximum)
+    x = torch.tensor([[1.0, 3.0, 3.0]], dtype=torch.float64, requires_grad=True)
+    torch.amax(x, dim=1).sum().backward()
+    assert x.grad.tolist() == [[0.0, 0.5, 0.5]]
+    z = torch.zeros(2, dtype=torch.float64, requires_grad=True)
+    ot._tf_max0(z).sum().backward()
+    assert z.grad.tolist() == [1.0, 1.0]
+
+
+@pytest.mark.parametrize("which,widths", [("Jointmvae", (128, 512, 128)), ("JointTwomvae", (512, 128)),
+                                          ("JointTwomvae2", (512, 128))])
+def test_joint_mlp_oracle_and_host_graph(which, widths):
+    """models/multimodal.py:287-465: concat -> 3 x dense 512 -> ReLU heads (133 / 512 / 128); per-pixel on 12x16 maps"""
+    from acimg import multimodal
+    from acimg.session import Session
+    from oracle import multimodal as om
+
+    ctot = sum(widths)
+    want = om.joint_param_shapes(which, ctot)
+    heads = om.JOINT_HEADS[which]
+    assert len(want) == 2 * (3 + len(heads)) and want[which + "/dense/kernel"] == (ctot, 512)
+    p = om.joint_init_params(which, ctot, dtype=torch.float64)
+    ins = [torch.rand(2, 12, 16, w, dtype=torch.float64) for w in widths]
+    outs, masks = om.joint_forward(p, which, ins)
+    assert [tuple(v.shape) for v in outs.values()] == [(2, 12, 16, w) for _, w in heads]
+    assert all(bool((v >= 0).all()) for v in outs.values()) and len(masks) == 3 + len(heads)
+    sess = Session(torch.device("cpu"))
+    buf = sess.zeros(2, 12, 16, ctot)
+    parts, o = [], 0
+    for w in widths:
+        parts.append(buf[..., o:o + w])
+        o += w
+    m = getattr(multimodal, which)()
+    m._build_model(*parts, session=sess)
+    sess.finalize()
+    m.initialize()
+    sd = {k: v for k, v in sess.store.state_dict().items() if k.startswith(which + "/")}
+    assert set(sd) == set(want) and all(tuple(sd[k].shape) == tuple(want[k]) for k in want)
+    with pytest.raises(AssertionError):                       # inputs in the wrong order are not a concat
+        getattr(multimodal, which)()._build_model(*parts[::-1], session=Session(torch.device("cpu")))
