@@ -387,12 +387,16 @@ def tile_mfcc(plan, mfcc, out, N, HW, Cn):
 
 
 def minmax_fwd(plan, x, ldx, out, ldo, mm, N, P, Cn):
-    plan.add("minmax_fwd", _L().acimg_minmax_fwd, x, ldx, out, ldo, mm, N, P, Cn)
+    L = _L()
+    plan.ws.require(L.acimg_minmax_workspace(int(N), int(P), int(Cn)))
+    plan.add("minmax_fwd", L.acimg_minmax_fwd, x, ldx, out, ldo, mm, N, P, Cn, _WsPtr(plan.ws), _WsBytes(plan.ws))
 
 
 def minmax_bwd(plan, x, ldx, go, ldgo, mm, gx, ldgx, N, P, Cn, accumulate=False, mask_relu=False):
-    plan.add("minmax_bwd", _L().acimg_minmax_bwd, x, ldx, go, ldgo, mm, gx, ldgx, N, P, Cn,
-             int(accumulate), int(mask_relu))
+    L = _L()
+    plan.ws.require(L.acimg_minmax_workspace(int(N), int(P), int(Cn)))
+    plan.add("minmax_bwd", L.acimg_minmax_bwd, x, ldx, go, ldgo, mm, gx, ldgx, N, P, Cn,
+             int(accumulate), int(mask_relu), _WsPtr(plan.ws), _WsBytes(plan.ws))
 
 
 def latent_fwd(plan, heads, eps, z, ldz, sigma, kl, N, Z):

@@ -308,15 +308,27 @@ __global__ __launch_bounds__(256) void tile_mfcc_kernel(const float* mfcc, float
 }
 
 // ------------------------------------------------------------------------------------------
-// per-sample min-max normalisation; one block per sample
+// per-sample min-max normalisation; S pixel chunks per sample (grid S x N), two phases each way:
+// partial (min, max) / partial gradient sums per chunk into the workspace, then every chunk combines the S
+// partials of its sample in a fixed order and does its share of the elementwise work.  Tie counts are
+// integer-valued float atomics (exact, order-independent), so results are bit-reproducible.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void minmax_fwd_kernel(const float* x, int ldx, float* out, int ldo,
-                                                         float* mm, int P, int C) {
+static inline int minmax_chunks(int P, int C) {
+    long s = ((long)P * C + 2047) / 2048;
+    if (s > 32) s = 32;
+    if (s > P) s = P;
+    if (s < 1) s = 1;
+    const int ppc = (P + (int)s - 1) / (int)s;
+    return (P + ppc - 1) / ppc;
+}
+
+__global__ __launch_bounds__(256) void minmax_part_kernel(const float* x, int ldx, float* part, float* mm,
+                                                          int P, int C, int ppc) {
     __shared__ float sm[32];
-    const int n = blockIdx.x;
-    const float* xs = x + (long)n * P * ldx;
-    float* os = out + (long)n * P * ldo;
-    const int cnt = P * C;
+    const int n = blockIdx.y, sidx = blockIdx.x, S = gridDim.x;
+    const int p0 = sidx * ppc, np = min(ppc, P - p0);
+    const float* xs = x + ((long)n * P + p0) * ldx;
+    const int cnt = np * C;
     float mn = INFINITY, mx = -INFINITY;
     for (int i = threadIdx.x; i < cnt; i += 256) {
         const int p = i / C, c = i - p * C;
@@ -332,9 +344,30 @@ __global__ __launch_bounds__(256) void minmax_fwd_kernel(const float* x, int ldx
         sm[4 + wid] = mx;
     }
     __syncthreads();
-    mn = fminf(fminf(sm[0], sm[1]), fminf(sm[2], sm[3]));
-    mx = fmaxf(fmaxf(sm[4], sm[5]), fmaxf(sm[6], sm[7]));
+    if (threadIdx.x == 0) {
+        part[((long)n * S + sidx) * 2 + 0] = fminf(fminf(sm[0], sm[1]), fminf(sm[2], sm[3]));
+        part[((long)n * S + sidx) * 2 + 1] = fmaxf(fmaxf(sm[4], sm[5]), fmaxf(sm[6], sm[7]));
+        if (sidx == 0) {
+            mm[n * 4 + 2] = 0.f;
+            mm[n * 4 + 3] = 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void minmax_apply_kernel(const float* x, int ldx, float* out, int ldo,
+                                                           const float* part, float* mm, int P, int C, int ppc) {
+    __shared__ float sm[32];
+    const int n = blockIdx.y, sidx = blockIdx.x, S = gridDim.x;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int k = 0; k < S; ++k) {
+        mn = fminf(mn, part[((long)n * S + k) * 2 + 0]);
+        mx = fmaxf(mx, part[((long)n * S + k) * 2 + 1]);
+    }
     const float D = mx - mn;
+    const int p0 = sidx * ppc, np = min(ppc, P - p0);
+    const float* xs = x + ((long)n * P + p0) * ldx;
+    float* os = out + ((long)n * P + p0) * ldo;
+    const int cnt = np * C;
     float cmin = 0.f, cmax = 0.f;
     for (int i = threadIdx.x; i < cnt; i += 256) {
         const int p = i / C, c = i - p * C;
@@ -346,25 +379,24 @@ __global__ __launch_bounds__(256) void minmax_fwd_kernel(const float* x, int ldx
     cmin = block_sum(cmin, sm);
     cmax = block_sum(cmax, sm);
     if (threadIdx.x == 0) {
-        mm[n * 4 + 0] = mn;
-        mm[n * 4 + 1] = mx;
-        mm[n * 4 + 2] = cmin;
-        mm[n * 4 + 3] = cmax;
+        if (sidx == 0) {
+            mm[n * 4 + 0] = mn;
+            mm[n * 4 + 1] = mx;
+        }
+        if (cmin != 0.f) atomicAdd(&mm[n * 4 + 2], cmin);
+        if (cmax != 0.f) atomicAdd(&mm[n * 4 + 3], cmax);
     }
 }
 
-__global__ __launch_bounds__(256) void minmax_bwd_kernel(const float* x, int ldx, const float* go,
-                                                         int ldgo, const float* mm, float* gx,
-                                                         int ldgx, int P, int C, int accumulate,
-                                                         int mask_relu) {
+__global__ __launch_bounds__(256) void minmax_bwd_part_kernel(const float* x, int ldx, const float* go, int ldgo,
+                                                              const float* mm, float* part, int P, int C, int ppc) {
     __shared__ float sm[32];
-    const int n = blockIdx.x;
-    const float* xs = x + (long)n * P * ldx;
-    const float* gs = go + (long)n * P * ldgo;
-    float* gxs = gx + (long)n * P * ldgx;
-    const float mn = mm[n * 4 + 0], mx = mm[n * 4 + 1], cmin = mm[n * 4 + 2], cmax = mm[n * 4 + 3];
-    const float D = mx - mn;
-    const int cnt = P * C;
+    const int n = blockIdx.y, sidx = blockIdx.x, S = gridDim.x;
+    const int p0 = sidx * ppc, np = min(ppc, P - p0);
+    const float* xs = x + ((long)n * P + p0) * ldx;
+    const float* gs = go + ((long)n * P + p0) * ldgo;
+    const float mn = mm[n * 4 + 0], D = mm[n * 4 + 1] - mn;
+    const int cnt = np * C;
     float s1 = 0.f, s2 = 0.f;
     for (int i = threadIdx.x; i < cnt; i += 256) {
         const int p = i / C, c = i - p * C;
@@ -375,8 +407,31 @@ __global__ __launch_bounds__(256) void minmax_bwd_kernel(const float* x, int ldx
     }
     s1 = block_sum(s1, sm);
     s2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+        part[((long)n * S + sidx) * 2 + 0] = s1;
+        part[((long)n * S + sidx) * 2 + 1] = s2;
+    }
+}
+
+__global__ __launch_bounds__(256) void minmax_bwd_kernel(const float* x, int ldx, const float* go,
+                                                         int ldgo, const float* mm, const float* part, float* gx,
+                                                         int ldgx, int P, int C, int ppc, int accumulate,
+                                                         int mask_relu) {
+    const int n = blockIdx.y, sidx = blockIdx.x, S = gridDim.x;
+    const int p0 = sidx * ppc, np = min(ppc, P - p0);
+    const float* xs = x + ((long)n * P + p0) * ldx;
+    const float* gs = go + ((long)n * P + p0) * ldgo;
+    float* gxs = gx + ((long)n * P + p0) * ldgx;
+    const float mn = mm[n * 4 + 0], mx = mm[n * 4 + 1], cmin = mm[n * 4 + 2], cmax = mm[n * 4 + 3];
+    const float D = mx - mn;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < S; ++k) {
+        s1 += part[((long)n * S + k) * 2 + 0];
+        s2 += part[((long)n * S + k) * 2 + 1];
+    }
     const float gmin = -(s1 - s2) / D / cmin;
     const float gmax = -s2 / D / cmax;
+    const int cnt = np * C;
     for (int i = threadIdx.x; i < cnt; i += 256) {
         const int p = i / C, c = i - p * C;
         const float v = xs[(long)p * ldx + c];
@@ -977,18 +1032,36 @@ int acimg_tile_mfcc(const float* mfcc, float* out, int N, int HW, int C, void* s
     return check_launch("tile_mfcc");
 }
 
-int acimg_minmax_fwd(const float* x, int ldx, float* out, int ldo, float* mm, int N, int P, int C,
-                     void* stream) {
-    hipLaunchKernelGGL(minmax_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo,
-                       mm, P, C);
+size_t acimg_minmax_workspace(int N, int P, int C) {
+    if (N <= 0 || P <= 0 || C <= 0) return 0;
+    return (size_t)N * minmax_chunks(P, C) * 2 * sizeof(float);
+}
+
+int acimg_minmax_fwd(const float* x, int ldx, float* out, int ldo, float* mm, int N, int P, int C, void* ws,
+                     size_t ws_bytes, void* stream) {
+    if (!x || !out || !mm || N <= 0 || P <= 0 || C <= 0) return fail(ACIMG_EINVAL, "minmax_fwd: bad argument");
+    if (!ws || ws_bytes < acimg_minmax_workspace(N, P, C))
+        return fail(ACIMG_EWORKSPACE, "minmax_fwd: workspace %zu < %zu", ws_bytes, acimg_minmax_workspace(N, P, C));
+    const int S = minmax_chunks(P, C), ppc = cdiv(P, S);
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(minmax_part_kernel, dim3(S, N), dim3(256), 0, (hipStream_t)stream, x, ldx, part, mm, P, C, ppc);
+    hipLaunchKernelGGL(minmax_apply_kernel, dim3(S, N), dim3(256), 0, (hipStream_t)stream, x, ldx, out, ldo, part,
+                       mm, P, C, ppc);
     return check_launch("minmax_fwd");
 }
 
 int acimg_minmax_bwd(const float* x, int ldx, const float* go, int ldgo, const float* mm,
-                     float* gx, int ldgx, int N, int P, int C, int accumulate, int mask_relu,
-                     void* stream) {
-    hipLaunchKernelGGL(minmax_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, ldx, go, ldgo,
-                       mm, gx, ldgx, P, C, accumulate, mask_relu);
+                     float* gx, int ldgx, int N, int P, int C, int accumulate, int mask_relu, void* ws,
+                     size_t ws_bytes, void* stream) {
+    if (!x || !go || !mm || !gx || N <= 0 || P <= 0 || C <= 0) return fail(ACIMG_EINVAL, "minmax_bwd: bad argument");
+    if (!ws || ws_bytes < acimg_minmax_workspace(N, P, C))
+        return fail(ACIMG_EWORKSPACE, "minmax_bwd: workspace %zu < %zu", ws_bytes, acimg_minmax_workspace(N, P, C));
+    const int S = minmax_chunks(P, C), ppc = cdiv(P, S);
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(minmax_bwd_part_kernel, dim3(S, N), dim3(256), 0, (hipStream_t)stream, x, ldx, go, ldgo, mm,
+                       part, P, C, ppc);
+    hipLaunchKernelGGL(minmax_bwd_kernel, dim3(S, N), dim3(256), 0, (hipStream_t)stream, x, ldx, go, ldgo,
+                       mm, part, gx, ldgx, P, C, ppc, accumulate, mask_relu);
     return check_launch("minmax_bwd");
 }
 
@@ -1105,7 +1178,7 @@ int acimg_recon_loss(const float* yhat, const float* target, float* g_logit, flo
     if (!aligned16(yhat) || !aligned16(target) || (g_logit && !aligned16(g_logit)))
         return fail(ACIMG_EINVAL, "recon_loss: buffers must be 16-byte aligned");
     long blocks = (count / 4 + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 160) blocks = 160;      // two float atomics per workgroup on the same two words: keep them few
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(recon_loss_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, yhat,
                        target, g_logit, sums, count, w_mse, w_huber);

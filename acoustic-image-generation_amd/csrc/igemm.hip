@@ -200,10 +200,19 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradParams p) {
         }
 }
 
-// sums `splits` slabs of [rows][ld] (only cols < ncols) into out[rows][ld]
+// sums `splits` slabs of [rows][ld] (only cols < ncols) into out[rows][ld]; workgroups >= nb1 do the same for a
+// second, one-row job (the bias gradient of the same launch: one reduce launch per weight gradient, not two)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int splits, long rows,
-                                                          int ncols, int ld, float* out) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+                                                          int ncols, int ld, float* out, int nb1,
+                                                          const float* slab2, float* out2) {
+    long bid = blockIdx.x;
+    if (bid >= nb1) {
+        bid -= nb1;
+        slab = slab2;
+        out = out2;
+        rows = 1;
+    }
+    const long idx = bid * 256 + threadIdx.x;
     if (idx >= rows * ncols) return;
     const long row = idx / ncols;
     const int col = (int)(idx - row * ncols);
@@ -215,10 +224,18 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int
 // the same for many slabs (few-channel weight gradients use up to 2048 pixel splits): 32 outputs per workgroup,
 // 8 lane groups walk the slabs with four loads in flight each, fixed-order combine -> deterministic
 __global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float* slab, int splits, long rows,
-                                                               int ncols, int ld, float* out) {
+                                                               int ncols, int ld, float* out, int nb1,
+                                                               const float* slab2, float* out2) {
     __shared__ float red[8][32];
     const int ol = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const long idx = (long)blockIdx.x * 32 + ol;
+    long bid = blockIdx.x;
+    if (bid >= nb1) {                  // second job: the one-row bias gradient
+        bid -= nb1;
+        slab = slab2;
+        out = out2;
+        rows = 1;
+    }
+    const long idx = bid * 32 + ol;
     const bool ok = idx < rows * ncols;
     const long row = ok ? idx / ncols : 0;
     const int col = ok ? (int)(idx - row * ncols) : 0;
@@ -674,17 +691,13 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
     if (p.splits > 1) {
         const long total = (long)p.KK * p.Ngemm;
         if (p.splits > 32) {
-            hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(cdiv(total, 32)), dim3(256), 0, st, p.out,
-                               p.splits, (long)p.KK, p.Ngemm, p.ldo, dw);
-            if (db)
-                hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(cdiv(p.Ngemm, 32)), dim3(256), 0, st, db_slab,
-                                   p.splits, 1L, p.Ngemm, p.ldo, db);
+            const int nb1 = (int)cdiv(total, 32), nb2 = db ? cdiv(p.Ngemm, 32) : 0;
+            hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(nb1 + nb2), dim3(256), 0, st, p.out, p.splits,
+                               (long)p.KK, p.Ngemm, p.ldo, dw, nb1, db_slab, db);
         } else {
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p.out,
-                               p.splits, (long)p.KK, p.Ngemm, p.ldo, dw);
-            if (db)
-                hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(p.Ngemm, 256)), dim3(256), 0, st, db_slab, p.splits,
-                                   1L, p.Ngemm, p.ldo, db);
+            const int nb1 = (int)cdiv(total, 256), nb2 = db ? cdiv(p.Ngemm, 256) : 0;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb1 + nb2), dim3(256), 0, st, p.out, p.splits,
+                               (long)p.KK, p.Ngemm, p.ldo, dw, nb1, db_slab, db);
         }
         rc = check_launch("wgrad_reduce");
     }
@@ -694,7 +707,7 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
 // column sums; workspace: parts*ncols floats
 static int launch_colsum(const float* G, long rows, int ncols, int ld, float* out, void* ws,
                          size_t ws_bytes, hipStream_t st) {
-    int parts = (int)((rows + 511) / 512);
+    int parts = (int)((rows + 255) / 256);
     if (parts > 256) parts = 256;
     if (parts < 1) parts = 1;
     const long rpb = (rows + parts - 1) / parts;

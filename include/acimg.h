@@ -255,14 +255,17 @@ int acimg_tile_mfcc(const float* mfcc, float* out, int N, int HW, int C, void* s
 /* Per-sample min-max normalisation o = (x-min)/(max-min) over `cnt` = P*C logical elements of
  * sample n (x pixel stride ldx, out pixel stride ldo, written at out+0: pass an offset pointer to
  * write into a concat slice).  mm[n] = {min, max, #argmin, #argmax} saved for backward.
+ * Every sample is cut into pixel chunks (one workgroup each); the per-chunk partials live in `ws`
+ * (acimg_minmax_workspace(N, P, C) bytes, scratch: nothing is kept there between calls).
  * Replaces models/unet_acresnet.py:55-58, :70-71. */
-int acimg_minmax_fwd(const float* x, int ldx, float* out, int ldo, float* mm, int N, int P, int C,
-                     void* stream);
+size_t acimg_minmax_workspace(int N, int P, int C);
+int acimg_minmax_fwd(const float* x, int ldx, float* out, int ldo, float* mm, int N, int P, int C, void* ws,
+                     size_t ws_bytes, void* stream);
 /* Gradient incl. the reduce_min / reduce_max paths with equal tie splitting (App. B.8).
  * gx = [accumulate? gx : 0] + d/dx; then zeroed where relu_mask (=x itself) <= 0 if mask_relu. */
 int acimg_minmax_bwd(const float* x, int ldx, const float* go, int ldgo, const float* mm,
-                     float* gx, int ldgx, int N, int P, int C, int accumulate, int mask_relu,
-                     void* stream);
+                     float* gx, int ldgx, int N, int P, int C, int accumulate, int mask_relu, void* ws,
+                     size_t ws_bytes, void* stream);
 
 /* heads [N,2*Z] = (mean | std_raw) -> sigma = softplus(std_raw), z = mean + sigma*eps,
  * kl[n] = 0.5*sum(mean^2+sigma^2-log(1e-8+sigma^2)-1).  z has row stride ldz (pads untouched).
