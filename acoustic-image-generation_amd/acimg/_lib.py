@@ -76,6 +76,11 @@ PROTOTYPES = {
     "acimg_softplus_fwd": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "acimg_softplus_bwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "acimg_latent_linear_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _P]),
+    "acimg_tapconv_stats_rows": (_I, [_DP]),
+    "acimg_tapconv_pack": (_I, [_DP, _P, _P, _I, _P]),
+    "acimg_tapconv_unpack": (_I, [_DP, _P, _I, _P, _F, _P, _P]),
+    "acimg_tapconv_gather": (_I, [_DP, _P, _I, _P, _P, _P]),
+    "acimg_tapconv_scatter": (_I, [_DP, _P, _I, _P, _I, _P]),
     "acimg_triplet_loss_workspace": (_SZ, [_I]),
     "acimg_triplet_loss_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _F, _I, _P, _SZ, _P, _P]),
     "acimg_triplet_loss_bwd": (_I, [_P, _I, _P, _I, _I, _I, _F, _P, _SZ, _P, _I, _P, _I, _I, _P]),

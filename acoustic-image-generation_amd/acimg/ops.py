@@ -416,6 +416,26 @@ def softplus_bwd(plan, x, ldx, gy, ldgy, gx, ldgx, rows, Cn):
     plan.add("softplus_bwd", _L().acimg_softplus_bwd, x, int(ldx), gy, int(ldgy), gx, int(ldgx), int(rows), int(Cn))
 
 
+def tapconv_stats_rows(d):
+    return int(_L().acimg_tapconv_stats_rows(C.byref(d)))
+
+
+def tapconv_pack(plan, d, w, wt, ldwt):
+    plan.add("tapconv_pack", _L().acimg_tapconv_pack, C.byref(d), w, wt, int(ldwt))
+
+
+def tapconv_unpack(plan, d, dwt, ldwt, w, decay, dw):
+    plan.add("tapconv_unpack", _L().acimg_tapconv_unpack, C.byref(d), dwt, int(ldwt), w, float(decay), dw)
+
+
+def tapconv_gather(plan, d, z, ldz, y, stats=None):
+    plan.add("tapconv_gather", _L().acimg_tapconv_gather, C.byref(d), z, int(ldz), y, stats)
+
+
+def tapconv_scatter(plan, d, gy, ldgy, gz, ldgz):
+    plan.add("tapconv_scatter", _L().acimg_tapconv_scatter, C.byref(d), gy, int(ldgy), gz, int(ldgz))
+
+
 def triplet_loss_workspace(B):
     return int(_L().acimg_triplet_loss_workspace(int(B)))
 

@@ -178,6 +178,16 @@ class ResNet50Model(object):
         self.g_raw_cm = z(N, fh, fw, 12)
         self.stats = None
         self._stats_need = 0
+        if self.precision == "f16x3":
+            # conv_map as a tap GEMM (ops.tapconv_*): packed kernel, its split image, per-input-pixel products
+            self._cm_d = ops.conv_desc(N, h, w, 2048, 12, 3, 4, 1, "VALID", ldx=2048, ldy=12, ldw=12)
+            self._cm_d1 = ops.conv_desc(N, h, w, 2048, 144, 1, 1, 1, "SAME", ldx=2048, ldy=144, ldw=144)
+            self.cm_wt = z(2048, 144)
+            self.cm_wsplit = torch.zeros(int(ops.conv2d_split3_weight_bytes(self._cm_d1)), dtype=torch.uint8,
+                                         device=sess.device)
+            self.cm_z = z(N * h * w, 144)
+            self.cm_gz = z(N * h * w, 144)
+            self.cm_dwt = z(2048, 144)
         # f16x3: split + transposed copies of the frozen kernels, refreshed when the store changes
         self._sp3 = {}
         self._sp3_bytes = 0
@@ -320,11 +330,38 @@ class ResNet50Model(object):
             if not last:
                 cur, nxt = nxt, cur
         fh, fw = self.feat_hw
-        _, _, scm, tcm = self._conv_bn(plan, self.scope + "/conv_map", self.xfinal, (h, w), 2048, 3, 4, 12, 1,
-                                       "VALID", self.raw_cm, None, training, save=True)
+        scm, tcm = self._conv_map_tap(plan, training)
         ops.bn_relu(plan, self.raw_cm, scm, tcm, self.output, N * fh * fw, 12, 12, 12)
         if self.stats is None or self.stats.numel() < self._stats_need:
             self.stats = self.session.zeros(self._stats_need)
+
+    def _conv_map_tap(self, plan, training):
+        """conv_map (3x4 VALID, 2048 -> 12) + BN statistics on the split-MFMA path: one GEMM over the INPUT pixels
+        with 12 taps x 12 channels = 144 columns, then a 12-tap gather (ops.tapconv_*); the kernel trains, so its
+        packed / split image is rebuilt in the plan (two tiny launches)"""
+        st = self.session.store
+        P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
+        cm = self.scope + "/conv_map"
+        d, d1 = self._cm_d, self._cm_d1
+        fh, fw = self.feat_hw
+        ops.tapconv_pack(plan, d, P(cm + "/weights"), self.cm_wt, 144)
+        ops.conv2d_split3_prepare(plan, d1, self.cm_wt, self.cm_wsplit)
+        ops.conv2d_fwd_split3(plan, d1, self.xfinal, self.cm_wsplit, self.cm_z)
+        rows = ops.tapconv_stats_rows(d)
+        self._stats_need = max(self._stats_need, rows * 2 * 12)
+        stats = ops.LazyPtr(lambda: self.stats)
+        ops.tapconv_gather(plan, d, self.cm_z, 144, self.raw_cm, stats if training else None)
+        if not hasattr(self, "_aff_cache"):
+            self._aff_cache = {}
+        if cm not in self._aff_cache:
+            self._aff_cache[cm] = self._new_affine(12)
+        sc, sh = self._aff_cache[cm]
+        b = cm + "/BatchNorm/"
+        ops.bn_finalize(plan, stats if training else None, rows if training else 0, 12, 12,
+                        self.N * fh * fw if training else 0, P(b + "gamma"), P(b + "beta"),
+                        P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, BN_DECAY, BN_EPS, training,
+                        self.save_mean, self.save_invstd)
+        return sc, sh
 
     def _record_forward(self, plan, training):
         if self.precision == "f16x3":
@@ -381,6 +418,12 @@ class ResNet50Model(object):
         ops.bn_relu_bwd(plan, self.raw_cm, self.output, self.g_output, P(cm + "/BatchNorm/gamma"),
                         self.save_mean, self.save_invstd, self.g_raw_cm, G(cm + "/BatchNorm/gamma"),
                         G(cm + "/BatchNorm/beta"), N * fh * fw, 12)
+        if self.precision == "f16x3":
+            # tap-GEMM form: dWt[2048][144] = xfinal^T . (tap-scattered g_raw_cm), then back to HWIO + the L2 term
+            ops.tapconv_scatter(plan, self._cm_d, self.g_raw_cm, 12, self.cm_gz, 144)
+            ops.conv2d_wgrad_split3(plan, self._cm_d1, self.xfinal, self.cm_gz, 144, self.cm_dwt, None)
+            ops.tapconv_unpack(plan, self._cm_d, self.cm_dwt, 144, P(cm + "/weights"), WEIGHT_DECAY, G(cm + "/weights"))
+            return
         d = ops.conv_desc(N, h, w, 2048, 12, 3, 4, 1, "VALID", ldx=2048, ldy=12, ldw=12)
         ops.conv2d_wgrad(plan, d, self.xfinal, self.g_raw_cm, 12, G(cm + "/weights"), None)
         ops.axpy(plan, WEIGHT_DECAY, P(cm + "/weights"), G(cm + "/weights"), 3 * 4 * 2048 * 12)

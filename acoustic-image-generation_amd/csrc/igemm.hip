@@ -262,6 +262,94 @@ __global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float* slab
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// "tap GEMM" form of a stride-1 VALID convolution with FEW output channels (conv_map: 3x4, 2048 -> 12):
+// as an implicit GEMM its N is one MFMA column and every output row gathers R*S*C inputs (no reuse across N:
+// L2-bound); instead Z[input pixel][tap*K + k] = X[input pixel][:] . W[tap][:][k] is ONE plain GEMM with
+// N = R*S*K columns that reads X once, and y[oh][ow][k] = sum_taps Z[oh+r][ow+s][tap*K + k] is a tiny gather.
+// The weight gradient is the same GEMM transposed: dWt = X^T . GZ with GZ the tap-scattered output gradient.
+// ------------------------------------------------------------------------------------------
+// wt[c][tap*K + k] = w[tap][c][k]
+__global__ __launch_bounds__(256) void tapconv_pack_kernel(const float* w, int taps, int C, int K, int ldw,
+                                                           float* wt, int ldwt) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int TK = taps * K;
+    if (idx >= (long)C * TK) return;
+    const int c = (int)(idx / TK), n = (int)(idx - (long)c * TK);
+    const int tap = n / K, k = n - tap * K;
+    wt[(long)c * ldwt + n] = w[((long)tap * C + c) * ldw + k];
+}
+
+// dw[tap][c][k] = dwt[c][tap*K + k] + decay * w[tap][c][k]
+__global__ __launch_bounds__(256) void tapconv_unpack_kernel(const float* dwt, int ldwt, int taps, int C, int K,
+                                                             int ldw, const float* w, float decay, float* dw) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)taps * C * K) return;
+    const int k = (int)(idx % K);
+    const long tc = idx / K;
+    const int c = (int)(tc % C), tap = (int)(tc / C);
+    float v = dwt[(long)c * ldwt + tap * K + k];
+    if (w) v = fmaf(decay, w[tc * ldw + k], v);
+    dw[tc * ldw + k] = v;
+}
+
+// y[(n,oh,ow)][k] = sum_{r,s} z[(n,oh+r,ow+s)][(r*S+s)*K + k]; 128 output pixels per workgroup, one thread per
+// (pixel, k); optional batch-norm partials stats[block][2][stats_ld] (rows past the end count as zeros)
+__global__ __launch_bounds__(256) void tapconv_gather_kernel(const float* z, int ldz, int H, int W, int R, int S,
+                                                             int K, int OH, int OW, long Mout, float* y, int ldy,
+                                                             float* stats, int stats_ld) {
+    extern __shared__ __attribute__((aligned(16))) float tg_smem[];     // [128][K] tile of outputs
+    const int ppb = 128;
+    const long m0 = (long)blockIdx.x * ppb;
+    for (int e = threadIdx.x; e < ppb * K; e += 256) {
+        const int pl = e / K, k = e - pl * K;
+        const long m = m0 + pl;
+        float acc = 0.f;
+        if (m < Mout) {
+            const int ow = (int)(m % OW);
+            const long t = m / OW;
+            const int oh = (int)(t % OH);
+            const long img = t / OH;
+            for (int r = 0; r < R; ++r)
+                for (int q = 0; q < S; ++q)
+                    acc += z[((img * H + oh + r) * W + ow + q) * ldz + (r * S + q) * K + k];
+            y[m * ldy + k] = acc;
+        }
+        tg_smem[e] = acc;
+    }
+    if (!stats) return;
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * K) {
+        const int which = threadIdx.x / K, k = threadIdx.x - which * K;
+        float sum = 0.f;
+        for (int pl = 0; pl < ppb; ++pl) {
+            const float v = tg_smem[pl * K + k];
+            sum += which ? v * v : v;
+        }
+        stats[((long)blockIdx.x * 2 + which) * stats_ld + k] = sum;
+    }
+}
+
+// gz[(n,ih,iw)][(r*S+s)*K + k] = gy[(n,ih-r,iw-s)][k] (0 outside the output)
+__global__ __launch_bounds__(256) void tapconv_scatter_kernel(const float* gy, int ldgy, int H, int W, int R, int S,
+                                                              int K, int OH, int OW, long Min, float* gz, int ldgz) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int TK = R * S * K;
+    if (idx >= Min * TK) return;
+    const long pix = idx / TK;
+    const int n = (int)(idx - pix * TK);
+    const int tap = n / K, k = n - tap * K;
+    const int r = tap / S, q = tap - r * S;
+    const int iw = (int)(pix % W);
+    const long t = pix / W;
+    const int ih = (int)(t % H);
+    const long img = t / H;
+    const int oh = ih - r, ow = iw - q;
+    float v = 0.f;
+    if ((unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW) v = gy[((img * OH + oh) * OW + ow) * ldgy + k];
+    gz[pix * ldgz + n] = v;
+}
+
 // column sums of G[rows][ld] (cols < ncols) -> out[ncols]; one block per 64 columns, 256 threads
 // = 4 row-groups x 64 columns.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* G, long rows, int ncols,
@@ -528,9 +616,13 @@ static TileCfg pick_cfg(int M, int Ngemm) {
 }
 
 static int pick_splits(int M, int Ngemm, TileCfg c, int kiters) {
+    // measured on the generator's 12x16 layers (192-288 tiles of 64x64, 36+ K steps: tools/splitk_sweep.sh):
+    // below ~1.25 workgroups per CU a K split towards ~3 per CU pays for its reduce pass
+    static const int cut = getenv("ACIMG_SPLITK_CUT") ? atoi(getenv("ACIMG_SPLITK_CUT")) : 320;
+    static const int target = getenv("ACIMG_SPLITK_TARGET") ? atoi(getenv("ACIMG_SPLITK_TARGET")) : 768;
     const long tiles = (long)cdiv(M, c.bm) * cdiv(Ngemm, c.bn);
-    if (tiles >= 192 || kiters < 8) return 1;
-    long s = (512 + tiles - 1) / tiles;
+    if (tiles >= cut || kiters < 8) return 1;
+    long s = (target + tiles - 1) / tiles;
     if (s > kiters / 4) s = kiters / 4;
     if (s > 64) s = 64;
     if (s < 1) s = 1;
@@ -1283,6 +1375,62 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
     else
         hipLaunchKernelGGL((igemm_split3d_kernel<128, 64, 2, 2, 256, 2, 2>), grid, dim3(256), lds_bytes, st, p);
     return check_launch("conv2d_fwd_split3p");
+}
+
+/* ---- tap-GEMM helpers (see the kernels above) ---- */
+static int tapconv_check(const AcimgConvDesc* d, const char* who) {
+    int rc = check_desc(d, who);
+    if (rc) return rc;
+    if (d->stride != 1 || d->pad_t || d->pad_l || d->OH != d->H - d->R + 1 || d->OW != d->W - d->S + 1)
+        return fail(ACIMG_EINVAL, "%s: stride-1 VALID convolutions only", who);
+    if (d->K > 64) return fail(ACIMG_EINVAL, "%s: K=%d > 64 (this form is for few output channels)", who, d->K);
+    return ACIMG_OK;
+}
+
+int acimg_tapconv_stats_rows(const AcimgConvDesc* d) { return cdiv(d->N * d->OH * d->OW, 128); }
+
+int acimg_tapconv_pack(const AcimgConvDesc* d, const float* w, float* wt, int ldwt, void* stream) {
+    int rc = tapconv_check(d, "tapconv_pack");
+    if (rc) return rc;
+    const int TK = d->R * d->S * d->K;
+    if (!w || !wt || ldwt < TK) return fail(ACIMG_EINVAL, "tapconv_pack: null pointer or ldwt < R*S*K");
+    hipLaunchKernelGGL(tapconv_pack_kernel, dim3(cdiv((long)d->C * TK, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       d->R * d->S, d->C, d->K, d->ldw, wt, ldwt);
+    return check_launch("tapconv_pack");
+}
+
+int acimg_tapconv_unpack(const AcimgConvDesc* d, const float* dwt, int ldwt, const float* w, float decay, float* dw,
+                         void* stream) {
+    int rc = tapconv_check(d, "tapconv_unpack");
+    if (rc) return rc;
+    const int TK = d->R * d->S * d->K;
+    if (!dwt || !dw || ldwt < TK) return fail(ACIMG_EINVAL, "tapconv_unpack: null pointer or ldwt < R*S*K");
+    hipLaunchKernelGGL(tapconv_unpack_kernel, dim3(cdiv((long)d->R * d->S * d->C * d->K, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dwt, ldwt, d->R * d->S, d->C, d->K, d->ldw, w, decay, dw);
+    return check_launch("tapconv_unpack");
+}
+
+int acimg_tapconv_gather(const AcimgConvDesc* d, const float* z, int ldz, float* y, float* stats, void* stream) {
+    int rc = tapconv_check(d, "tapconv_gather");
+    if (rc) return rc;
+    const int TK = d->R * d->S * d->K;
+    if (!z || !y || ldz < TK || d->ldy < d->K) return fail(ACIMG_EINVAL, "tapconv_gather: null pointer or ldz < R*S*K");
+    const long Mout = (long)d->N * d->OH * d->OW;
+    hipLaunchKernelGGL(tapconv_gather_kernel, dim3(cdiv(Mout, 128)), dim3(256), (size_t)128 * d->K * 4,
+                       (hipStream_t)stream, z, ldz, d->H, d->W, d->R, d->S, d->K, d->OH, d->OW, Mout, y, d->ldy, stats,
+                       d->ldw);
+    return check_launch("tapconv_gather");
+}
+
+int acimg_tapconv_scatter(const AcimgConvDesc* d, const float* gy, int ldgy, float* gz, int ldgz, void* stream) {
+    int rc = tapconv_check(d, "tapconv_scatter");
+    if (rc) return rc;
+    const int TK = d->R * d->S * d->K;
+    if (!gy || !gz || ldgz < TK || ldgy < d->K) return fail(ACIMG_EINVAL, "tapconv_scatter: null pointer or ldgz < R*S*K");
+    const long Min = (long)d->N * d->H * d->W;
+    hipLaunchKernelGGL(tapconv_scatter_kernel, dim3(cdiv(Min * TK, 256)), dim3(256), 0, (hipStream_t)stream, gy, ldgy,
+                       d->H, d->W, d->R, d->S, d->K, d->OH, d->OW, Min, gz, ldgz);
+    return check_launch("tapconv_scatter");
 }
 
 /* weight + bias gradient on the bf16x3 MFMA path (same contract as acimg_conv2d_wgrad) */

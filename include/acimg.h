@@ -291,6 +291,22 @@ int acimg_softplus_fwd(const float* x, int ldx, float* y, int ldy, int rows, int
 int acimg_softplus_bwd(const float* x, int ldx, const float* gy, int ldgy, float* gx, int ldgx, int rows, int C,
                        void* stream);
 
+/* "Tap GEMM" form of a stride-1 VALID convolution with few output channels (d->K <= 64; the trunk's conv_map,
+ * models/resnet50.py:205-209 / models/vision.py:60-66: 3x4, 2048 -> 12).  With T = R*S*K:
+ *   pack:    wt[c][tap*K + k] = w[tap][c][k]                 (then split / multiply it as a 1x1 conv C -> T)
+ *   gather:  y[(n,oh,ow)][k] = sum_taps z[(n,oh+r,ow+s)][tap*K + k]  from z = x . wt over the INPUT pixels;
+ *            optional batch-norm partials stats[acimg_tapconv_stats_rows(d)][2][d->ldw] (128 pixels per row)
+ *   scatter: gz[(n,ih,iw)][tap*K + k] = gy[(n,ih-r,iw-s)][k]  (0 outside), so that dwt = x^T . gz is a 1x1
+ *            weight gradient
+ *   unpack:  dw[tap][c][k] = dwt[c][tap*K + k] + decay * w[tap][c][k]   (w optional: slim's L2 term)
+ * d is the descriptor of the ORIGINAL convolution. */
+int acimg_tapconv_stats_rows(const AcimgConvDesc* d);
+int acimg_tapconv_pack(const AcimgConvDesc* d, const float* w, float* wt, int ldwt, void* stream);
+int acimg_tapconv_unpack(const AcimgConvDesc* d, const float* dwt, int ldwt, const float* w, float decay, float* dw,
+                         void* stream);
+int acimg_tapconv_gather(const AcimgConvDesc* d, const float* z, int ldz, float* y, float* stats, void* stream);
+int acimg_tapconv_scatter(const AcimgConvDesc* d, const float* gy, int ldgy, float* gz, int ldgz, void* stream);
+
 /* Cross-modal triplet losses over B embedding pairs e0[B][D], e1[B][D] with int32 labels / scenario per sample
  * (trainer/trainer_three.py): distances as `_pairwise_distances` :551-591 computes them (squared form,
  * D[i][j] = max(|e0_j|^2 - 2 <e0_i, e1_j> + |e1_i|^2, 0)); a pair (i, j) is "same video" when label and scenario

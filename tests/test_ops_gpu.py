@@ -766,3 +766,57 @@ def test_few_channel_direct_conv(device, case):
         ops.conv2d_dgrad(plan, d0, dev(gy, device), K, wd, dx, dev(res, device), Cc)
         torch.cuda.synchronize()
         close(dx, x.grad + res, what="direct dgrad %s" % (case,))
+
+
+def test_tapconv_matches_valid_conv(device):
+    """tap-GEMM form of a stride-1 VALID conv with few output channels (conv_map 3x4, C -> 12): forward incl. the
+    batch-norm partials, and the weight gradient incl. the L2 term, vs torch in fp64"""
+    from acimg import ops
+    g = torch.Generator().manual_seed(11)
+    N, H, W, Cin, K, R, S = 3, 7, 9, 64, 12, 3, 4
+    OH, OW, TK = H - R + 1, W - S + 1, R * S * K
+    x = rnd(g, N, H, W, Cin)
+    w = rnd(g, R, S, Cin, K) * 0.1
+    gy = rnd(g, N, OH, OW, K)
+    d = ops.conv_desc(N, H, W, Cin, K, R, S, 1, "VALID", ldx=Cin, ldy=K, ldw=K)
+    d1 = ops.conv_desc(N, H, W, Cin, TK, 1, 1, 1, "SAME", ldx=Cin, ldy=TK, ldw=TK)
+    plan = ops.Plan(device, eager=True)
+    xd, wd, gyd = dev(x, device), dev(w, device), dev(gy, device)
+    wt = torch.zeros(Cin, TK, device=device)
+    ops.tapconv_pack(plan, d, wd, wt, TK)
+    assert torch.equal(wt.cpu(), w.float().permute(2, 0, 1, 3).reshape(Cin, TK))
+    z = torch.zeros(N * H * W, TK, device=device)
+    ops.conv2d_fwd(plan, d1, xd, wt, None, z)                        # exact-f32 GEMM: isolates the gather
+    y = torch.zeros(N, OH, OW, K, device=device)
+    rows = ops.tapconv_stats_rows(d)
+    stats = torch.zeros(rows, 2, K, device=device)
+    ops.tapconv_gather(plan, d, z, TK, y, stats)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1)).permute(0, 2, 3, 1)
+    close(y, ref, tol=1e-5, what="tapconv forward")
+    flat = ref.reshape(-1, K)
+    close(stats[:, 0].sum(0), flat.sum(0), tol=1e-5, what="tapconv stats sum")
+    close(stats[:, 1].sum(0), (flat * flat).sum(0), tol=1e-5, what="tapconv stats sumsq")
+    gz = torch.zeros(N * H * W, TK, device=device)
+    ops.tapconv_scatter(plan, d, gyd, K, gz, TK)
+    dwt = torch.zeros(Cin, TK, device=device)
+    ops.conv2d_wgrad(plan, d1, xd, gz, TK, dwt, None)
+    dw = torch.zeros(R, S, Cin, K, device=device)
+    ops.tapconv_unpack(plan, d, dwt, TK, wd, 0.25, dw)
+    torch.cuda.synchronize()
+    wr = w.clone().requires_grad_(True)
+    out = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), wr.permute(3, 2, 0, 1)).permute(0, 2, 3, 1)
+    (out * gy).sum().backward()
+    close(dw, wr.grad + 0.25 * w, tol=1e-5, what="tapconv weight gradient + decay")
+    # split-MFMA GEMM in the middle (what the trunk records)
+    wsplit = torch.zeros(int(ops.conv2d_split3_weight_bytes(d1)), dtype=torch.uint8, device=device)
+    ops.conv2d_split3_prepare(plan, d1, wt, wsplit)
+    ops.conv2d_fwd_split3(plan, d1, xd, wsplit, z)
+    ops.tapconv_gather(plan, d, z, TK, y, None)
+    close(y, ref, tol=1e-4, what="tapconv forward (split MFMA)")
+    ops.conv2d_wgrad_split3(plan, d1, xd, gz, TK, dwt, None)
+    ops.tapconv_unpack(plan, d, dwt, TK, None, 0.0, dw)
+    torch.cuda.synchronize()
+    close(dw, wr.grad, tol=1e-4, what="tapconv weight gradient (split MFMA)")
+    L = __import__("acimg._lib", fromlist=["load"]).load()
+    bad = ops.conv_desc(N, H, W, Cin, K, R, S, 2, "VALID", ldx=Cin, ldy=K, ldw=K)
+    assert L.acimg_tapconv_pack(__import__("ctypes").byref(bad), wd.data_ptr(), wt.data_ptr(), TK, None) != 0
