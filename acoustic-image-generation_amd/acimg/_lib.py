@@ -67,6 +67,7 @@ PROTOTYPES = {
     "acimg_bn_relu": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "acimg_bn_relu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "acimg_pad_channels": (_I, [_P, _P, _L, _I, _I, _P]),
+    "acimg_pad_image": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "acimg_tile_mfcc": (_I, [_P, _P, _I, _I, _I, _P]),
     "acimg_minmax_workspace": (_SZ, [_I, _I, _I]),
     "acimg_minmax_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _SZ, _P]),

@@ -382,6 +382,11 @@ def pad_channels(plan, x, y, pixels, Cn, Cp):
     plan.add("pad_channels", _L().acimg_pad_channels, x, y, int(pixels), Cn, Cp)
 
 
+def pad_image(plan, x, y, N, H, W, Cn, Cp, Hp, Wp, pad_t, pad_l):
+    plan.add("pad_image", _L().acimg_pad_image, x, y, int(N), int(H), int(W), int(Cn), int(Cp), int(Hp), int(Wp),
+             int(pad_t), int(pad_l))
+
+
 def tile_mfcc(plan, mfcc, out, N, HW, Cn):
     plan.add("tile_mfcc", _L().acimg_tile_mfcc, mfcc, out, N, HW, Cn)
 

@@ -179,6 +179,12 @@ class ResNet50Model(object):
         self.stats = None
         self._stats_need = 0
         if self.precision == "f16x3":
+            # stem as a row-run conv on the split-MFMA kernel: zero-padded 4-channel frame (+ slack for the last run),
+            # kernel re-laid as [7][32 = 7 pixels x 4 channels + 4 zero rows][64]
+            self.stem_frame = z(N * (H + 6) * (W + 6) * 4 + 64)
+            self.stem_w = z(7, 1, 32, 64)
+            self._stem_d = ops.conv_desc(N, H + 6, W + 6, 32, 64, 7, 1, 2, "VALID", ldx=4, ldy=64, ldw=64)
+            self._stem_d.OH, self._stem_d.OW = oh1, ow1
             # conv_map as a tap GEMM (ops.tapconv_*): packed kernel, its split image, per-input-pixel products
             self._cm_d = ops.conv_desc(N, h, w, 2048, 12, 3, 4, 1, "VALID", ldx=2048, ldy=12, ldw=12)
             self._cm_d1 = ops.conv_desc(N, h, w, 2048, 144, 1, 1, 1, "SAME", ldx=2048, ldy=144, ldw=144)
@@ -244,6 +250,8 @@ class ResNet50Model(object):
         """host hook at the head of the forward plans: re-split the frozen kernels iff they changed"""
         st = self.session.store
         if self._sp3_bytes and self._sp3_version != st.version:
+            if self.precision == "f16x3":      # [7][7][4][64] -> [7][28 of 32][64] (parameter plumbing, load time only)
+                self.stem_w.view(7, 32, 64)[:, :28].copy_(st.p(self.scope + "/conv1/weights").reshape(7, 28, 64))
             self.plan_prepare.run()
             self._sp3_version = st.version
 
@@ -293,9 +301,8 @@ class ResNet50Model(object):
         N = self.N
         H, W = self.height, self.width
         plan.add_hook(self._refresh_split_weights)
-        ops.pad_channels(plan, self.images, self.xpad, N * H * W, 3, 4)
-        oh, ow, sc, sh = self._conv_bn(plan, self.scope + "/conv1", self.xpad, (H, W), 4, 7, 7, 64, 2, 3,
-                                       self.raw0, None, training)
+        ops.pad_image(plan, self.images, self.stem_frame, N, H, W, 3, 4, H + 6, W + 6, 3, 3)
+        oh, ow, sc, sh = self._stem_bn(plan, training)
         ph, pw = self.pool_hw
         _, pt = ops.same_out_pad(oh, 3, 2)
         _, pl = ops.same_out_pad(ow, 3, 2)
@@ -334,6 +341,35 @@ class ResNet50Model(object):
         ops.bn_relu(plan, self.raw_cm, scm, tcm, self.output, N * fh * fw, 12, 12, 12)
         if self.stats is None or self.stats.numel() < self._stats_need:
             self.stats = self.session.zeros(self._stats_need)
+
+    def _stem_bn(self, plan, training):
+        """conv1 (7x7/2 after 3+3 explicit zero padding) + BN statistics as a row-run conv (include/acimg.h,
+        acimg_conv2d_fwd_split3) on the split-MFMA kernel"""
+        st = self.session.store
+        P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
+        scope = self.scope + "/conv1"
+        d = self._stem_d
+        rows = ops.conv2d_fwd_split3_stats_rows(d)
+        self._stats_need = max(self._stats_need, rows * 2 * 64)
+        stats = ops.LazyPtr(lambda: self.stats)
+        if scope not in self._sp3:
+            off = self._sp3_bytes
+            self._sp3[scope] = off
+            self._sp3_bytes += -(-ops.conv2d_split3_weight_bytes(d) // 256) * 256
+            ops.conv2d_split3_prepare(self.plan_prepare, d, self.stem_w, ops.LazyPtr(lambda off=off: self.wsplit[off:]))
+        off = self._sp3[scope]
+        ops.conv2d_fwd_split3(plan, d, self.stem_frame, ops.LazyPtr(lambda off=off: self.wsplit[off:]), self.raw0,
+                              None, None, 0, stats if training else None)
+        if not hasattr(self, "_aff_cache"):
+            self._aff_cache = {}
+        if scope not in self._aff_cache:
+            self._aff_cache[scope] = self._new_affine(64)
+        sc, sh = self._aff_cache[scope]
+        b = scope + "/BatchNorm/"
+        ops.bn_finalize(plan, stats if training else None, rows if training else 0, 64, 64,
+                        self.N * d.OH * d.OW if training else 0, P(b + "gamma"), P(b + "beta"),
+                        P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, BN_DECAY, BN_EPS, training)
+        return d.OH, d.OW, sc, sh
 
     def _conv_map_tap(self, plan, training):
         """conv_map (3x4 VALID, 2048 -> 12) + BN statistics on the split-MFMA path: one GEMM over the INPUT pixels
@@ -430,10 +466,25 @@ class ResNet50Model(object):
 
     def record_regularizer(self, plan, accum):
         """adds sum(w^2) over every conv kernel of the scope into accum[0] (slim l2_regularizer terms
-        collected by tf.losses.get_total_loss, trainer/mfcctrainer.py:60)"""
+        collected by tf.losses.get_total_loss, trainer/mfcctrainer.py:60).  The trunk is frozen
+        (trainer/mfcctrainer.py:64), so its 23.5 M-element sum is computed when the parameters are (re)loaded and
+        only added here; conv_map trains and is summed every step."""
         st = self.session.store
-        ops.sumsq(plan, ops.LazyPtr(lambda: st.flat["trunkw"]), st._sizes["trunkw"], accum)
+        if not hasattr(self, "_trunk_ss"):
+            self._trunk_ss = self.session.zeros(4)
+            self._trunk_ss_version = -1
+            self._plan_reg = self.session.new_plan()
+            ops.zero(self._plan_reg, self._trunk_ss)
+            ops.sumsq(self._plan_reg, ops.LazyPtr(lambda: st.flat["trunkw"]), st._sizes["trunkw"], self._trunk_ss)
+        plan.add_hook(self._refresh_trunk_sumsq)
+        ops.axpy(plan, 1.0, self._trunk_ss, accum, 1)
         ops.sumsq(plan, ops.LazyPtr(lambda: st.p(self.scope + "/conv_map/weights")), 3 * 4 * 2048 * 12, accum)
+
+    def _refresh_trunk_sumsq(self):
+        st = self.session.store
+        if self._trunk_ss_version != st.version:
+            self._plan_reg.run()
+            self._trunk_ss_version = st.version
 
 
 def load_state_file(f):

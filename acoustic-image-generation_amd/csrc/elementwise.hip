@@ -298,6 +298,21 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const float* x, float
     }
 }
 
+// [N,H,W,C] -> interior of a zeroed [N,Hp,Wp,Cp] image at (pt, pl); the border and the pad channels are never
+// written (the caller zeroes the buffer once)
+__global__ __launch_bounds__(256) void pad_image_kernel(const float* x, float* y, int H, int W, int C, int Cp,
+                                                        int Hp, int Wp, int pt, int pl, long total) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const long p = idx / C;
+        const int w = (int)(p % W);
+        const long q = p / W;
+        const int h = (int)(q % H);
+        const long n = q / H;
+        y[((n * Hp + h + pt) * Wp + w + pl) * Cp + c] = x[idx];
+    }
+}
+
 __global__ __launch_bounds__(256) void tile_mfcc_kernel(const float* mfcc, float* out, int HW, int C,
                                                         long total) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -1023,6 +1038,16 @@ int acimg_pad_channels(const float* x, float* y, long pixels, int C, int Cp, voi
     hipLaunchKernelGGL(pad_channels_kernel, dim3(ew_grid(pixels * Cp)), dim3(256), 0,
                        (hipStream_t)stream, x, y, pixels, C, Cp);
     return check_launch("pad_channels");
+}
+
+int acimg_pad_image(const float* x, float* y, int N, int H, int W, int C, int Cp, int Hp, int Wp, int pad_t,
+                    int pad_l, void* stream) {
+    if (!x || !y || C > Cp || pad_t < 0 || pad_l < 0 || H + pad_t > Hp || W + pad_l > Wp)
+        return fail(ACIMG_EINVAL, "pad_image: the image does not fit the padded frame");
+    const long total = (long)N * H * W * C;
+    hipLaunchKernelGGL(pad_image_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, Cp,
+                       Hp, Wp, pad_t, pad_l, total);
+    return check_launch("pad_image");
 }
 
 int acimg_tile_mfcc(const float* mfcc, float* out, int N, int HW, int C, void* stream) {

@@ -816,12 +816,16 @@ static int launch_colsum(const float* G, long rows, int ncols, int ld, float* ou
 }
 static size_t colsum_ws_bytes(int ncols) { return (size_t)256 * ncols * sizeof(float); }
 
-static int check_desc(const AcimgConvDesc* d, const char* who) {
+// row_run: the caller's kernel accepts ldx < C with S == 1: the C "channels" of a tap are then a run of C / ldx
+// consecutive pixels of one input row (windows of neighbouring outputs overlap), see acimg_conv2d_fwd_split3
+static int check_desc(const AcimgConvDesc* d, const char* who, bool row_run = false) {
     if (!d) return fail(ACIMG_EINVAL, "%s: null descriptor", who);
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->OH <= 0 || d->OW <= 0 ||
         d->R <= 0 || d->S <= 0 || d->stride <= 0)
         return fail(ACIMG_EINVAL, "%s: non-positive dimension", who);
-    if ((d->C & 3) || (d->ldx & 3) || (d->ldw & 3) || d->ldx < d->C)
+    const bool run_view = row_run && d->S == 1 && d->pad_l == 0 && d->ldx > 0 && d->C % d->ldx == 0 &&
+                          (d->OW - 1) * d->stride + d->C / d->ldx <= d->W;
+    if ((d->C & 3) || (d->ldx & 3) || (d->ldw & 3) || (d->ldx < d->C && !run_view))
         return fail(ACIMG_EINVAL, "%s: C=%d ldx=%d ldw=%d must be multiples of 4 (ldx>=C)", who, d->C, d->ldx, d->ldw);
     if ((long)d->N * d->H * d->W * d->ldx >= (1L << 31) || (long)d->N * d->OH * d->OW * (long)d->ldy >= (1L << 31))
         return fail(ACIMG_EINVAL, "%s: tensor exceeds 2^31 elements", who);
@@ -1168,7 +1172,7 @@ size_t acimg_conv2d_split3_weight_bytes(const AcimgConvDesc* d) {
 }
 
 int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream) {
-    int rc = check_desc(d, "conv2d_split3_prepare");
+    int rc = check_desc(d, "conv2d_split3_prepare", true);
     if (rc) return rc;
     const int Ktot = d->R * d->S * d->C;
     hipLaunchKernelGGL((split3_prepare_kernel<SplitF16, false>), dim3(cdiv(Ktot, 32), cdiv(d->ldw, 32)), dim3(256), 0,
@@ -1216,7 +1220,7 @@ static void epi_vec_flag(EpiParams& e) {
 int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* wsplit, const float* bias,
                             float* y, const float* in_scale, const float* in_shift, int in_relu, float* stats,
                             void* stream) {
-    int rc = check_desc(d, "conv2d_fwd_split3");
+    int rc = check_desc(d, "conv2d_fwd_split3", true);
     if (rc) return rc;
     if (d->C % 32) return fail(ACIMG_EINVAL, "conv2d_fwd_split3: C=%d must be a multiple of 32", d->C);
     if (d->ldw < d->K || !aligned16(x) || !aligned16(wsplit))

@@ -86,6 +86,10 @@ size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d);
  * kernel: [hi|lo][ldw][R*S*C] fp16.  Semantics otherwise as acimg_conv2d_fwd (deferred BN on load, raw
  * output + statistics partials of acimg_conv2d_fwd_split3_stats_rows(d) rows; optional bias + d->act; no
  * split-K).
+ * Row-run view (this entry only): with S == 1 and pad_l == 0, ldx < C is accepted when C % ldx == 0 — the C
+ * "channels" of a tap are then the C / ldx consecutive pixels of an input row starting at ow*stride (windows of
+ * neighbouring outputs overlap; (OW-1)*stride + C/ldx <= W).  The 7x7/2 stem on a zero-padded 4-channel frame is
+ * such a conv: R = 7, S = 1, C = 32 = 7 pixels x 4 channels + one pixel of zero weights, ldx = 4.
  * Replaces: slim layers.conv2d / conv2d_same in the trunk, models/resnet50.py:109-121. */
 size_t acimg_conv2d_split3_weight_bytes(const AcimgConvDesc* d);
 int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream);
@@ -245,6 +249,12 @@ int acimg_bn_relu_bwd(const float* x, const float* y, const float* gy, const flo
 
 /* [N,H,W,3] -> [N,H,W,4] zero padded (stem input; lets the stem use 16-byte loads) */
 int acimg_pad_channels(const float* x, float* y, long pixels, int C, int Cp, void* stream);
+
+/* [N,H,W,C] -> the interior (at pad_t, pad_l) of a [N,Hp,Wp,Cp] frame the caller zeroed once: explicit zero
+ * padding for the stem (resnet_utils.conv2d_same pads 3 + 3 before the VALID 7x7/2, models/resnet50.py:205),
+ * so that the stem can run as a row-run convolution (acimg_conv2d_fwd_split3). */
+int acimg_pad_image(const float* x, float* y, int N, int H, int W, int C, int Cp, int Hp, int Wp, int pad_t,
+                    int pad_l, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Generator-side elementwise / reduction ops (models/unet_acresnet.py, trainer/mfcctrainer.py)

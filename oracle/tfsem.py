@@ -87,9 +87,18 @@ def batch_norm(x, gamma, beta, moving_mean, moving_var, training, decay=0.997, e
     return y, new_mm, new_mv, mean, var
 
 
-def minmax_norm(x, dims):
+def minmax_norm(x, dims, sel=None):
     """x - reduce_min; then / reduce_max of the shifted tensor (models/unet_acresnet.py:55-58).
-    torch.amin/amax split the gradient equally among ties, as TF's reduce_min/max do (App. B.8)."""
+    torch.amin/amax split the gradient equally among ties, as TF's reduce_min/max do (App. B.8).
+    sel = (argmin set, argmax set) as bool tensors prescribes WHICH elements are the minimum / maximum (taken from
+    the implementation under test, like the ReLU patterns of oracle/unet_acresnet.py:_relu): min and max are then the
+    means over those sets, i.e. the same values up to fp32 rounding and the same equal split of the gradient, so
+    that both sides differentiate the same piecewise-linear function when an element sits within rounding of the
+    minimum (a post-ReLU zero that is 1e-7 on one side)."""
+    if sel is not None:
+        mnm, mxm = sel[0].to(x.dtype), sel[1].to(x.dtype)
+        a = x - (x * mnm).sum(dim=dims, keepdim=True) / mnm.sum(dim=dims, keepdim=True)
+        return a / ((a * mxm).sum(dim=dims, keepdim=True) / mxm.sum(dim=dims, keepdim=True))
     a = x - x.amin(dim=dims, keepdim=True)
     return a / a.amax(dim=dims, keepdim=True)
 

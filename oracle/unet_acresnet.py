@@ -109,8 +109,9 @@ def _forward(p, inputs, resnetfeature, eps, num_skip, embedding, end_points):
     ep["layer2/conv_1"] = c
     conv2_0 = _c(p, "layer2/conv_2", c)
     ep.update(conv1=conv1, pool1=pool1, conv2_0=conv2_0)
-    conv2 = tfsem.minmax_norm(conv2_0, (1, 2, 3))
-    feat = tfsem.minmax_norm(resnetfeature, (1, 2, 3))
+    sel = _MASKS or {}     # optional prescribed argmin / argmax sets, see tfsem.minmax_norm
+    conv2 = tfsem.minmax_norm(conv2_0, (1, 2, 3), sel.get("minmax/conv2_0"))
+    feat = tfsem.minmax_norm(resnetfeature, (1, 2, 3), sel.get("minmax/feature"))
     conv2 = torch.cat((conv2, feat), dim=-1)
     ep["features"] = conv2
     n = inputs.shape[0]

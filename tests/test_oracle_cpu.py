@@ -104,6 +104,12 @@ def test_minmax_gradient_splits_ties():
     gmin, gmax = -(s1 - s2) / D / 2, -s2 / D / 2
     exp = np.array([1 / D + gmin, 2 / D + gmin, 3 / D, 4 / D + gmax, 5 / D + gmax])
     np.testing.assert_allclose(x.grad.numpy()[0], exp, rtol=1e-12)
+    # prescribed argmin / argmax sets (parity tests take them from the implementation under test): same result
+    x2 = x.detach().clone().requires_grad_(True)
+    o2 = tfsem.minmax_norm(x2, (1,), sel=(x2.detach() == 0.0, x2.detach() == 2.0))
+    o2.backward(torch.tensor([[1.0, 2.0, 3.0, 4.0, 5.0]], dtype=torch.float64))
+    assert torch.equal(o2.detach(), o.detach())
+    np.testing.assert_allclose(x2.grad.numpy()[0], exp, rtol=1e-12)
 
 
 def test_losses_reductions():

@@ -116,6 +116,10 @@ def test_train_step_matches_oracle(device, num_skip, embedding, precision):
         grads = store.grad_dict()
         # backward comparison: the oracle differentiates with the HIP run's ReLU on/off patterns
         masks = dict((k, v > 0) for k, v in acts.items())
+        # ... and the argmin / argmax sets of the two per-sample min-max normalisations (a post-ReLU zero that is
+        # 1e-7 on one side would otherwise become THE minimum there and take the whole reduce_min gradient)
+        for key, src in (("minmax/conv2_0", acts["layer2/conv_2"]), ("minmax/feature", acts["conv_map"])):
+            masks[key] = (src == src.amin(dim=(1, 2, 3), keepdim=True), src == src.amax(dim=(1, 2, 3), keepdim=True))
         ep = {}
         ref = orc.train_step(ac, mf, vid, eps, end_points=ep, keep_grads=True, relu_masks=masks)
         for k in ("mse", "huber", "latent", "reg", "loss"):
