@@ -516,12 +516,16 @@ __global__ __launch_bounds__(256) void direct_prepare_kernel(const DirectParams 
     wprep[i] = v;
 }
 
+// TR, TS, TC > 0: compile-time kernel extent / channel count (the tap and channel loops unroll completely: all the
+// pixel loads of a thread are in flight together and the weights arrive as batched scalar loads); 0: run-time
+template <int TR, int TS, int TC>
 __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectParams p, const float* __restrict__ wprep) {
     // the weight addresses below are wave-uniform: they become scalar loads (s_load_dwordx8), the FMAs take the
     // weights from SGPRs, no LDS and no vector-memory traffic for them
-    const int ntaps = p.R * p.S;
+    const int R = TR ? TR : p.R, S = TS ? TS : p.S, C = TC ? TC : p.C;
+    const int ntaps = R * S;
     const int kg = blockIdx.y * 8;
-    const float* __restrict__ wl = wprep + (long)blockIdx.y * ntaps * p.C * 8;
+    const float* __restrict__ wl = wprep + (long)blockIdx.y * ntaps * C * 8;
     const long m_raw = (long)blockIdx.x * 256 + threadIdx.x;
     const bool live = m_raw < p.M;
     const long m = live ? m_raw : p.M - 1;         // dead lanes recompute the last pixel and contribute nothing
@@ -533,17 +537,22 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectParams p, 
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
     const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
-    for (int r = 0; r < p.R; ++r) {
+    const float* const img = p.x + n * p.H * p.W * p.ldx;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
         const int ih = ih0 + r;
-        for (int q = 0; q < p.S; ++q) {
+        const int ihc = min(max(ih, 0), p.H - 1);
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
             const int iw = iw0 + q;
             const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const float* src = p.x + ((n * p.H + ih) * p.W + iw) * p.ldx;
-            const float* __restrict__ wt = wl + (r * p.S + q) * p.C * 8;
-            for (int c = 0; c < p.C; c += 4) {
-                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) xv = *reinterpret_cast<const float4*>(src + c);
-                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            // clamped address: the load is unconditional (and can be hoisted), padding taps are zeroed by select
+            const float* src = img + ((long)ihc * p.W + min(max(iw, 0), p.W - 1)) * p.ldx;
+            const float* __restrict__ wt = wl + (r * S + q) * C * 8;
+#pragma unroll
+            for (int c = 0; c < C; c += 4) {
+                float4 xv = *reinterpret_cast<const float4*>(src + c);
+                const float xs[4] = {ok ? xv.x : 0.f, ok ? xv.y : 0.f, ok ? xv.z : 0.f, ok ? xv.w : 0.f};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float4 w0 = *reinterpret_cast<const float4*>(wt + (c + i) * 8);
@@ -596,6 +605,12 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectParams p, 
         }
         o.x = apply_act(o.x, p.act); o.y = apply_act(o.y, p.act);
         o.z = apply_act(o.z, p.act); o.w = apply_act(o.w, p.act);
+        const int left = p.K - (kg + 4 * h);          // pad columns (K % 4 != 0) are written as zeros
+        if (left < 4) {
+            o.w = 0.f;
+            if (left < 3) o.z = 0.f;
+            if (left < 2) o.y = 0.f;
+        }
         *reinterpret_cast<float4*>(dst + 4 * h) = o;
     }
 }
@@ -752,7 +767,7 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
         return fail(ACIMG_EINVAL, "wgrad: operands must be 16-byte aligned");
     int bmo, bn;
     wgrad_tile(p.Ngemm, bmo, bn);
-    if (split3) bn = p.Ngemm > 64 ? 128 : 64;
+    if (split3) bn = p.Ngemm > 64 ? 128 : (p.Ngemm > 32 ? 64 : 32);
     p.splits = pick_wgrad_splits(p.M, p.KK, p.Ngemm, bmo, bn);
     int rps = cdiv(p.M, p.splits);
     rps = ((rps + 31) / 32) * 32;
@@ -773,7 +788,8 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
     const int rows = p.KK + (db ? 1 : 0);
     dim3 grid(cdiv(rows, bmo), cdiv(p.Ngemm, bn), p.splits);
     if (split3 && bn == 128) hipLaunchKernelGGL((wgrad_split3_kernel<128>), grid, dim3(256), 65536, st, p);
-    else if (split3) hipLaunchKernelGGL((wgrad_split3_kernel<64>), grid, dim3(256), 65536, st, p);
+    else if (split3 && bn == 64) hipLaunchKernelGGL((wgrad_split3_kernel<64>), grid, dim3(256), 65536, st, p);
+    else if (split3) hipLaunchKernelGGL((wgrad_split3_kernel<32>), grid, dim3(256), 65536, st, p);
     else if (bn == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, st, p);
     else if (bn == 64) hipLaunchKernelGGL((wgrad_f32_kernel<128, 64>), grid, dim3(256), 0, st, p);
     else if (bn == 32) hipLaunchKernelGGL((wgrad_f32_kernel<128, 32>), grid, dim3(256), 0, st, p);
@@ -845,17 +861,26 @@ extern "C" {
 // few-channel direct path: C <= 16 (wider pixels stop coalescing across lanes), K <= 32 and a multiple of 8
 static bool direct_ok(int C, int K, int ldy, int ldres, const float* y, const float* bias, const float* res,
                       bool affine, const float* mask) {
-    return !affine && !mask && C <= 16 && K <= 32 && (K & 7) == 0 && (C & 3) == 0 && (ldy & 3) == 0 &&
+    return !affine && !mask && C <= 16 && K <= 32 && ldy >= ((K + 3) & ~3) && (C & 3) == 0 && (ldy & 3) == 0 &&
            (!res || ((ldres & 3) == 0 && aligned16(res))) && aligned16(y) && (!bias || aligned16(bias));
 }
 static size_t direct_ws_bytes(int R, int S, int C, int K) { return ((size_t)R * S * C * K * sizeof(float) + 255) & ~(size_t)255; }
 static int launch_direct(const DirectParams& q, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!aligned16(q.x) || (q.ldx & 3)) return fail(ACIMG_EINVAL, "direct conv: input must be 16-byte aligned");
-    const int total = q.R * q.S * q.C * q.K;
+    const int total = q.R * q.S * q.C * ((q.K + 7) & ~7);
     if (!ws || ws_bytes < (size_t)total * sizeof(float)) return fail(ACIMG_EWORKSPACE, "direct conv: workspace too small");
     float* wprep = static_cast<float*>(ws);
     hipLaunchKernelGGL(direct_prepare_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, q, wprep, total);
-    hipLaunchKernelGGL(direct_conv_kernel, dim3(cdiv(q.M, 256), q.K / 8), dim3(256), 0, st, q, wprep);
+    const dim3 grid(cdiv(q.M, 256), cdiv(q.K, 8));
+#define ACIMG_DIRECT(RR, SS, CC) \
+    hipLaunchKernelGGL((direct_conv_kernel<RR, SS, CC>), grid, dim3(256), 0, st, q, wprep)
+    if (q.R == 3 && q.S == 3 && q.C == 4) ACIMG_DIRECT(3, 3, 4);
+    else if (q.R == 3 && q.S == 3 && q.C == 8) ACIMG_DIRECT(3, 3, 8);
+    else if (q.R == 3 && q.S == 3 && q.C == 16) ACIMG_DIRECT(3, 3, 16);
+    else if (q.R == 1 && q.S == 1 && q.C == 8) ACIMG_DIRECT(1, 1, 8);
+    else if (q.R == 2 && q.S == 2 && q.C == 8) ACIMG_DIRECT(2, 2, 8);
+    else ACIMG_DIRECT(0, 0, 0);
+#undef ACIMG_DIRECT
     return check_launch("direct_conv");
 }
 
@@ -1142,7 +1167,8 @@ struct Split3Cfg { int bm, bn; };
 // Tile choice, measured per trunk conv shape at batch 32 (tools/tune_dma.py): the 8-wave 128x128 tile
 // (2 workgroups/CU) wins on every shape with at least ~1 tile per CU; below that (the stride-2 3x3 conv into
 // the 14x19 stage: 134 tiles) 64x128 fills more CUs; Cout = 64 uses 128x64.
-static Split3Cfg pick_split3(int M, int K) {
+static Split3Cfg pick_split3(int M, int K, bool allow32 = false) {
+    if (K <= 32 && allow32) return {128, 32};     // on-the-fly kernel only (32-channel U-Net layers)
     if (K <= 64) return {128, 64};
     if (const char* ov = getenv("ACIMG_SPLIT3_TILE")) {   // experiments only: "BMxBN"
         int bm = 0, bn = 0;
@@ -1197,9 +1223,11 @@ int acimg_conv2d_split3_prepare_dgrad(const AcimgConvDesc* d, const float* w, vo
 extern "C++" {
 template <typename TR>
 static int launch_split3(IgemmParams& p, hipStream_t st) {
-    Split3Cfg c = pick_split3(p.M, p.Ngemm);
+    Split3Cfg c = pick_split3(p.M, p.Ngemm, true);
     dim3 grid(cdiv(p.M, c.bm), cdiv(p.Ngemm, c.bn), 1);
-    if (c.bm == 128 && c.bn == 128)
+    if (c.bm == 128 && c.bn == 32)
+        hipLaunchKernelGGL((igemm_split3_kernel<128, 32, 4, 1, 256, TR>), grid, dim3(256), 2 * (2 * 128 * 64 + 2 * 32 * 64), st, p);
+    else if (c.bm == 128 && c.bn == 128)
         hipLaunchKernelGGL((igemm_split3_kernel<128, 128, 2, 4, 512, TR>), grid, dim3(512), 65536, st, p);
     else if (c.bm == 64 && c.bn == 128)
         hipLaunchKernelGGL((igemm_split3_kernel<64, 128, 1, 4, 256, TR>), grid, dim3(256), 2 * (2 * 64 * 64 + 2 * 128 * 64), st, p);

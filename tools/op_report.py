@@ -1,5 +1,5 @@
 """Per-call report of the recorded train step, measured in place: every C-ABI call of the plan is bracketed with
-events (Plan.run_probed) over a few steps.  Run on the GPU box.  usage: python tools/op_report.py [batch] [first_call]"""
+events (Plan.run_probed) over a few steps.  Run on the GPU box.  usage: python tools/op_report.py [batch] [first_call] [trainer_mask|unet_rgb|unet_sound]"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "acoustic-image-generation_amd"))
@@ -12,19 +12,27 @@ from acimg.vision import ResNet50Model
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+workload = sys.argv[3] if len(sys.argv) > 3 else "trainer_mask"
 dev = torch.device("cuda:0")
-FLAGS.model = "UNet"
 sess = Session(dev)
-FLAGS.ae, FLAGS.num_skip_conn = 0, 1
-tr = Trainer(UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=1),
-             ResNet50Model(input_shape=[224, 298, 3], num_classes=None), learning_rate=1e-4, session=sess)
-g = tr._build_functions(batch_size=B)
-tr.modelimages.initialize(seed=1238)
-tr.modelac.initialize(seed=1239)
 gen = torch.Generator().manual_seed(1234)
-g.video.copy_(torch.rand(B, 224, 298, 3, generator=gen))
-g.mfcc.copy_(torch.rand(B, 12, generator=gen))
-g.acoustic.copy_(torch.rand(B, 36, 48, 12, generator=gen))
+if workload == "trainer_mask":
+    FLAGS.model, FLAGS.ae, FLAGS.num_skip_conn = "UNet", 0, 1
+    tr = Trainer(UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=1),
+                 ResNet50Model(input_shape=[224, 298, 3], num_classes=None), learning_rate=1e-4, session=sess)
+    g = tr._build_functions(batch_size=B)
+    tr.modelimages.initialize(seed=1238)
+    tr.modelac.initialize(seed=1239)
+    g.video.copy_(torch.rand(B, 224, 298, 3, generator=gen))
+    g.mfcc.copy_(torch.rand(B, 12, generator=gen))
+    g.acoustic.copy_(torch.rand(B, 36, 48, 12, generator=gen))
+else:
+    from acimg.trainer_vae import TrainerVAE
+    from acimg.unet_vae import UNet, UNetSound
+    tr = TrainerVAE((UNet if workload == "unet_rgb" else UNetSound)(), learning_rate=1e-4, session=sess)
+    g = tr._build_functions(batch_size=B)
+    tr.model.initialize(seed=1240)
+    g.images.copy_(torch.rand(*g.images.shape, generator=gen))
 for _ in range(3):
     tr.train_step(sync=False)
 torch.cuda.synchronize()
@@ -46,6 +54,8 @@ for i, (name, fn, a) in enumerate(plan.calls):
     d = getattr(a[0], "_obj", None)
     if d is not None and hasattr(d, "OH"):
         shape = "%dx%d %d->%d %dx%d/%d" % (d.H, d.W, d.C, d.K, d.R, d.S, d.stride)
+    elif name.startswith("bn_") or name in ("maxpool_fwd", "grad_slice"):
+        shape = " ".join(str(x) for x in a if isinstance(x, int))[:28]
     tot[name] = tot.get(name, [0, 0.0]); tot[name][0] += 1; tot[name][1] += acc[i]
     if i >= first:
         print("%4d %-24s %-28s %8.1f" % (i, name, shape, acc[i]))
