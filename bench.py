@@ -211,7 +211,7 @@ def main():
     f16 = args.precision == "f16x3"
     cand = {}
     for i, (name, fn, a) in enumerate(g.plan_train.calls):
-        if name in ("conv2d_fwd_split3", "conv2d_fwd_split3p") and f16:
+        if name == "conv2d_fwd_split3p" and f16:      # the trunk's pre-split LDS-DMA kernel (igemm_split3d_kernel)
             d = a[0]._obj
             key = ops.conv2d_fwd_split3_tiling(d)
         elif name == "conv2d_fwd" and not f16:
@@ -261,10 +261,12 @@ def main():
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "mfma_dtype": "f16 (3-term hi/lo split of fp32 operands, fp32 accumulate)" if f16 else "f32",
                 "hw_flop_factor": 3 if f16 else 1,
+                # matrix-core utilisation: the 3 MFMAs issued per algorithmic product, against the same peak
+                "hw_frac": achieved * (3 if f16 else 1) / peak,
                 # HBM bytes per launch of this kernel from the PMC pass committed under profiles/ (FETCH_SIZE x2 per
                 # the gfx950 correction + WRITE_SIZE, batch 32, f16x3): not re-measured by this run
-                "traffic": 252.5e6 if (f16 and B == 32 and tile[:2] == (128, 128)) else None,
-                "traffic_source": "profiles/r01/hbm_traffic_v7.txt" if (f16 and B == 32 and tile[:2] == (128, 128)) else None,
+                "traffic": 252.0e6 if (f16 and B == 32 and tile[:2] == (128, 128)) else None,
+                "traffic_source": "profiles/r01/hbm_traffic_v10.txt" if (f16 and B == 32 and tile[:2] == (128, 128)) else None,
                 "launches_per_step": len(probe_idx),
                 "avg_launch_ms": ms / len(events), "avg_launch_gflop": fl / len(events) / 1e9,
                 "share_of_step_time": (ms / args.steps) / (dt / args.steps * 1e3)}

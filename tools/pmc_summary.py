@@ -1,0 +1,40 @@
+"""HBM traffic per kernel from the two rocprofv3 --pmc passes of tools/pmc_traffic.sh (FETCH_SIZE, WRITE_SIZE; KB per
+dispatch).  FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (128-B requests of
+16-B/lane streams are tallied at 64 B).  usage: python tools/pmc_summary.py <dir with fetch/ and write/> [steps]"""
+import csv, os, sys, collections
+root = sys.argv[1]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+
+
+def load(sub, counter):
+    f = os.path.join(root, sub, "run_counter_collection.csv")
+    acc = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].replace("void ", "").replace("acimg::", "").split("(")[0]
+        a = acc.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return acc
+
+
+rd, wr = load("fetch", "FETCH_SIZE"), load("write", "WRITE_SIZE")
+rows = []
+for k, (n, kb) in rd.items():
+    wn, wkb = wr.get(k, [n, 0.0])
+    rmb = 2.0 * kb / n / 1e3            # KB -> MB, gfx950 correction x2
+    wmb = wkb / max(wn, 1) / 1e3
+    rows.append((k, n / steps, rmb, wmb, (rmb + wmb) * n / steps / 1e3))
+rows.sort(key=lambda r: -r[4])
+print("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
+      "(%d steps, batch 32)" % steps)
+print("FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests of 16-B/lane streams at 64 B); "
+      "MB per launch, averaged")
+print("%-62s %10s %14s %15s %12s" % ("kernel", "calls/step", "read MB/launch", "write MB/launch", "GB/step"))
+tot = 0.0
+for k, c, r, w, g in rows:
+    tot += g
+    if g >= 0.01:
+        print("%-62s %10.1f %14.1f %15.1f %12.2f" % (k[:62], c, r, w, g))
+print("total %.2f GB/step" % tot)
