@@ -301,15 +301,20 @@ __global__ __launch_bounds__(256) void pad_channels_kernel(const float* x, float
 // [N,H,W,C] -> interior of a zeroed [N,Hp,Wp,Cp] image at (pt, pl); the border and the pad channels are never
 // written (the caller zeroes the buffer once)
 __global__ __launch_bounds__(256) void pad_image_kernel(const float* x, float* y, int H, int W, int C, int Cp,
-                                                        int Hp, int Wp, int pt, int pl, long total) {
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int c = (int)(idx % C);
-        const long p = idx / C;
+                                                        int Hp, int Wp, int pt, int pl, long pixels) {
+    // one pixel per thread: C contiguous floats in, one (zero-padded) Cp-float pixel out
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (long)gridDim.x * 256) {
         const int w = (int)(p % W);
         const long q = p / W;
         const int h = (int)(q % H);
         const long n = q / H;
-        y[((n * Hp + h + pt) * Wp + w + pl) * Cp + c] = x[idx];
+        const float* src = x + p * C;
+        float* dst = y + ((n * Hp + h + pt) * Wp + w + pl) * Cp;
+        if (C == 3 && Cp == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(src[0], src[1], src[2], 0.f);
+        } else {
+            for (int c = 0; c < C; ++c) dst[c] = src[c];
+        }
     }
 }
 
@@ -1044,9 +1049,10 @@ int acimg_pad_image(const float* x, float* y, int N, int H, int W, int C, int Cp
                     int pad_l, void* stream) {
     if (!x || !y || C > Cp || pad_t < 0 || pad_l < 0 || H + pad_t > Hp || W + pad_l > Wp)
         return fail(ACIMG_EINVAL, "pad_image: the image does not fit the padded frame");
-    const long total = (long)N * H * W * C;
-    hipLaunchKernelGGL(pad_image_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, Cp,
-                       Hp, Wp, pad_t, pad_l, total);
+    const long pixels = (long)N * H * W;
+    if (C == 3 && Cp == 4 && !aligned16(y)) return fail(ACIMG_EINVAL, "pad_image: the frame must be 16-byte aligned");
+    hipLaunchKernelGGL(pad_image_kernel, dim3(ew_grid(pixels)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, Cp,
+                       Hp, Wp, pad_t, pad_l, pixels);
     return check_launch("pad_image");
 }
 

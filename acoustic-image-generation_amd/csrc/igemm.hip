@@ -758,6 +758,210 @@ static size_t wgrad_ws_bytes(int M, int KK, int Ngemm, int ldo) {
     return s > 1 ? (size_t)(s + 1) * ((size_t)KK + 1) * ldo * sizeof(float) : 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// few-channel weight gradient (C <= 16 input channels, <= 32 output channels; the full-resolution layers of the
+// RGB / spectrogram U-Nets: 72 x 8 ... 288 x 32 weights, millions of pixels).  As an implicit GEMM the im2col
+// gather re-reads x once per tap through L2 (9x for 3x3); here a workgroup stages an 8 x 32 output-pixel tile of
+// gy and the matching x tile WITH ITS HALO in LDS once and builds every tap from there:
+//   dW[kk][n] += x_patch(pixel, kk) * gy[pixel][n]   on exact-f32 MFMA (16x16x4: 16 kk rows x 16 columns x 4
+//   pixels), operands read from LDS per lane (ds_read_b32), the bias gradient as an all-ones row kk = KK.
+// Workgroups walk tiles grid-stride and keep their sums in registers; one partial slab per workgroup, then the
+// ordinary deterministic slab reduce.
+// ------------------------------------------------------------------------------------------
+struct WgradHaloParams {
+    const float* X; int H, W, C, ldx;
+    const float* G; int OH, OW, Kp, ldg;
+    int R, S, stride, pad_t, pad_l;
+    int XH, XW;                 // x tile extent incl. halo
+    int tiles_x, tiles_y; long tiles;
+    int KK;                     // R*S*C
+    float* out; float* db_out; int ldo;   // slabs [gridDim.x][KK][ldo], [gridDim.x][ldo]
+};
+constexpr int WH_TH = 8, WH_TW = 32, WH_MAXT = 10;
+
+// NT: 16-column tiles (1 or 2); NKT: 16-row tiles of (R*S*C + 1) the instance has accumulators for
+template <int NT, int NKT>
+__global__ __launch_bounds__(256, 3) void wgrad_halo_kernel(const WgradHaloParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wh_smem[];
+    const int xsz = p.XH * p.XW * p.C;
+    float* xs = wh_smem;                       // [XH][XW][C], then {1.0f, 0.0f, 0, 0}
+    float* gs = wh_smem + xsz + 4;             // [8][32][Kp]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int row16 = lane & 15, quad = lane >> 4;
+    const int nkt = (p.KK + 1 + 15) / 16;
+    // LDS offset of this lane's x element for row tile t, relative to the pixel's window origin; the bias row reads
+    // the constant 1, rows past it the constant 0 (absolute addresses: their pixel offset is masked away)
+    int xoff[NKT], xmask[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        const int kk = 16 * t + row16;
+        if (kk < p.KK) {
+            const int tap = kk / p.C, c = kk - tap * p.C;
+            const int r = tap / p.S, q = tap - r * p.S;
+            xoff[t] = (r * p.XW + q) * p.C + c;
+            xmask[t] = -1;
+        } else {
+            xoff[t] = xsz + (kk == p.KK ? 0 : 1);      // the constants 1 (bias row) and 0
+            xmask[t] = 0;
+        }
+    }
+    int bcol[NT];
+    bool bok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        bok[j] = row16 + 16 * j < p.Kp;
+        bcol[j] = min(row16 + 16 * j, p.Kp - 1);
+    }
+    f32x4 acc[NKT][NT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid == 0) {
+        xs[xsz] = 1.f;
+        xs[xsz + 1] = 0.f;
+    }
+    const int c4n = p.C >> 2, k4n = p.Kp >> 2;
+    const int c4sh = c4n == 1 ? 0 : (c4n == 2 ? 1 : 2);
+    // Software pipeline: the global loads of tile i+1 are issued (into registers) before tile i is multiplied, so
+    // every workgroup keeps a tile's worth of HBM requests in flight all the time.
+    // Staging is division-free and branch-free (stride 1, R, S <= 3: at most 10 x 34 x pixels): wave w takes x rows
+    // w, w+4, w+8, its lanes the row's float4s lane, lane+64, lane+128; every load goes to a clamped (valid) address
+    // and is zeroed by select, so all 9 + 4 loads of a thread are in flight together.
+    float4 xv[3][3], gv[2][2];
+    const int rowlen = p.XW << c4sh;
+    auto issue = [&](long tile) {
+        const int tx = (int)(tile % p.tiles_x);
+        const long t2 = tile / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y);
+        const long img = t2 / p.tiles_y;
+        const int oh0 = ty * WH_TH, ow0 = tx * WH_TW;
+        const int ih0 = oh0 * p.stride - p.pad_t, iw0 = ow0 * p.stride - p.pad_l;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int iy = wid + 4 * a;
+            const int ih = ih0 + iy;
+            const int ihc = min(max(ih, 0), p.H - 1);
+            const float* grow = p.X + ((img * p.H + ihc) * p.W) * p.ldx;
+#pragma unroll
+            for (int bq = 0; bq < 3; ++bq) {
+                const int e = lane + 64 * bq;
+                const int ix = e >> c4sh, c4 = e & (c4n - 1);
+                const int iw = iw0 + ix;
+                const bool ok = iy < p.XH && e < rowlen && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const float4 v = *reinterpret_cast<const float4*>(grow + (long)min(max(iw, 0), p.W - 1) * p.ldx + 4 * c4);
+                xv[a][bq] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int py = 2 * wid + half, px = lane & 31;
+            const int oh = oh0 + py, ow = ow0 + px;
+            const bool ok = oh < p.OH && ow < p.OW;
+            const float* gsrc = p.G + ((img * p.OH + min(oh, p.OH - 1)) * p.OW + min(ow, p.OW - 1)) * p.ldg;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k4 = (lane >> 5) + 2 * j;
+                const float4 v = *reinterpret_cast<const float4*>(gsrc + 4 * min(k4, k4n - 1));
+                gv[half][j] = ok && k4 < k4n ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int iy = wid + 4 * a;
+#pragma unroll
+            for (int bq = 0; bq < 3; ++bq) {
+                const int e = lane + 64 * bq;
+                if (iy < p.XH && e < rowlen)
+                    *reinterpret_cast<float4*>(xs + iy * p.XW * p.C + (e >> c4sh) * p.C + 4 * (e & (c4n - 1))) = xv[a][bq];
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k4 = (lane >> 5) + 2 * j;
+                if (k4 < k4n)
+                    *reinterpret_cast<float4*>(gs + ((2 * wid + half) * WH_TW + (lane & 31)) * p.Kp + 4 * k4) = gv[half][j];
+            }
+    };
+    issue(blockIdx.x);
+    for (long tile = blockIdx.x; tile < p.tiles; tile += gridDim.x) {
+        __syncthreads();                                   // the previous tile has been consumed
+        commit();
+        __syncthreads();
+        if (tile + gridDim.x < p.tiles) issue(tile + gridDim.x);
+        // this wave: tile rows 2*wid, 2*wid+1 = 64 pixels, 4 at a time (quad = which of the 4); all addresses
+        // advance incrementally (4 pixels per step, one row jump half way)
+        {
+            int xb = ((2 * wid) * p.XW + quad) * p.C;
+            const float* gp = gs + ((2 * wid) * WH_TW + quad) * p.Kp;
+#pragma unroll 4
+            for (int gq = 0; gq < 16; ++gq) {
+                float b[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float v = gp[bcol[j]];
+                    b[j] = bok[j] ? v : 0.f;
+                }
+#pragma unroll
+                for (int t = 0; t < NKT; ++t) {
+                    if (t < nkt) {
+                        const float a = xs[xoff[t] + (xb & xmask[t])];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[t][j], 0, 0, 0);
+                    }
+                }
+                gp += 4 * p.Kp;
+                xb += 4 * p.C + (gq == 7 ? (p.XW - WH_TW) * p.C : 0);
+            }
+        }
+    }
+    // the 4 waves add their sums in wave order (deterministic) in LDS: red[kk][NT*16]
+    __syncthreads();
+    float* red = wh_smem;
+    const int rw = NT * 16;
+    for (int w = 0; w < 4; ++w) {
+        if (wid == w) {
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) {
+                if (t < nkt) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float* dst = red + (16 * t + 4 * quad + i) * rw + 16 * j + row16;
+                            *dst = (w == 0 ? 0.f : *dst) + acc[t][j][i];
+                        }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = p.out + (long)blockIdx.x * p.KK * p.ldo;
+    for (int e = tid; e < (p.KK + 1) * p.Kp; e += 256) {
+        const int kk = e / p.Kp, n = e - kk * p.Kp;
+        const float v = red[kk * rw + n];
+        if (kk < p.KK) out[(long)kk * p.ldo + n] = v;
+        else if (p.db_out) p.db_out[(long)blockIdx.x * p.ldo + n] = v;
+    }
+}
+
+static size_t wgrad_halo_lds(int R, int S, int C, int Kp, int stride) {
+    const int XH = (WH_TH - 1) * stride + R, XW = (WH_TW - 1) * stride + S;
+    const size_t stage = ((size_t)XH * XW * C + 4 + (size_t)WH_TH * WH_TW * Kp) * sizeof(float);
+    const size_t red = (size_t)(((R * S * C + 1 + 15) / 16) * 16) * (Kp > 16 ? 32 : 16) * sizeof(float);
+    return stage > red ? stage : red;
+}
+static bool wgrad_halo_ok(const WgradParams& p) {
+    return (p.C == 4 || p.C == 8 || p.C == 16) && p.Nld <= 16 && p.Ngemm == p.Nld && p.stride == 1 && p.R <= 3 && p.S <= 3 && (long)p.M >= 65536 && (p.ldx & 3) == 0 && (p.ldg & 3) == 0 &&
+           (p.KK + 1 + 15) / 16 <= WH_MAXT && wgrad_halo_lds(p.R, p.S, p.C, p.Nld, p.stride) <= 65536 &&
+           !getenv("ACIMG_NO_WGRAD_HALO");
+}
+
 // db (optional): fused bias gradient, db[n] = sum_m G[m][n] for n < Ngemm
 static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t st,
                         bool split3 = false) {
@@ -767,6 +971,41 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
         return fail(ACIMG_EINVAL, "wgrad: operands must be 16-byte aligned");
     int bmo, bn;
     wgrad_tile(p.Ngemm, bmo, bn);
+    if (wgrad_halo_ok(p)) {
+        WgradHaloParams q{};
+        q.X = p.X; q.H = p.H; q.W = p.W; q.C = p.C; q.ldx = p.ldx;
+        q.G = p.G; q.OH = p.OH; q.OW = p.OW; q.Kp = p.Nld; q.ldg = p.ldg;
+        q.R = p.R; q.S = p.S; q.stride = p.stride; q.pad_t = p.pad_t; q.pad_l = p.pad_l;
+        q.XH = (WH_TH - 1) * p.stride + p.R; q.XW = (WH_TW - 1) * p.stride + p.S;
+        q.tiles_x = cdiv(p.OW, WH_TW); q.tiles_y = cdiv(p.OH, WH_TH);
+        q.tiles = (long)(p.M / (p.OH * p.OW)) * q.tiles_x * q.tiles_y;
+        q.KK = p.KK; q.ldo = p.ldo;
+        int nb = pick_wgrad_splits(p.M, p.KK, p.Ngemm, bmo, bn);     // = what the workspace was sized for
+        if (nb > 768) nb = 768;                                      // 3 resident workgroups per CU, each pipelined
+        if (nb > q.tiles) nb = (int)q.tiles;
+        if (nb < 2) nb = 2;
+        const size_t need = (size_t)nb * ((size_t)p.KK + 1) * p.ldo * sizeof(float);
+        if (ws == nullptr || ws_bytes < need) return fail(ACIMG_EWORKSPACE, "wgrad: workspace %zu < %zu", ws_bytes, need);
+        q.out = static_cast<float*>(ws);
+        float* db_slab = q.out + (size_t)nb * p.KK * p.ldo;
+        q.db_out = db ? db_slab : nullptr;
+        const size_t lds = wgrad_halo_lds(p.R, p.S, p.C, p.Nld, p.stride);
+        const int nkt = (p.KK + 1 + 15) / 16;
+#define ACIMG_WH(NTv, NKTv) hipLaunchKernelGGL((wgrad_halo_kernel<NTv, NKTv>), dim3(nb), dim3(256), lds, st, q)
+        if (p.Nld > 16) {
+            if (nkt <= 1) ACIMG_WH(2, 1); else if (nkt <= 3) ACIMG_WH(2, 3); else if (nkt <= 5) ACIMG_WH(2, 5); else ACIMG_WH(2, 10);
+        } else {
+            if (nkt <= 1) ACIMG_WH(1, 1); else if (nkt <= 3) ACIMG_WH(1, 3); else if (nkt <= 5) ACIMG_WH(1, 5); else ACIMG_WH(1, 10);
+        }
+#undef ACIMG_WH
+        int rc = check_launch("wgrad_halo");
+        if (rc) return rc;
+        const long total = (long)p.KK * p.Ngemm;
+        const int nb1 = (int)cdiv(total, 32), nb2 = db ? cdiv(p.Ngemm, 32) : 0;
+        hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(nb1 + nb2), dim3(256), 0, st, q.out, nb, (long)p.KK, p.Ngemm,
+                           p.ldo, dw, nb1, db_slab, db);
+        return check_launch("wgrad_reduce");
+    }
     if (split3) bn = p.Ngemm > 64 ? 128 : (p.Ngemm > 32 ? 64 : 32);
     p.splits = pick_wgrad_splits(p.M, p.KK, p.Ngemm, bmo, bn);
     int rps = cdiv(p.M, p.splits);
