@@ -788,7 +788,6 @@ __global__ __launch_bounds__(256, 3) void wgrad_halo_kernel(const WgradHaloParam
     float* gs = wh_smem + xsz + 4;             // [8][32][Kp]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int row16 = lane & 15, quad = lane >> 4;
-    const int nkt = (p.KK + 1 + 15) / 16;
     // LDS offset of this lane's x element for row tile t, relative to the pixel's window origin; the bias row reads
     // the constant 1, rows past it the constant 0 (absolute addresses: their pixel offset is masked away)
     int xoff[NKT], xmask[NKT];
@@ -806,10 +805,10 @@ __global__ __launch_bounds__(256, 3) void wgrad_halo_kernel(const WgradHaloParam
         }
     }
     int bcol[NT];
-    bool bok[NT];
+    float bscale[NT];               // columns past Kp multiply a valid (finite) element by 0
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        bok[j] = row16 + 16 * j < p.Kp;
+        bscale[j] = row16 + 16 * j < p.Kp ? 1.f : 0.f;
         bcol[j] = min(row16 + 16 * j, p.Kp - 1);
     }
     f32x4 acc[NKT][NT];
@@ -896,27 +895,35 @@ __global__ __launch_bounds__(256, 3) void wgrad_halo_kernel(const WgradHaloParam
         // this wave: tile rows 2*wid, 2*wid+1 = 64 pixels, 4 at a time (quad = which of the 4); all addresses
         // advance incrementally (4 pixels per step, one row jump half way)
         {
+            // register double buffer: the LDS reads of step g+1 are issued before the MFMAs of step g (all NKT row
+            // tiles unconditionally - rows past KK + 1 read the constant 0 - so the loop has no branch)
             int xb = ((2 * wid) * p.XW + quad) * p.C;
             const float* gp = gs + ((2 * wid) * WH_TW + quad) * p.Kp;
-#pragma unroll 4
-            for (int gq = 0; gq < 16; ++gq) {
-                float b[NT];
+            float a[2][NKT], b[2][NT];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const float v = gp[bcol[j]];
-                    b[j] = bok[j] ? v : 0.f;
-                }
+            for (int t = 0; t < NKT; ++t) a[0][t] = xs[xoff[t] + (xb & xmask[t])];
 #pragma unroll
-                for (int t = 0; t < NKT; ++t) {
-                    if (t < nkt) {
-                        const float a = xs[xoff[t] + (xb & xmask[t])];
+            for (int j = 0; j < NT; ++j) b[0][j] = gp[bcol[j]] * bscale[j];
+#pragma unroll 1
+            for (int g2 = 0; g2 < 8; ++g2) {            // two steps per trip: buffers 0 -> 1 -> 0
+#pragma unroll
+                for (int cur = 0; cur < 2; ++cur) {
+                    const int nxt = cur ^ 1;
+                    const int gq = 2 * g2 + cur;
+                    if (gq < 15) {
+                        gp += 4 * p.Kp;
+                        xb += 4 * p.C + (gq == 7 ? (p.XW - WH_TW) * p.C : 0);
+#pragma unroll
+                        for (int t = 0; t < NKT; ++t) a[nxt][t] = xs[xoff[t] + (xb & xmask[t])];
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) b[nxt][j] = gp[bcol[j]] * bscale[j];
+                    }
+#pragma unroll
+                    for (int t = 0; t < NKT; ++t)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
-                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[t][j], 0, 0, 0);
-                    }
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][t], b[cur][j], acc[t][j], 0, 0, 0);
                 }
-                gp += 4 * p.Kp;
-                xb += 4 * p.C + (gq == 7 ? (p.XW - WH_TW) * p.C : 0);
             }
         }
     }
@@ -928,15 +935,13 @@ __global__ __launch_bounds__(256, 3) void wgrad_halo_kernel(const WgradHaloParam
         if (wid == w) {
 #pragma unroll
             for (int t = 0; t < NKT; ++t) {
-                if (t < nkt) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
+                for (int j = 0; j < NT; ++j)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            float* dst = red + (16 * t + 4 * quad + i) * rw + 16 * j + row16;
-                            *dst = (w == 0 ? 0.f : *dst) + acc[t][j][i];
-                        }
-                }
+                    for (int i = 0; i < 4; ++i) {
+                        float* dst = red + (16 * t + 4 * quad + i) * rw + 16 * j + row16;
+                        *dst = (w == 0 ? 0.f : *dst) + acc[t][j][i];
+                    }
             }
         }
         __syncthreads();
@@ -953,7 +958,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_halo_kernel(const WgradHaloParam
 static size_t wgrad_halo_lds(int R, int S, int C, int Kp, int stride) {
     const int XH = (WH_TH - 1) * stride + R, XW = (WH_TW - 1) * stride + S;
     const size_t stage = ((size_t)XH * XW * C + 4 + (size_t)WH_TH * WH_TW * Kp) * sizeof(float);
-    const size_t red = (size_t)(((R * S * C + 1 + 15) / 16) * 16) * (Kp > 16 ? 32 : 16) * sizeof(float);
+    const size_t red = (size_t)WH_MAXT * 16 * (Kp > 16 ? 32 : 16) * sizeof(float);   // any instance's [16*NKT][16*NT]
     return stage > red ? stage : red;
 }
 static bool wgrad_halo_ok(const WgradParams& p) {
@@ -992,11 +997,11 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
         const size_t lds = wgrad_halo_lds(p.R, p.S, p.C, p.Nld, p.stride);
         const int nkt = (p.KK + 1 + 15) / 16;
 #define ACIMG_WH(NTv, NKTv) hipLaunchKernelGGL((wgrad_halo_kernel<NTv, NKTv>), dim3(nb), dim3(256), lds, st, q)
-        if (p.Nld > 16) {
-            if (nkt <= 1) ACIMG_WH(2, 1); else if (nkt <= 3) ACIMG_WH(2, 3); else if (nkt <= 5) ACIMG_WH(2, 5); else ACIMG_WH(2, 10);
-        } else {
-            if (nkt <= 1) ACIMG_WH(1, 1); else if (nkt <= 3) ACIMG_WH(1, 3); else if (nkt <= 5) ACIMG_WH(1, 5); else ACIMG_WH(1, 10);
-        }
+        if (nkt <= 1) ACIMG_WH(1, 1);
+        else if (nkt <= 2) ACIMG_WH(1, 2);
+        else if (nkt <= 3) ACIMG_WH(1, 3);
+        else if (nkt <= 5) ACIMG_WH(1, 5);
+        else ACIMG_WH(1, 10);
 #undef ACIMG_WH
         int rc = check_launch("wgrad_halo");
         if (rc) return rc;
