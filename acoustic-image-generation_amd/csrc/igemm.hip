@@ -736,7 +736,8 @@ static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipSt
 static int pick_wgrad_splits(int M, int KK, int Ngemm, int bmo, int bn) {
     const long tiles = (long)cdiv(KK, bmo) * cdiv(Ngemm, bn);
     long s = (512 + tiles - 1) / tiles;   // ~2 workgroups per CU; every split costs a KK x N slab round trip
-    const long maxs = (M + 255) / 256;  // at least 256 pixels per split
+    static const int minpix = getenv("ACIMG_WGRAD_MINPIX") ? atoi(getenv("ACIMG_WGRAD_MINPIX")) : 128;
+    const long maxs = (M + minpix - 1) / minpix;  // at least `minpix` pixels per split
     long cap = 128;
     if ((long)KK * Ngemm <= 8192) {       // few-channel layers (the RGB / spectrogram U-Nets: 72 x 8 ... 288 x 32
         s = (2048 + tiles - 1) / tiles;   // weights, millions of pixels): slabs are a few KB, the pixel stream is
