@@ -34,7 +34,8 @@ class ResNet50Model(object):
 
     def __init__(self, input_shape=None, num_classes=None, precision="f16x3"):
         """precision: arithmetic of the frozen trunk convs — "f16x3" (split-fp16 MFMA, fp32-class
-        results, default) or "f32" (exact-f32 MFMA).  conv1 (C=3) and conv_map always use f32."""
+        results, default) or "f32" (exact-f32 MFMA).  With "f16x3" the stem runs as a row-run conv and conv_map as a
+        tap GEMM on the same split-MFMA kernels (_stem_bn, _conv_map_tap)."""
         self.scope = 'resnet_v1_50'
         assert precision in ("f16x3", "f32")
         self.precision = precision
