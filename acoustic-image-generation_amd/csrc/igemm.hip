@@ -533,9 +533,10 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectParams p, 
     const long t = m / p.OW;
     const int oh = (int)(t % p.OH);
     const long n = t / p.OH;
-    float acc[8];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int k = 0; k < 4; ++k) acc2[k] = f32x2{0.f, 0.f};
     const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
     const float* const img = p.x + n * p.H * p.W * p.ldx;
 #pragma unroll
@@ -555,19 +556,22 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(const DirectParams p, 
                 const float xs[4] = {ok ? xv.x : 0.f, ok ? xv.y : 0.f, ok ? xv.z : 0.f, ok ? xv.w : 0.f};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float4 w0 = *reinterpret_cast<const float4*>(wt + (c + i) * 8);
-                    const float4 w1 = *reinterpret_cast<const float4*>(wt + (c + i) * 8 + 4);
-                    acc[0] = fmaf(xs[i], w0.x, acc[0]);
-                    acc[1] = fmaf(xs[i], w0.y, acc[1]);
-                    acc[2] = fmaf(xs[i], w0.z, acc[2]);
-                    acc[3] = fmaf(xs[i], w0.w, acc[3]);
-                    acc[4] = fmaf(xs[i], w1.x, acc[4]);
-                    acc[5] = fmaf(xs[i], w1.y, acc[5]);
-                    acc[6] = fmaf(xs[i], w1.z, acc[6]);
-                    acc[7] = fmaf(xs[i], w1.w, acc[7]);
+                    // packed fp32 FMAs (v_pk_fma_f32: two accumulators per instruction, same rounding as fmaf)
+                    const f32x2 xx = {xs[i], xs[i]};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x2 ww = *reinterpret_cast<const f32x2*>(wt + (c + i) * 8 + 2 * j);
+                        acc2[j] = __builtin_elementwise_fma(xx, ww, acc2[j]);
+                    }
                 }
             }
         }
+    }
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        acc[2 * k] = acc2[k][0];
+        acc[2 * k + 1] = acc2[k][1];
     }
     if (p.stats) {
         // batch-norm partials of this 256-pixel row block (conv + bias, before any activation): lanes -> waves -> LDS
