@@ -92,7 +92,46 @@ def _resolve(a):
         return a.ws.ptr
     if isinstance(a, _WsBytes):
         return a.ws.nbytes
+    if isinstance(a, _JobsArg):
+        return a.value()
     return a
+
+
+class PrepareJobs(object):
+    """Kernels whose split images one acimg_conv2d_split3_prepare_multi launch rebuilds: (descriptor, fp32 kernel,
+    image buffer, mode 0 forward / 1 data gradient).  The ctypes tables are built when the plan is finalised, so
+    jobs may still be added after the launch has been recorded."""
+
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, d, w, out, mode):
+        self.jobs.append((d, w, out, int(mode)))
+
+    def build(self):
+        n = len(self.jobs)
+        assert n <= 16, "conv2d_split3_prepare_multi takes at most 16 jobs (%d)" % n
+        self._d = (C.POINTER(ConvDesc) * n)(*[C.pointer(j[0]) for j in self.jobs])
+        self._w = (C.c_void_p * n)(*[_resolve(j[1]) for j in self.jobs])
+        self._o = (C.c_void_p * n)(*[_resolve(j[2]) for j in self.jobs])
+        self._m = (C.c_int * n)(*[j[3] for j in self.jobs])
+        # several plans may replay this launch (each resolves its own copy of the arguments): every generation of
+        # the tables stays alive
+        self._keep = getattr(self, "_keep", [])
+        self._keep.append((self._d, self._w, self._o, self._m))
+        return n
+
+
+class _JobsArg(object):
+    __slots__ = ("jobs", "which")
+
+    def __init__(self, jobs, which):
+        self.jobs, self.which = jobs, which
+
+    def value(self):
+        if self.which == "n":
+            return self.jobs.build()
+        return C.addressof(getattr(self.jobs, "_" + self.which))
 
 
 def current_stream_handle(device=None):
@@ -264,6 +303,12 @@ def conv2d_fwd_split3_tiling(d):
 
 def conv2d_split3_prepare(plan, d, w, wsplit):
     plan.add("conv2d_split3_prepare", _L().acimg_conv2d_split3_prepare, C.byref(d), w, wsplit)
+
+
+def conv2d_split3_prepare_multi(plan, jobs):
+    """one launch for all of `jobs` (a PrepareJobs; the first argument resolved builds the tables)"""
+    plan.add("conv2d_split3_prepare_multi", _L().acimg_conv2d_split3_prepare_multi, _JobsArg(jobs, "n"),
+             _JobsArg(jobs, "d"), _JobsArg(jobs, "w"), _JobsArg(jobs, "o"), _JobsArg(jobs, "m"))
 
 
 def conv2d_fwd_split3(plan, d, x, wsplit, y, in_scale=None, in_shift=None, in_relu=0, stats=None, bias=None):

@@ -230,13 +230,23 @@ class UNetAc(object):
             self._wsplit_bufs[key] = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.session.device)
         return self._wsplit_bufs[key]
 
+    def _prepare_job(self, plan, d, name, image, mode):
+        """the kernels change every step: ONE launch at the head of the forward plan re-splits them all (forward
+        images and, once the backward is recorded, the flipped / transposed data-gradient images)"""
+        if getattr(self, "_prep_jobs", None) is None:
+            # a plan other than the forward one (should not happen): fall back to a launch in place
+            (ops.conv2d_split3_prepare_dgrad if mode else ops.conv2d_split3_prepare)(plan, d, self._P(name + "/kernel"),
+                                                                                      image)
+            return
+        self._prep_jobs.add(d, self._P(name + "/kernel"), image, mode)
+
     def _conv(self, plan, name, x, y, stride=1, act=ACT_RELU):
         d = self._desc(x, y.C, stride, y, act)
         self._descs[name] = (d, x, y)
         if self._use_split(d):
             # the kernel changes every step: re-split it right before use (one tiny launch)
             ws = self._wsplit(name, ops.conv2d_split3_weight_bytes(d), "fwd")
-            ops.conv2d_split3_prepare(plan, d, self._P(name + "/kernel"), ws)
+            self._prepare_job(plan, d, name, ws, 0)
             ops.conv2d_fwd_split3(plan, d, x.ptr, ws, y.ptr, bias=self._P(name + "/bias"))
         else:
             ops.conv2d_fwd(plan, d, x.ptr, self._P(name + "/kernel"), self._P(name + "/bias"), y.ptr)
@@ -245,6 +255,10 @@ class UNetAc(object):
         N = self.N
         self._descs = {}
         h, w = self.pool1.H, self.pool1.W
+        self._prep_jobs = None
+        if self.precision == "split":
+            self._prep_jobs = ops.PrepareJobs()
+            ops.conv2d_split3_prepare_multi(plan, self._prep_jobs)
         self._conv(plan, "layer1/conv_1", self.inp, self.c11)
         self._conv(plan, "layer1/conv_2", self.c11, self.conv1)
         self._conv(plan, "layer1/pool_2", self.conv1, self.pool1, stride=3)
@@ -302,7 +316,7 @@ class UNetAc(object):
             wg(plan, d, x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
             if dx is not None and self._use_split(d):
                 wt = self._wsplit(name, ops.conv2d_split3_dgrad_weight_bytes(d), "dgrad")
-                ops.conv2d_split3_prepare_dgrad(plan, d, self._P(name + "/kernel"), wt)
+                self._prepare_job(plan, d, name, wt, 1)
                 ops.conv2d_dgrad_split3(plan, d, gy.ptr, gy.ld, wt, dx.ptr,
                                         res.ptr if res is not None else None, res.ld if res is not None else 0,
                                         mask.ptr if mask is not None else None, mask.ld if mask is not None else 0,

@@ -1469,6 +1469,43 @@ int acimg_conv2d_split3_prepare_dgrad(const AcimgConvDesc* d, const float* w, vo
     return check_launch("split3_prepare_dgrad");
 }
 
+/* all of a model's trainable kernels in one launch: mode[i] = 0 forward image (acimg_conv2d_split3_prepare), 1 data-
+ * gradient image (acimg_conv2d_split3_prepare_dgrad) */
+int acimg_conv2d_split3_prepare_multi(int n, const AcimgConvDesc* const* descs, const float* const* w, void* const* out,
+                                      const int* mode, void* stream) {
+    if (n == 0) return ACIMG_OK;
+    if (n < 0 || n > 16 || !descs || !w || !out || !mode)
+        return fail(ACIMG_EINVAL, "conv2d_split3_prepare_multi: need 0..16 jobs and non-null tables");
+    PrepJobs jobs{};
+    jobs.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const AcimgConvDesc* d = descs[i];
+        int rc = check_desc(d, "conv2d_split3_prepare_multi", true);
+        if (rc) return rc;
+        if (!w[i] || !out[i]) return fail(ACIMG_EINVAL, "conv2d_split3_prepare_multi: null pointer in job %d", i);
+        PrepJob& J = jobs.j[i];
+        J.w = w[i]; J.out = out[i]; J.ntaps = d->R * d->S; J.C = d->C; J.K = d->K; J.ldw = d->ldw;
+        J.dgrad = mode[i] ? 1 : 0;
+        int tiles_n;
+        if (J.dgrad) {
+            if (d->K % 32 || d->K > d->ldw)
+                return fail(ACIMG_EINVAL, "conv2d_split3_prepare_multi: job %d: K must be a multiple of 32", i);
+            J.Nrows = d->C;
+            J.tiles_k = cdiv(d->R * d->S * d->K, 32);
+            tiles_n = cdiv(d->C, 32);
+        } else {
+            J.Nrows = d->ldw;
+            J.tiles_k = cdiv(d->R * d->S * d->C, 32);
+            tiles_n = cdiv(d->ldw, 32);
+        }
+        J.block0 = blocks;
+        blocks += J.tiles_k * tiles_n;
+    }
+    hipLaunchKernelGGL(split3_prepare_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs);
+    return check_launch("split3_prepare_multi");
+}
+
 extern "C++" {
 template <typename TR>
 static int launch_split3(IgemmParams& p, hipStream_t st) {

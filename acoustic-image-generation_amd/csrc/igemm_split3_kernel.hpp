@@ -70,12 +70,11 @@ __device__ __forceinline__ void split4(float4 v, uint2& hi, uint2& lo) {
 //   FWD  : rows n = output channel,  k = tap*C + c            value W[tap][c][n]
 //   DGRAD: rows n = input channel c, k = tap'*K + ko          value W[ntaps-1-tap'][n][ko]   (flipped taps)
 template <typename TR, bool DGRAD>
-__global__ __launch_bounds__(256) void split3_prepare_kernel(const float* w, int ntaps, int C, int K, int ldw,
-                                                             int Nrows, typename TR::T* out) {
+__device__ __forceinline__ void split3_prepare_body(const float* w, int ntaps, int C, int K, int ldw, int Nrows,
+                                                    typename TR::T* out, int bx, int by, float (*tile)[33]) {
     typedef typename TR::T T;
-    __shared__ float tile[32][33];
     const int Ktot = DGRAD ? ntaps * K : ntaps * C;
-    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int k0 = bx * 32, n0 = by * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -104,6 +103,39 @@ __global__ __launch_bounds__(256) void split3_prepare_kernel(const float* w, int
             out[((long)Nrows + n) * Ktot + k] = (T)(v - (float)h);
         }
     }
+}
+
+template <typename TR, bool DGRAD>
+__global__ __launch_bounds__(256) void split3_prepare_kernel(const float* w, int ntaps, int C, int K, int ldw,
+                                                             int Nrows, typename TR::T* out) {
+    __shared__ float tile[32][33];
+    split3_prepare_body<TR, DGRAD>(w, ntaps, C, K, ldw, Nrows, out, blockIdx.x, blockIdx.y, tile);
+}
+
+// several kernels in ONE launch (the generator re-splits its trainable kernels every step: forward f16 images and
+// flipped / transposed bf16 images for the data gradients): job table by value, workgroup -> job by block ranges
+struct PrepJob {
+    const float* w;
+    void* out;
+    int ntaps, C, K, ldw, Nrows, dgrad, tiles_k, block0;
+};
+struct PrepJobs {
+    PrepJob j[16];
+    int n;
+};
+__global__ __launch_bounds__(256) void split3_prepare_multi_kernel(const PrepJobs jobs) {
+    __shared__ float tile[32][33];
+    int ji = 0;
+#pragma unroll 1
+    for (int i = 1; i < jobs.n; ++i)
+        if ((int)blockIdx.x >= jobs.j[i].block0) ji = i;
+    const PrepJob& J = jobs.j[ji];
+    const int lb = blockIdx.x - J.block0;
+    const int bx = lb % J.tiles_k, by = lb / J.tiles_k;
+    if (J.dgrad)
+        split3_prepare_body<SplitBF16, true>(J.w, J.ntaps, J.C, J.K, J.ldw, J.Nrows, static_cast<__bf16*>(J.out), bx, by, tile);
+    else
+        split3_prepare_body<SplitF16, false>(J.w, J.ntaps, J.C, J.K, J.ldw, J.Nrows, static_cast<_Float16*>(J.out), bx, by, tile);
 }
 
 template <int BM, int BN, int WGM, int WGN, int NTHR, typename TR>

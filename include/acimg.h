@@ -93,6 +93,10 @@ size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d);
  * Replaces: slim layers.conv2d / conv2d_same in the trunk, models/resnet50.py:109-121. */
 size_t acimg_conv2d_split3_weight_bytes(const AcimgConvDesc* d);
 int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream);
+/* Up to 16 kernels in ONE launch (a model that trains re-splits its kernels every step): mode[i] = 0 -> the forward
+ * image of acimg_conv2d_split3_prepare, 1 -> the data-gradient image of acimg_conv2d_split3_prepare_dgrad. */
+int acimg_conv2d_split3_prepare_multi(int n, const AcimgConvDesc* const* descs, const float* const* w, void* const* out,
+                                      const int* mode, void* stream);
 int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d);
 int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out /* {BM, BN} */);
 int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* wsplit, const float* bias,
