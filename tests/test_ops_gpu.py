@@ -820,3 +820,63 @@ def test_tapconv_matches_valid_conv(device):
     L = __import__("acimg._lib", fromlist=["load"]).load()
     bad = ops.conv_desc(N, H, W, Cin, K, R, S, 2, "VALID", ldx=Cin, ldy=K, ldw=K)
     assert L.acimg_tapconv_pack(__import__("ctypes").byref(bad), wd.data_ptr(), wt.data_ptr(), TK, None) != 0
+
+
+def test_stem_row_run_conv_matches_7x7_stride2(device):
+    """the stem as a row-run conv (include/acimg.h, acimg_conv2d_fwd_split3): 7x7/2 after 3+3 zero padding on a
+    4-channel frame == R=7, S=1, C=32 with pixel pitch 4, incl. the batch-norm partials"""
+    from acimg import ops
+    g = torch.Generator().manual_seed(21)
+    N, H, W = 2, 30, 42
+    x = rnd(g, N, H, W, 3).abs()
+    w = rnd(g, 7, 7, 3, 64) * 0.1
+    OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), stride=2, padding=3).permute(0, 2, 3, 1)
+    plan = ops.Plan(device, eager=True)
+    Hp, Wp = H + 6, W + 6
+    frame = torch.zeros(N * Hp * Wp * 4 + 64, device=device)
+    ops.pad_image(plan, dev(x, device), frame, N, H, W, 3, 4, Hp, Wp, 3, 3)
+    fr = frame[:N * Hp * Wp * 4].view(N, Hp, Wp, 4).cpu()
+    assert torch.equal(fr[:, 3:3 + H, 3:3 + W, :3], x.float()) and float(fr[..., 3].abs().max()) == 0.0
+    assert float(fr[:, :3].abs().max()) == 0.0 and float(fr[:, :, Wp - 3:].abs().max()) == 0.0
+    wr = torch.zeros(7, 1, 32, 64)
+    wr.view(7, 32, 64)[:, :28] = torch.nn.functional.pad(w.float(), (0, 0, 0, 1)).reshape(7, 28, 64)
+    d = ops.conv_desc(N, Hp, Wp, 32, 64, 7, 1, 2, "VALID", ldx=4, ldy=64, ldw=64)
+    d.OH, d.OW = OH, OW
+    wsplit = torch.zeros(int(ops.conv2d_split3_weight_bytes(d)), dtype=torch.uint8, device=device)
+    ops.conv2d_split3_prepare(plan, d, dev(wr, device), wsplit)
+    y = torch.zeros(N, OH, OW, 64, device=device)
+    rows = ops.conv2d_fwd_split3_stats_rows(d)
+    stats = torch.zeros(rows, 2, 64, device=device)
+    ops.conv2d_fwd_split3(plan, d, frame, wsplit, y, None, None, 0, stats)
+    torch.cuda.synchronize()
+    close(y, ref, tol=1e-4, what="row-run stem")
+    flat = ref.reshape(-1, 64)
+    close(stats[:, 0].sum(0), flat.sum(0), tol=1e-4, what="row-run stem stats sum")
+    close(stats[:, 1].sum(0), (flat * flat).sum(0), tol=1e-4, what="row-run stem stats sumsq")
+    bad = ops.conv_desc(N, Hp, Wp, 32, 64, 7, 3, 2, "VALID", ldx=4, ldy=64, ldw=64)     # S != 1: not a row run
+    L = __import__("acimg._lib", fromlist=["load"]).load()
+    assert L.acimg_conv2d_split3_prepare(__import__("ctypes").byref(bad), wr.data_ptr(), wsplit.data_ptr(), None) != 0
+
+
+def test_split3_prepare_multi_equals_single_launches(device):
+    from acimg import ops
+    g = torch.Generator().manual_seed(22)
+    plan = ops.Plan(device, eager=True)
+    jobs = ops.PrepareJobs()
+    singles = []
+    for (C_, K_, R_, mode) in ((64, 64, 3, 0), (128, 64, 3, 1), (32, 96, 1, 0), (64, 128, 3, 1)):
+        d = ops.conv_desc(2, 12, 16, C_, K_, R_, R_, 1, "SAME")
+        w = dev(rnd(g, R_, R_, C_, K_) * 0.1, device)
+        nbytes = int(ops.conv2d_split3_dgrad_weight_bytes(d) if mode else ops.conv2d_split3_weight_bytes(d))
+        a = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        b = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        (ops.conv2d_split3_prepare_dgrad if mode else ops.conv2d_split3_prepare)(plan, d, w, a)
+        jobs.add(d, w, b, mode)
+        singles.append((a, b))
+    ops.conv2d_split3_prepare_multi(plan, jobs)
+    torch.cuda.synchronize()
+    for a, b in singles:
+        assert torch.equal(a, b)
+    empty = ops.PrepareJobs()
+    ops.conv2d_split3_prepare_multi(plan, empty)            # nothing to do is not an error
