@@ -286,6 +286,16 @@ def main():
             "final_loss": last["loss"], "final_mse": last["mse"],
             "roofline": roof,
         }
+        # the whole step against both chip roofs (41.7 GFLOP algorithmic per image; HBM bytes per step
+        # from the PMC pass under profiles/, batch 32 f16x3 only)
+        per_gpu_rate = B * args.steps / dt
+        out["step"] = {"alg_tflops": 41.7e9 * per_gpu_rate / 1e12,
+                       "hbm_GBps": (28.67e9 / (dt / args.steps) / 1e9) if (f16 and B == 32) else None,
+                       "hbm_frac": (28.67e9 / (dt / args.steps) / 8.0e12) if (f16 and B == 32) else None,
+                       "hbm_source": "profiles/r01/hbm_traffic_v10.txt (28.67 GB/step)" if (f16 and B == 32) else None}
+        if roof is not None and roof.get("traffic"):
+            roof["hbm_GBps"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9
+            roof["hbm_frac"] = roof["hbm_GBps"] * 1e9 / 8.0e12
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         if world == 1 and not args.no_secondary:
