@@ -202,3 +202,77 @@ def test_partial_batch_and_device_noise(device):
     assert np.isfinite(r1["loss"])
     e = tr.graphs[1].eps.cpu()
     assert abs(float(e.mean())) < 0.5 and 0.5 < float(e.std()) < 1.5
+
+
+def test_full_size_properties(device):
+    """The bench configuration itself (batch 32, f16x3, 1 skip) through properties that need no oracle:
+    (a) a train step replayed from the same state is bit-identical (generated images and every gradient; the scalar
+        loss sums to summation order);
+    (b) the inference pass is per-image: the batch of 32 equals its two halves run as batches of 16;
+    (c) the reported MSE is the MSE of the generated images;
+    (d) the gradient is the derivative of the reported loss: a central difference along the (normalised) gradient
+        direction of all trained variables reproduces |g| (batch statistics and noise held fixed)."""
+    from acimg.flags import FLAGS
+    from acimg.session import Session
+    from acimg.trainer import Trainer
+    from acimg.unet_acresnet import UNetAc
+    from acimg.vision import ResNet50Model
+    from oracle import trainer as otr
+
+    B = 32
+    FLAGS.model, FLAGS.ae, FLAGS.latent_loss = "UNet", 0, 1e-6
+    sess = Session(device)
+    tr = Trainer(UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=1),
+                 ResNet50Model(input_shape=[224, 298, 3], num_classes=None), learning_rate=1e-4, session=sess)
+    g = tr._build_functions(batch_size=B)
+    tr.modelimages.initialize(seed=1238)
+    tr.modelac.initialize(seed=1239)
+    ac, mf, vid, eps = otr.synthetic_batch(B, seed=41)
+    st = sess.store
+    w0 = st.flat["train"].clone()
+    bn0 = st.flat["state"].clone()
+    m0, v0 = st.adam_m.clone(), st.adam_v.clone()
+
+    def restore(w=None):
+        st.flat["train"].copy_(w0 if w is None else w)
+        st.flat["state"].copy_(bn0)
+        st.adam_m.copy_(m0)
+        st.adam_v.copy_(v0)
+        tr.global_step = 0
+
+    # (a) determinism
+    r1 = tr.train_step((ac, mf, vid), eps=eps)
+    g1 = st.grad.clone()
+    out1 = g.modelac.output.clone()
+    restore()
+    r2 = tr.train_step((ac, mf, vid), eps=eps)
+    assert torch.equal(g1, st.grad) and torch.equal(out1, g.modelac.output)
+    for k in r1:            # the scalar loss sums are float atomics over 160 workgroups: equal to summation order
+        assert abs(r1[k] - r2[k]) <= 1e-6 * abs(r1[k]), (k, r1[k], r2[k])
+    # (c) the reported MSE
+    mse = float(((out1.double().cpu() - ac.double().reshape(B, 36, 48, 12)) ** 2).mean())
+    assert abs(r1["mse"] - mse) <= 1e-5 * mse, (r1["mse"], mse)
+    # (d) directional derivative along g (every trained variable: generator + conv_map)
+    restore()
+    gn = float(g1.double().norm())
+    d = (g1.double() / gn).float()
+    # step: the largest single weight moves by 2e-3 (weights are ~1e-2 ... 1e-1); the loss (~16, fp32: 2e-6 steps)
+    # then changes by hundreds of its representable steps
+    h = 2e-3 / max(float(d.abs().max()), 1e-12)
+    fp, fm = [], []
+    for sign, acc in ((+1.0, fp), (-1.0, fm)):
+        restore(w0 + sign * h * d)
+        acc.append(tr.train_step((ac, mf, vid), eps=eps)["loss"])
+    restore()
+    fd = (fp[0] - fm[0]) / (2 * h)
+    assert abs(fd - gn) <= 3e-2 * gn, (fd, gn, h, fp[0] - fm[0])
+    # (b) inference is per image
+    full = tr.eval_step((ac, mf, vid), eps=eps)
+    out_full = g.modelac.output.clone()
+    halves = []
+    for lo in (0, 16):
+        tr.eval_step((ac[lo:lo + 16], mf[lo:lo + 16], vid[lo:lo + 16]), eps=eps[lo:lo + 16])
+        halves.append(tr.graphs[16].modelac.output.clone())
+    both = torch.cat(halves, 0)
+    assert rel_err(both, out_full) < 1e-5, rel_err(both, out_full)
+    assert np.isfinite(full["mse"])
