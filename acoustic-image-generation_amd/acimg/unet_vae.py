@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, Ptr
+from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
 from .params import FusedHeads, Var, up4
 from .session import get_default_session
 from .unet_acresnet import Act

@@ -5,7 +5,6 @@ import csv, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "acoustic-image-generation_amd"))
 import torch
-from acimg import ops
 from acimg.flags import FLAGS
 from acimg.session import Session
 from acimg.trainer import Trainer

@@ -1,6 +1,6 @@
 """Per-call report of the recorded train step, measured in place: every C-ABI call of the plan is bracketed with
 events (Plan.run_probed) over a few steps.  Run on the GPU box.  usage: python tools/op_report.py [batch] [first_call] [trainer_mask|unet_rgb|unet_sound]"""
-import ctypes, os, sys
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "acoustic-image-generation_amd"))
 import torch
