@@ -269,6 +269,8 @@ __global__ __launch_bounds__(NTHR) void igemm_f32_kernel(const IgemmParams p) {
     }
 
     float4 ra[NA], rb[NB];
+    float4 ld_sc4 = make_float4(1.f, 1.f, 1.f, 1.f), ld_sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned ld_ok = 0;     // bit j: element j of the parked A tile is a real (not padding / tail) element
 
     auto load_tiles = [&]() {
         int r, s, c, seg = 0, chunk = 0;
@@ -292,32 +294,22 @@ __global__ __launch_bounds__(NTHR) void igemm_f32_kernel(const IgemmParams p) {
                 c = pp;
             }
         }
-        const bool affine = p.a_scale != nullptr;
-        float4 sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (affine && validk) {
-            sc4 = *reinterpret_cast<const float4*>(p.a_scale + c);
-            sh4 = *reinterpret_cast<const float4*>(p.a_shift + c);
+        // The deferred-BN affine (+ ReLU) of the A operand is applied in store_tiles, NOT here: touching a loaded
+        // value inside this loop makes the compiler wait for each load before the next is issued (a full memory
+        // round trip per load); here the loads only leave, with the scale / shift of their channel chunk and the
+        // padding flags parked beside them.
+        if (p.a_scale != nullptr && validk) {
+            ld_sc4 = *reinterpret_cast<const float4*>(p.a_scale + c);
+            ld_sh4 = *reinterpret_cast<const float4*>(p.a_shift + c);
         }
         const int tapoff = ((r * p.W + s) * p.lda + c) * 4;
+        ld_ok = 0;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int ih = a_ih0[j] + r, iw = a_iw0[j] + s;
             const bool ok = validk && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            float4 v = buf_load4(rsA, ok ? (unsigned)(a_off[j] + tapoff) : OOB);
-            if (affine) {
-                v.x = v.x * sc4.x + sh4.x;
-                v.y = v.y * sc4.y + sh4.y;
-                v.z = v.z * sc4.z + sh4.z;
-                v.w = v.w * sc4.w + sh4.w;
-                if (p.a_relu) {
-                    v.x = fmaxf(v.x, 0.f);
-                    v.y = fmaxf(v.y, 0.f);
-                    v.z = fmaxf(v.z, 0.f);
-                    v.w = fmaxf(v.w, 0.f);
-                }
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding AFTER the affine
-            }
-            ra[j] = v;
+            ra[j] = buf_load4(rsA, ok ? (unsigned)(a_off[j] + tapoff) : OOB);      // out of range -> zeros
+            ld_ok |= ok ? (1u << j) : 0u;
         }
         if constexpr (B_NT) {
             int tap;
@@ -368,6 +360,24 @@ __global__ __launch_bounds__(NTHR) void igemm_f32_kernel(const IgemmParams p) {
     auto store_tiles = [&](int buf) {
         float* As = smem + buf * STAGE;
         float* Bs = As + A_ELEMS;
+        if (p.a_scale != nullptr) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                float4 v = ra[j];
+                v.x = v.x * ld_sc4.x + ld_sh4.x;
+                v.y = v.y * ld_sc4.y + ld_sh4.y;
+                v.z = v.z * ld_sc4.z + ld_sh4.z;
+                v.w = v.w * ld_sc4.w + ld_sh4.w;
+                if (p.a_relu) {
+                    v.x = fmaxf(v.x, 0.f);
+                    v.y = fmaxf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f);
+                    v.w = fmaxf(v.w, 0.f);
+                }
+                if (!((ld_ok >> j) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);  // zero padding AFTER the affine
+                ra[j] = v;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int row = arow0 + j * RPP;
