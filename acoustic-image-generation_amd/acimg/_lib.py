@@ -94,13 +94,14 @@ PROTOTYPES = {
     "acimg_clip_softmax_ce": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "acimg_bn_bwd_workspace": (_SZ, [_L, _I]),
     "acimg_bn_bwd": (_I, [_P, _I, _P, _I, _P, _P, _P, _P, _P, _L, _I, _P, _I, _P, _P, _P, _SZ, _P]),
-    "acimg_recon_loss": (_I, [_P, _P, _P, _P, _L, _F, _F, _P]),
+    "acimg_loss_scratch_bytes": (_SZ, []),
+    "acimg_recon_loss": (_I, [_P, _P, _P, _P, _L, _F, _F, _P, _SZ, _P]),
     "acimg_grad_slice": (_I, [_P, _I, _P, _I, _P, _I, _L, _I, _I, _P]),
     "acimg_loss_finalize": (_I, [_P, _P, _I, _D, _F, _F, _F, _F, _P, _P]),
     "acimg_randn": (_I, [_P, _L, C.c_uint64, C.c_uint64, _P]),
     "acimg_sqerr_channels": (_I, [_P, _P, _L, _I, _P, _P]),
     "acimg_zero": (_I, [_P, _SZ, _P]),
-    "acimg_sumsq": (_I, [_P, _L, _P, _P]),
+    "acimg_sumsq": (_I, [_P, _L, _P, _P, _SZ, _P]),
     "acimg_axpy": (_I, [_F, _P, _P, _L, _P]),
     "acimg_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
     "acimg_mfcc_frontend": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),

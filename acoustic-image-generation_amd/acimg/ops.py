@@ -538,9 +538,22 @@ def clip_softmax_ce(plan, logits, ldl, clips, F, K, labels, out, g_logits, ldg):
              int(ldg))
 
 
+_LOSS_SCRATCH = {}
+
+
+def loss_scratch(device):
+    """the dedicated, zero-initialised hand-off buffer that makes acimg_recon_loss / acimg_sumsq bit-reproducible (one
+    per device: these launches are stream-ordered, the last workgroup of each leaves its ticket at zero)"""
+    key = str(device)
+    if key not in _LOSS_SCRATCH:
+        _LOSS_SCRATCH[key] = torch.zeros(int(_L().acimg_loss_scratch_bytes()), dtype=torch.uint8, device=device)
+    return _LOSS_SCRATCH[key]
+
+
 def recon_loss(plan, yhat, target, g_logit, sums, count, w_mse=1.0, w_huber=1.0):
+    sc = loss_scratch(plan.device)
     plan.add("recon_loss", _L().acimg_recon_loss, yhat, target, g_logit, sums, int(count),
-             float(w_mse), float(w_huber))
+             float(w_mse), float(w_huber), sc, int(sc.numel()))
 
 
 def grad_slice(plan, src, ldsrc, dst, lddst, mask, ldmask, pixels, Cn, accumulate=False):
@@ -567,7 +580,8 @@ def sqerr_channels(plan, a, b, pixels, Cn, out):
 
 
 def sumsq(plan, x, n, out):
-    plan.add("sumsq", _L().acimg_sumsq, x, int(n), out)
+    sc = loss_scratch(plan.device)
+    plan.add("sumsq", _L().acimg_sumsq, x, int(n), out, sc, int(sc.numel()))
 
 
 def axpy(plan, a, x, y, n):

@@ -659,9 +659,47 @@ __global__ __launch_bounds__(64) void clip_softmax_ce_kernel(const float* logits
 // ------------------------------------------------------------------------------------------
 // reconstruction loss (MSE + Huber delta=1) and gradient w.r.t. pre-sigmoid logits
 // ------------------------------------------------------------------------------------------
+// Ordered combination of per-workgroup partial sums (bit-reproducible, unlike float atomics): every workgroup
+// parks its NV partials in `scratch` (agent-scope stores), takes a ticket, and the LAST arriver adds all
+// partials in workgroup order with a fixed tree and accumulates them into dst[0..NV).  scratch: int ticket at
+// [0] (zero before the first use; the last arriver resets it), partials from float index 4 on.  Call from all
+// 256 threads; v is meaningful on thread 0.  scratch == nullptr: plain float atomics.
+template <int NV>
+__device__ __forceinline__ void ordered_block_sums(const float (&v)[NV], float* scratch, float* dst, float* sm) {
+    if (scratch == nullptr) {
+        if (threadIdx.x == 0)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) atomicAdd(&dst[i], v[i]);
+        return;
+    }
+    int* ticket = reinterpret_cast<int*>(scratch);
+    float* part = scratch + 4;
+    __shared__ int last_flag;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            __hip_atomic_store(&part[(long)blockIdx.x * NV + i], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = t == (int)gridDim.x - 1;
+        if (last_flag) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!last_flag) return;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float acc = 0.f;
+        for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)
+            acc += __hip_atomic_load(&part[(long)b * NV + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc = block_sum(acc, sm);
+        if (threadIdx.x == 0) dst[i] += acc;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(256) void recon_loss_kernel(const float* yhat, const float* target,
                                                          float* glogit, float* sums, long count,
-                                                         float w_mse, float w_huber) {
+                                                         float w_mse, float w_huber, float* scratch) {
     __shared__ float sm[32];
     float s_mse = 0.f, s_hub = 0.f;
     const float inv = 1.f / (float)count;
@@ -701,13 +739,11 @@ __global__ __launch_bounds__(256) void recon_loss_kernel(const float* yhat, cons
     }
     s_mse = block_sum(s_mse, sm);
     s_hub = block_sum(s_hub, sm);
-    if (threadIdx.x == 0) {
-        atomicAdd(&sums[0], s_mse);
-        atomicAdd(&sums[1], s_hub);
-    }
+    const float v[2] = {s_mse, s_hub};
+    ordered_block_sums<2>(v, scratch, sums, sm);
 }
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, float* out, float* scratch) {
     __shared__ float sm[32];
     float s = 0.f;
     const long n4 = n >> 2;
@@ -718,7 +754,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, long n, floa
     for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
         s += x[i] * x[i];
     s = block_sum(s, sm);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    const float v[1] = {s};
+    ordered_block_sums<1>(v, scratch, out, sm);
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(float a, const float* x, float* y, long n) {
@@ -1204,24 +1241,31 @@ int acimg_bn_bwd(const float* x, int ldx, const float* gy, int ldgy, const float
     return check_launch("bn_bwd");
 }
 
+size_t acimg_loss_scratch_bytes(void) { return (size_t)(4 + 2 * 1024) * sizeof(float); }
+
 int acimg_recon_loss(const float* yhat, const float* target, float* g_logit, float* sums,
-                     long count, float w_mse, float w_huber, void* stream) {
+                     long count, float w_mse, float w_huber, void* scratch, size_t scratch_bytes, void* stream) {
     if (!aligned16(yhat) || !aligned16(target) || (g_logit && !aligned16(g_logit)))
         return fail(ACIMG_EINVAL, "recon_loss: buffers must be 16-byte aligned");
+    if (scratch && scratch_bytes < acimg_loss_scratch_bytes())
+        return fail(ACIMG_EWORKSPACE, "recon_loss: scratch %zu < %zu", scratch_bytes, acimg_loss_scratch_bytes());
     long blocks = (count / 4 + 255) / 256;
-    if (blocks > 160) blocks = 160;      // two float atomics per workgroup on the same two words: keep them few
+    if (blocks > 160) blocks = 160;      // one ordered hand-off (or two float atomics) per workgroup: keep them few
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(recon_loss_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, yhat,
-                       target, g_logit, sums, count, w_mse, w_huber);
+                       target, g_logit, sums, count, w_mse, w_huber, static_cast<float*>(scratch));
     return check_launch("recon_loss");
 }
 
-int acimg_sumsq(const float* x, long n, float* out, void* stream) {
+int acimg_sumsq(const float* x, long n, float* out, void* scratch, size_t scratch_bytes, void* stream) {
     if (!aligned16(x)) return fail(ACIMG_EINVAL, "sumsq: buffer must be 16-byte aligned");
+    if (scratch && scratch_bytes < acimg_loss_scratch_bytes())
+        return fail(ACIMG_EWORKSPACE, "sumsq: scratch %zu < %zu", scratch_bytes, acimg_loss_scratch_bytes());
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out,
+                       static_cast<float*>(scratch));
     return check_launch("sumsq");
 }
 

@@ -342,8 +342,12 @@ int acimg_triplet_loss_bwd(const float* e0, int lde0, const float* e1, int lde1,
  *   sums[0] += sum (yhat-y)^2, sums[1] += sum huber_1(yhat-y)   (caller zeroes sums)
  *   g_logit = (w_mse*2e + w_huber*clip(e,-1,1)) / count * yhat*(1-yhat)
  * Replaces tf.losses.mean_squared_error / huber_loss, trainer/mfcctrainer.py:47,50. */
+/* `scratch` (optional; acimg_loss_scratch_bytes() bytes, zeroed ONCE by the caller and dedicated to acimg_recon_loss /
+ * acimg_sumsq calls of one stream) makes the two sums bit-reproducible: the workgroups' partials are combined in
+ * workgroup order by the last arriver instead of by float atomics. */
+size_t acimg_loss_scratch_bytes(void);
 int acimg_recon_loss(const float* yhat, const float* target, float* g_logit, float* sums,
-                     long count, float w_mse, float w_huber, void* stream);
+                     long count, float w_mse, float w_huber, void* scratch, size_t scratch_bytes, void* stream);
 
 /* dst[p][c] = (accumulate ? dst : 0) + src[p][c] for c < C, zeroed where mask[p][c] <= 0 (mask
  * optional): routes the gradient of one channel slice of a tf.concat back to its producer
@@ -368,9 +372,9 @@ int acimg_zero(void* ptr, size_t bytes, void* stream);
  * the per-3-channel test MSEs of trainer/mfcctrainer.py:105-117 are sums of 3 of these / count. */
 int acimg_sqerr_channels(const float* a, const float* b, long pixels, int C, float* out, void* stream);
 
-/* sum of squares of a flat buffer into *out (+=) — slim l2_regularizer terms
+/* sum of squares of a flat buffer into *out (+=; `scratch` as for acimg_recon_loss) — slim l2_regularizer terms
  * (models/vision.py:54, tf.losses.get_total_loss trainer/mfcctrainer.py:60). */
-int acimg_sumsq(const float* x, long n, float* out, void* stream);
+int acimg_sumsq(const float* x, long n, float* out, void* scratch, size_t scratch_bytes, void* stream);
 /* y += a*x */
 int acimg_axpy(float a, const float* x, float* y, long n, void* stream);
 

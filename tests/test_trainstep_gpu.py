@@ -206,8 +206,7 @@ def test_partial_batch_and_device_noise(device):
 
 def test_full_size_properties(device):
     """The bench configuration itself (batch 32, f16x3, 1 skip) through properties that need no oracle:
-    (a) a train step replayed from the same state is bit-identical (generated images and every gradient; the scalar
-        loss sums to summation order);
+    (a) a train step replayed from the same state is bit-identical (losses, generated images, every gradient);
     (b) the inference pass is per-image: the batch of 32 equals its two halves run as batches of 16;
     (c) the reported MSE is the MSE of the generated images;
     (d) the gradient is the derivative of the reported loss: a central difference along the (normalised) gradient
@@ -246,9 +245,7 @@ def test_full_size_properties(device):
     out1 = g.modelac.output.clone()
     restore()
     r2 = tr.train_step((ac, mf, vid), eps=eps)
-    assert torch.equal(g1, st.grad) and torch.equal(out1, g.modelac.output)
-    for k in r1:            # the scalar loss sums are float atomics over 160 workgroups: equal to summation order
-        assert abs(r1[k] - r2[k]) <= 1e-6 * abs(r1[k]), (k, r1[k], r2[k])
+    assert r1 == r2 and torch.equal(g1, st.grad) and torch.equal(out1, g.modelac.output)
     # (c) the reported MSE
     mse = float(((out1.double().cpu() - ac.double().reshape(B, 36, 48, 12)) ** 2).mean())
     assert abs(r1["mse"] - mse) <= 1e-5 * mse, (r1["mse"], mse)
