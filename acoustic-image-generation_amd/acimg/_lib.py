@@ -38,6 +38,7 @@ PROTOTYPES = {
     "acimg_conv2d_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _P, _I, _P, _P, _SZ, _P]),
     "acimg_conv2d_stats_rows": (_I, [_DP]),
     "acimg_conv2d_fwd_tiling": (_I, [_DP, C.POINTER(C.c_int)]),
+    "acimg_set_ticket_buffer": (_I, [_P, _SZ]),
     "acimg_conv2d_fwd_workspace": (_SZ, [_DP]),
     "acimg_conv2d_split3_weight_bytes": (_SZ, [_DP]),
     "acimg_conv2d_split3_prepare": (_I, [_DP, _P, _P, _P]),

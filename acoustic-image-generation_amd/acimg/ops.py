@@ -143,6 +143,7 @@ class Plan(object):
 
     def __init__(self, device=None, eager=False, ws=None):
         self.device = device
+        ensure_tickets(device)
         self.eager = eager
         self.ws = ws if ws is not None else Workspace(device)
         self.calls = []      # (name, fn, raw args); args None => host hook
@@ -539,6 +540,20 @@ def clip_softmax_ce(plan, logits, ldl, clips, F, K, labels, out, g_logits, ldg):
 
 
 _LOSS_SCRATCH = {}
+_TICKETS = {}
+
+
+def ensure_tickets(device):
+    """register (once per process; one process per GPU) the zeroed ticket words that let split-K launches combine
+    their K ranges inside the kernel (acimg_set_ticket_buffer); kept alive for the life of the process"""
+    if device is None or torch.device(device).type != "cuda" or not torch.cuda.is_available():
+        return
+    key = str(torch.device(device))
+    if key not in _TICKETS:
+        _TICKETS[key] = torch.zeros(16384, dtype=torch.uint8, device=device)
+        _lib.check(_L().acimg_set_ticket_buffer(_TICKETS[key].data_ptr(), 16384), "set_ticket_buffer")
+
+
 
 
 def loss_scratch(device):

@@ -648,12 +648,19 @@ static int pick_splits(int M, int Ngemm, TileCfg c, int kiters) {
     return (int)s;
 }
 
+// caller-owned ticket words for the in-kernel split-K hand-off (acimg_set_ticket_buffer): zero-initialised once,
+// dedicated to this library, every launch leaves them at zero
+static int* g_tickets = nullptr;
+static size_t g_ticket_words = 0;
+
 static size_t igemm_ws_bytes(int M, int Ngemm, int kiters) {
     TileCfg c = pick_cfg(M, Ngemm);
     int s = pick_splits(M, Ngemm, c, kiters);
     if (s <= 1) return 0;
     const int ld = (Ngemm + 3) & ~3;
-    return (size_t)s * M * ld * sizeof(float);
+    const size_t rows = (size_t)s * M * ld * sizeof(float);                                   // reduce-launch layout
+    const size_t tiled = (size_t)s * cdiv(M, c.bm) * cdiv(Ngemm, c.bn) * c.bm * c.bn * sizeof(float);   // hand-off layout
+    return rows > tiled ? rows : tiled;
 }
 
 template <int BM, int BN, int WGM, int WGN, int NTHR>
@@ -710,13 +717,18 @@ static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipSt
     }
     p.slab = nullptr;
     p.slab_ld = (p.Ngemm + 3) & ~3;
+    p.ts_counters = nullptr;
+    dim3 grid(cdiv(p.M, c.bm), cdiv(p.Ngemm, c.bn), p.splits);
     if (p.splits > 1) {
-        const size_t need = (size_t)p.splits * p.M * p.slab_ld * sizeof(float);
+        size_t need = (size_t)p.splits * p.M * p.slab_ld * sizeof(float);
+        const size_t tiles = (size_t)grid.x * grid.y;
+        const bool handoff = g_tickets != nullptr && tiles <= g_ticket_words && !getenv("ACIMG_NO_SPLITK_HANDOFF");
+        if (handoff) need = (size_t)p.splits * tiles * c.bm * c.bn * sizeof(float);
         if (ws == nullptr || ws_bytes < need)
             return fail(ACIMG_EWORKSPACE, "igemm: workspace %zu < %zu", ws_bytes, need);
         p.slab = static_cast<float*>(ws);
+        if (handoff) p.ts_counters = g_tickets;
     }
-    dim3 grid(cdiv(p.M, c.bm), cdiv(p.Ngemm, c.bn), p.splits);
     if (c.bm == 128 && c.bn == 128) launch_cfg<128, 128, 2, 4, 512>(p, nt, cal, grid, st);
     else if (c.bm == 128 && c.bn == 64) launch_cfg<128, 64, 2, 2, 256>(p, nt, cal, grid, st);
     else if (c.bm == 64 && c.bn == 64) launch_cfg<64, 64, 2, 2, 256>(p, nt, cal, grid, st);
@@ -724,10 +736,12 @@ static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipSt
     int rc = check_launch("igemm");
     if (rc) return rc;
     if (p.splits > 1) {
-        const long total = (long)p.M * p.Ngemm;
-        hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
-                           p.slab, p.splits, p.M, p.Ngemm, p.slab_ld, p.e);
-        rc = check_launch("igemm_splitk_reduce");
+        if (p.ts_counters == nullptr) {
+            const long total = (long)p.M * p.Ngemm;
+            hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st,
+                               p.slab, p.splits, p.M, p.Ngemm, p.slab_ld, p.e);
+            rc = check_launch("igemm_splitk_reduce");
+        }
         if (!rc && stats_after) {
             hipLaunchKernelGGL(partial_stats_kernel, dim3(cdiv(p.M, 256)), dim3(256), 0, st, e.Y, e.ldy, p.M,
                                e.Nstore, stats_after, e.stats_ld, 256);
@@ -1156,6 +1170,14 @@ int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
     out[0] = c.bm;
     out[1] = c.bn;
     out[2] = pick_splits(M, d->K, c, fwd_kiters(d));
+    return ACIMG_OK;
+}
+
+int acimg_set_ticket_buffer(void* tickets, size_t bytes) {
+    if (tickets && (bytes < 4096 || (reinterpret_cast<uintptr_t>(tickets) & 15)))
+        return fail(ACIMG_EINVAL, "set_ticket_buffer: need >= 4096 zeroed bytes, 16-byte aligned");
+    g_tickets = static_cast<int*>(tickets);
+    g_ticket_words = tickets ? bytes / sizeof(int) : 0;
     return ACIMG_OK;
 }
 

@@ -89,10 +89,10 @@ __device__ __forceinline__ void epi_store4(const EpiParams& e, long opix, int cn
 template <int BM, int BN, int WGM, int WGN, int NTHR, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[TM][TN], float* smem, int m0,
                                                int n0, int wm, int wn, int li, int g, int tid,
-                                               int stat_row = -1, bool stats_only = false) {
+                                               int stat_row = -1, bool stats_only = false, bool merged = false) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     if (stat_row < 0) stat_row = blockIdx.x;
-    if (p.splits > 1) {
+    if (p.splits > 1 && !merged) {
         float* slab = p.slab + (long)blockIdx.z * p.M * p.slab_ld;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -460,6 +460,55 @@ __global__ __launch_bounds__(NTHR) void igemm_f32_kernel(const IgemmParams p) {
         cur ^= 1;
     }
 
+    if (p.splits > 1 && p.ts_counters != nullptr) {
+        // split-K without a reduce launch (same hand-off as the trunk kernel's tail split): every K range parks its
+        // partial tile (write-through sc1 stores: visible to the other XCDs), takes a ticket; the last arriver adds
+        // the ranges IN RANGE ORDER (its own included, from memory: the result does not depend on who came last)
+        // and runs the ordinary epilogue.  Nobody waits.
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int tl = blockIdx.y * gridDim.x + blockIdx.x;
+        float* const slot0 = p.slab + (long)tl * p.splits * (BM * BN);
+        const __amdgpu_buffer_rsrc_t rsP =
+            __builtin_amdgcn_make_buffer_rsrc(slot0 + (long)blockIdx.z * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsP,
+                                                       ((i * TN + j) * NTHR + tid) * 16, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* const flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const int ticket = __hip_atomic_fetch_add(p.ts_counters + tl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == p.splits - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.ts_counters + tl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        __syncthreads();                           // everyone has read the flag before the epilogue reuses the LDS
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < p.splits; ++c) {
+            const __amdgpu_buffer_rsrc_t rsQ =
+                __builtin_amdgcn_make_buffer_rsrc(slot0 + (long)c * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)     // sc1 loads: never a stale L1 / L2 copy
+                    acc[i][j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                               rsQ, ((i * TN + j) * NTHR + tid) * 16, 0, 16));
+        }
+        igemm_epilogue<BM, BN, WGM, WGN, NTHR, TM, TN>(p, acc, smem, m0, n0, wm, wn, li, g, tid, -1, false, true);
+        return;
+    }
     igemm_epilogue<BM, BN, WGM, WGN, NTHR, TM, TN>(p, acc, smem, m0, n0, wm, wn, li, g, tid);
 }
 

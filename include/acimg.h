@@ -74,6 +74,12 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
 int acimg_conv2d_stats_rows(const AcimgConvDesc* d);
 /* out[3] = {BM, BN, split-K factor} the forward launch will use (profiling / roofline bookkeeping) */
 int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out);
+/* Optional, once per process (one process per GPU): hand the library `bytes` (>= 4096) of ZEROED device memory that
+ * nothing else touches.  Split-K launches of acimg_conv2d_fwd / _dgrad (and the transposed-conv entries built on
+ * them) then combine their K ranges inside the kernel — ticket per output tile, the last arriver adds the ranges in
+ * range order and runs the epilogue — instead of through a separate reduce launch; every launch leaves the words at
+ * zero.  Results are bit-identical to the reduce-launch path.  NULL switches it off. */
+int acimg_set_ticket_buffer(void* tickets, size_t bytes);
 size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d);
 
 /* f16x3 ("split fp16") forward convolution for frozen weights (the ResNet-50 trunk): x and w are fp32,

@@ -880,3 +880,38 @@ def test_split3_prepare_multi_equals_single_launches(device):
         assert torch.equal(a, b)
     empty = ops.PrepareJobs()
     ops.conv2d_split3_prepare_multi(plan, empty)            # nothing to do is not an error
+
+
+def test_splitk_handoff_equals_reduce_launch(device):
+    """split-K combined inside the kernel (acimg_set_ticket_buffer: ticket per tile, last arriver adds the K ranges in
+    range order) is bit-identical to the separate reduce launch, forward (bias + ReLU epilogue) and data gradient
+    (residual + mask epilogue), and leaves its ticket words at zero"""
+    from acimg import _lib, ops
+    L = _lib.load()
+    g = torch.Generator().manual_seed(31)
+    N, H, W, Cin, K = 4, 12, 16, 128, 128
+    d = ops.conv_desc(N, H, W, Cin, K, 3, 3, 1, "SAME", act=1)
+    assert ops.conv2d_fwd_tiling(d)[2] > 1
+    x, w, b = dev(rnd(g, N, H, W, Cin), device), dev(rnd(g, 3, 3, Cin, K) * 0.05, device), dev(rnd(g, K), device)
+    gy = dev(rnd(g, N, H, W, K), device)
+    res = dev(rnd(g, N, H, W, Cin), device)
+    outs = []
+    for handoff in (True, False):
+        plan = ops.Plan(device, eager=True)              # registers the ticket words
+        tick = ops._TICKETS[str(torch.device(device))]
+        if not handoff:
+            _lib.check(L.acimg_set_ticket_buffer(None, 0), "set_ticket_buffer")
+        y = torch.zeros(N, H, W, K, device=device)
+        dx = torch.zeros(N, H, W, Cin, device=device)
+        ops.conv2d_fwd(plan, d, x, w, b, y)
+        ops.conv2d_dgrad(plan, d, gy, K, w, dx, res, Cin, x, Cin)
+        torch.cuda.synchronize()
+        outs.append((y.clone(), dx.clone()))
+        assert int(tick.view(torch.int32).abs().max()) == 0
+        _lib.check(L.acimg_set_ticket_buffer(tick.data_ptr(), tick.numel()), "set_ticket_buffer")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.relu(torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().permute(3, 2, 0, 1).cpu(),
+                                                 b.double().cpu(), padding=1)).permute(0, 2, 3, 1)
+    close(outs[0][0], ref, tol=1e-5, what="split-K forward")
+    assert L.acimg_set_ticket_buffer(tick.data_ptr(), 16) != 0       # too small
+    _lib.check(L.acimg_set_ticket_buffer(tick.data_ptr(), tick.numel()), "set_ticket_buffer")
