@@ -7,31 +7,35 @@ namespace acimg {
 
 // ------------------------------------------------------------------------------------------
 // batch-norm statistics -> scale/shift (+ moving averages)
-// block = 1024 threads = 32 row groups x 32 channels; 4 independent partial sums per thread keep
+// block = 1024 threads = (1024 / CPB) row groups x CPB channels; 4 independent partial sums per thread keep
 // several loads in flight (the partials are tiny, the kernel is pure load latency)
 // ------------------------------------------------------------------------------------------
+// CPB channels per workgroup (32, or 8 when there are thousands of partial rows and few channels: the stem, the
+// full-resolution U-Net layers), 1024 / CPB row groups
+template <int CPB>
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float* stats, int rows, int C, int ld, double count, const float* gamma, const float* beta,
     float* moving_mean, float* moving_var, float decay, float eps, int training, float* scale,
     float* shift, float* save_mean, float* save_invstd) {
-    __shared__ double red[2][32][32];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    constexpr int NRG = 1024 / CPB;
+    __shared__ double red[2][NRG][CPB];
+    const int cl = threadIdx.x % CPB, rg = threadIdx.x / CPB;
+    const int c = blockIdx.x * CPB + cl;
     double s1 = 0.0, s2 = 0.0;
     if (training && c < C) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
         int r = rg;
-        for (; r + 96 < rows; r += 128) {
+        for (; r + 3 * NRG < rows; r += 4 * NRG) {
             a0 += stats[((long)r * 2 + 0) * ld + c];
             b0 += stats[((long)r * 2 + 1) * ld + c];
-            a1 += stats[((long)(r + 32) * 2 + 0) * ld + c];
-            b1 += stats[((long)(r + 32) * 2 + 1) * ld + c];
-            a2 += stats[((long)(r + 64) * 2 + 0) * ld + c];
-            b2 += stats[((long)(r + 64) * 2 + 1) * ld + c];
-            a3 += stats[((long)(r + 96) * 2 + 0) * ld + c];
-            b3 += stats[((long)(r + 96) * 2 + 1) * ld + c];
+            a1 += stats[((long)(r + NRG) * 2 + 0) * ld + c];
+            b1 += stats[((long)(r + NRG) * 2 + 1) * ld + c];
+            a2 += stats[((long)(r + 2 * NRG) * 2 + 0) * ld + c];
+            b2 += stats[((long)(r + 2 * NRG) * 2 + 1) * ld + c];
+            a3 += stats[((long)(r + 3 * NRG) * 2 + 0) * ld + c];
+            b3 += stats[((long)(r + 3 * NRG) * 2 + 1) * ld + c];
         }
-        for (; r < rows; r += 32) {
+        for (; r < rows; r += NRG) {
             a0 += stats[((long)r * 2 + 0) * ld + c];
             b0 += stats[((long)r * 2 + 1) * ld + c];
         }
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     if (training) {
         s1 = 0.0;
         s2 = 0.0;
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < NRG; ++i) {
             s1 += red[0][i][cl];
             s2 += red[1][i][cl];
         }
@@ -1035,9 +1039,14 @@ int acimg_bn_finalize(const float* stats, int rows, int C, int ldstats, double c
                       float* shift, float* save_mean, float* save_invstd, void* stream) {
     if (C <= 0 || (training && (!stats || rows <= 0 || count <= 0)) || (!training && (!moving_mean || !moving_var)))
         return fail(ACIMG_EINVAL, "bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, stats,
-                       rows, C, ldstats, count, gamma, beta, moving_mean, moving_var, decay, eps,
-                       training, scale, shift, save_mean, save_invstd);
+    if (training && rows > 1024 && C <= 64)
+        hipLaunchKernelGGL(bn_finalize_kernel<8>, dim3(cdiv(C, 8)), dim3(1024), 0, (hipStream_t)stream, stats,
+                           rows, C, ldstats, count, gamma, beta, moving_mean, moving_var, decay, eps,
+                           training, scale, shift, save_mean, save_invstd);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, stats,
+                           rows, C, ldstats, count, gamma, beta, moving_mean, moving_var, decay, eps,
+                           training, scale, shift, save_mean, save_invstd);
     return check_launch("bn_finalize");
 }
 
