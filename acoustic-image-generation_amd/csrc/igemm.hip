@@ -1336,6 +1336,10 @@ size_t acimg_deconv_workspace(const AcimgConvDesc* d) {
     size_t c = wgrad_ws_bytes(d->N * d->H * d->W, d->R * d->S * up4(d->K), d->C, d->ldw) + colsum_ws_bytes(up4(d->K));
     size_t m = a > b ? a : b;
     m = m > c ? m : c;
+    if (up4(d->K) <= 16 && d->C <= 32) {        // data gradient on the direct few-channel kernel
+        const size_t dd = direct_ws_bytes(d->R, d->S, up4(d->K), (d->C + 7) & ~7);
+        m = m > dd ? m : dd;
+    }
     if (d->R > d->stride || d->S > d->stride)   // forward goes through a zero-inserted copy of x
         m += dilated_bytes(d->N, d->H, d->W, d->C, d->stride) +
              igemm_ws_bytes(d->N * d->OH * d->OW, d->K, d->R * d->S * cdiv(d->C, 32)) +
@@ -1402,6 +1406,17 @@ int acimg_deconv_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
     const int ca = up4(d->K);
     if (ca > ldgy || (ldgy & 3) || ca != d->K) return fail(ACIMG_EINVAL, "deconv_dgrad: K must be a multiple of 4 and <= ldgy");
     // dx[n,h,w,c] = sum_{r,s,k} gy[n, h*stride+r, w*stride+s, k] * W[r][s][k][c]  (a strided conv)
+    if (!mask && direct_ok(ca, d->C, d->ldx, 0, dx, nullptr, nullptr, false, nullptr) &&
+        (long)d->N * d->H * d->W >= 65536) {
+        // few channels: the direct kernel, the [kh][kw][out][in] kernel read as the HWIO kernel of that conv
+        DirectParams q{};
+        q.x = gy; q.ldx = ldgy; q.H = d->OH; q.W = d->OW; q.C = ca;
+        q.y = dx; q.ldy = d->ldx; q.OH = d->H; q.OW = d->W; q.K = d->C;
+        q.R = d->R; q.S = d->S; q.stride = d->stride; q.pad_t = 0; q.pad_l = 0;
+        q.w = w; q.ldw = d->ldw; q.mode = 0; q.wrows = d->K; q.act = ACIMG_ACT_NONE;
+        q.M = (long)d->N * d->H * d->W;
+        return launch_direct(q, ws, ws_bytes, (hipStream_t)stream);
+    }
     IgemmParams p{};
     p.A = gy; p.H = d->OH; p.W = d->OW; p.C = ca; p.lda = ldgy; p.OH = d->H; p.OW = d->W;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad_t = 0; p.pad_l = 0;

@@ -915,3 +915,23 @@ def test_splitk_handoff_equals_reduce_launch(device):
     close(outs[0][0], ref, tol=1e-5, what="split-K forward")
     assert L.acimg_set_ticket_buffer(tick.data_ptr(), 16) != 0       # too small
     _lib.check(L.acimg_set_ticket_buffer(tick.data_ptr(), tick.numel()), "set_ticket_buffer")
+
+
+def test_deconv_dgrad_few_channels_direct(device):
+    """unet_architecture.py upsample_9 (32 -> 8, 2x2 / 2) at a size that takes the direct few-channel kernel: the data
+    gradient of the transposed conv is a strided conv of gy with the [kh][kw][out][in] kernel read as HWIO"""
+    from acimg import ops
+
+    N, H, W, Cc, K, R, S, s = 5, 112, 149, 32, 8, 2, 2, 2
+    g = torch.Generator().manual_seed(78)
+    x = rnd(g, N, H, W, Cc).requires_grad_(True)
+    w = (rnd(g, R, S, K, Cc) * 0.1).requires_grad_(True)
+    y = F.conv_transpose2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), None, stride=s).permute(0, 2, 3, 1)
+    gy = rnd(g, *y.shape)
+    y.backward(gy)
+    d = ops.deconv_desc(N, H, W, Cc, K, R, S, s)
+    plan = ops.Plan(device, eager=True)
+    dx = torch.empty(N, H, W, Cc, device=device)
+    ops.deconv_dgrad(plan, d, dev(gy, device), K, dev(w.detach(), device), dx)
+    torch.cuda.synchronize()
+    close(dx, x.grad, what="deconv dgrad (direct)")
