@@ -78,7 +78,8 @@ int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out);
  * nothing else touches.  Split-K launches of acimg_conv2d_fwd / _dgrad (and the transposed-conv entries built on
  * them) then combine their K ranges inside the kernel — ticket per output tile, the last arriver adds the ranges in
  * range order and runs the epilogue — instead of through a separate reduce launch; every launch leaves the words at
- * zero.  Results are bit-identical to the reduce-launch path.  NULL switches it off. */
+ * zero.  Results are bit-identical to the reduce-launch path.  The launches that use it must be ordered against
+ * each other (one stream, as the recorded plans are); NULL switches it off. */
 int acimg_set_ticket_buffer(void* tickets, size_t bytes);
 size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d);
 
