@@ -1348,7 +1348,10 @@ int acimg_bn_add_relu_split(const float* a, const float* sa, const float* ta, co
         return fail(ACIMG_EINVAL, "bn_add_relu_split: exactly one of b32 / b_planes");
     if (b32 && (!sb || !tb)) return fail(ACIMG_EINVAL, "bn_add_relu_split: projection shortcut needs scale/shift");
     const long total4 = (long)N * OH * OW * (C / 4);
-    hipLaunchKernelGGL(bn_add_relu_split_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, a, sa,
+    // one float4 per thread (no grid-stride loop): measured 4 % faster than 4096 persistent workgroups on this
+    // three-stream pass (16 M float4 at the 56x75x512 stage)
+    const long nblk = (total4 + 255) / 256;
+    hipLaunchKernelGGL(bn_add_relu_split_kernel, dim3((unsigned)(nblk < (1L << 22) ? nblk : (1L << 22))), dim3(256), 0, (hipStream_t)stream, a, sa,
                        ta, b32, sb, tb, static_cast<const char*>(b_planes), (long)b_lo_off,
                        static_cast<char*>(out_planes), (long)out_lo_off, out32, total4, OH, OW, C / 4, BH, BW,
                        bstride);
