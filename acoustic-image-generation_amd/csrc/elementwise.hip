@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_relu_kernel(const float* x, const floa
 }
 
 // one block per channel
-__global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* x, const float* y,
+__global__ __launch_bounds__(1024) void bn_relu_bwd_kernel(const float* x, const float* y,
                                                           const float* gy, const float* gamma,
                                                           const float* mean, const float* invstd,
                                                           float* gx, float* dgamma, float* dbeta,
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* x, const 
     const int c = blockIdx.x;
     const float mu = mean[c], is = invstd[c];
     float s1 = 0.f, s2 = 0.f;
-    for (long r = threadIdx.x; r < rows; r += 256) {
+    for (long r = threadIdx.x; r < rows; r += blockDim.x) {
         const float g = y[r * C + c] > 0.f ? gy[r * C + c] : 0.f;
         s1 += g;
         s2 += g * (x[r * C + c] - mu) * is;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_kernel(const float* x, const 
     }
     const float k = gamma[c] * is;
     const float inv_n = 1.f / (float)rows;
-    for (long r = threadIdx.x; r < rows; r += 256) {
+    for (long r = threadIdx.x; r < rows; r += blockDim.x) {
         const float g = y[r * C + c] > 0.f ? gy[r * C + c] : 0.f;
         const float xh = (x[r * C + c] - mu) * is;
         gx[r * C + c] = k * (g - s1 * inv_n - xh * s2 * inv_n);
@@ -1086,7 +1086,7 @@ int acimg_bn_relu(const float* x, const float* scale, const float* shift, float*
 int acimg_bn_relu_bwd(const float* x, const float* y, const float* gy, const float* gamma,
                       const float* save_mean, const float* save_invstd, float* gx, float* dgamma,
                       float* dbeta, long rows, int C, void* stream) {
-    hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, y, gy, gamma,
+    hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3(C), dim3(1024), 0, (hipStream_t)stream, x, y, gy, gamma,
                        save_mean, save_invstd, gx, dgamma, dbeta, rows, C);
     return check_launch("bn_relu_bwd");
 }

@@ -293,13 +293,14 @@ __global__ __launch_bounds__(256) void tapconv_unpack_kernel(const float* dwt, i
     dw[tc * ldw + k] = v;
 }
 
-// y[(n,oh,ow)][k] = sum_{r,s} z[(n,oh+r,ow+s)][(r*S+s)*K + k]; 128 output pixels per workgroup, one thread per
+constexpr int TG_PPB = 32;     // output pixels per workgroup of the gather (= rows per batch-norm partial)
+// y[(n,oh,ow)][k] = sum_{r,s} z[(n,oh+r,ow+s)][(r*S+s)*K + k]; TG_PPB output pixels per workgroup, one thread per
 // (pixel, k); optional batch-norm partials stats[block][2][stats_ld] (rows past the end count as zeros)
 __global__ __launch_bounds__(256) void tapconv_gather_kernel(const float* z, int ldz, int H, int W, int R, int S,
                                                              int K, int OH, int OW, long Mout, float* y, int ldy,
                                                              float* stats, int stats_ld) {
     extern __shared__ __attribute__((aligned(16))) float tg_smem[];     // [128][K] tile of outputs
-    const int ppb = 128;
+    const int ppb = TG_PPB;
     const long m0 = (long)blockIdx.x * ppb;
     for (int e = threadIdx.x; e < ppb * K; e += 256) {
         const int pl = e / K, k = e - pl * K;
@@ -1742,7 +1743,7 @@ static int tapconv_check(const AcimgConvDesc* d, const char* who) {
     return ACIMG_OK;
 }
 
-int acimg_tapconv_stats_rows(const AcimgConvDesc* d) { return cdiv(d->N * d->OH * d->OW, 128); }
+int acimg_tapconv_stats_rows(const AcimgConvDesc* d) { return cdiv(d->N * d->OH * d->OW, TG_PPB); }
 
 int acimg_tapconv_pack(const AcimgConvDesc* d, const float* w, float* wt, int ldwt, void* stream) {
     int rc = tapconv_check(d, "tapconv_pack");
@@ -1771,7 +1772,7 @@ int acimg_tapconv_gather(const AcimgConvDesc* d, const float* z, int ldz, float*
     const int TK = d->R * d->S * d->K;
     if (!z || !y || ldz < TK || d->ldy < d->K) return fail(ACIMG_EINVAL, "tapconv_gather: null pointer or ldz < R*S*K");
     const long Mout = (long)d->N * d->OH * d->OW;
-    hipLaunchKernelGGL(tapconv_gather_kernel, dim3(cdiv(Mout, 128)), dim3(256), (size_t)128 * d->K * 4,
+    hipLaunchKernelGGL(tapconv_gather_kernel, dim3(cdiv(Mout, TG_PPB)), dim3(256), (size_t)TG_PPB * d->K * 4,
                        (hipStream_t)stream, z, ldz, d->H, d->W, d->R, d->S, d->K, d->OH, d->OW, Mout, y, d->ldy, stats,
                        d->ldw);
     return check_launch("tapconv_gather");

@@ -316,7 +316,7 @@ int acimg_softplus_bwd(const float* x, int ldx, const float* gy, int ldgy, float
  * models/resnet50.py:205-209 / models/vision.py:60-66: 3x4, 2048 -> 12).  With T = R*S*K:
  *   pack:    wt[c][tap*K + k] = w[tap][c][k]                 (then split / multiply it as a 1x1 conv C -> T)
  *   gather:  y[(n,oh,ow)][k] = sum_taps z[(n,oh+r,ow+s)][tap*K + k]  from z = x . wt over the INPUT pixels;
- *            optional batch-norm partials stats[acimg_tapconv_stats_rows(d)][2][d->ldw] (128 pixels per row)
+ *            optional batch-norm partials stats[acimg_tapconv_stats_rows(d)][2][d->ldw]
  *   scatter: gz[(n,ih,iw)][tap*K + k] = gy[(n,ih-r,iw-s)][k]  (0 outside), so that dwt = x^T . gz is a 1x1
  *            weight gradient
  *   unpack:  dw[tap][c][k] = dwt[c][tap*K + k] + decay * w[tap][c][k]   (w optional: slim's L2 term)
