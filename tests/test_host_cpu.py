@@ -206,3 +206,34 @@ def test_frontend_tables_match_oracle():
     ref = ofe.find_logen(x)
     got = 1.0 / np.exp(x @ t["idct"]).sum(-1)
     np.testing.assert_allclose(got, ref, rtol=1e-12)
+
+
+def test_bench_contract_on_cpu():
+    """bench.py: defaults of the driver contract, the cpu_baseline object on a one-image sample, and NO CPU fallback —
+    without a GPU the measured path must fail loudly instead of timing something else"""
+    import importlib.util
+    import subprocess
+    import sys
+    import types
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        spec.loader.exec_module(bench)
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    assert (args.gpus, args.batch, args.workload, args.precision) == (1, 32, "trainer_mask", "f16x3")
+    assert args.steps * 0.01 < 60 and args.warmup >= 1          # minutes at ~10 ms / step
+    small = types.SimpleNamespace(num_skip=1, cpu_batch=1, cpu_steps=1)
+    cb = bench.cpu_baseline(small)
+    assert set(cb) == {"value", "unit", "cores", "kind", "sample"} and cb["kind"] == "port" and cb["value"] > 0
+    assert cb["unit"] == "images/s" and cb["cores"] >= 1
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0",
+                            "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "{" not in r.stdout, r.stdout[-500:]
