@@ -23,6 +23,14 @@ class ConvDesc(C.Structure):
         return "ConvDesc(" + ", ".join("%s=%d" % (n, getattr(self, n)) for n, _ in self._fields_) + ")"
 
 
+class Config(C.Structure):
+    """Mirror of AcimgConfig (include/acimg.h): the launch heuristics' tuning record."""
+
+    _fields_ = [(n, C.c_int32) for n in (
+        "splitk_cut", "splitk_target", "splitk_handoff", "wgrad_minpix", "wgrad_halo", "split3_tile_bm",
+        "split3_tile_bn", "tail_split", "tail_s")]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_long
@@ -35,10 +43,11 @@ _DP = C.POINTER(ConvDesc)
 PROTOTYPES = {
     "acimg_version": (_I, []),
     "acimg_last_error": (_I, [C.c_char_p, _SZ]),
-    "acimg_conv2d_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _P, _I, _P, _P, _SZ, _P]),
+    "acimg_conv2d_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _P, _I, _P, _P, _SZ, _P, _P]),
     "acimg_conv2d_stats_rows": (_I, [_DP]),
     "acimg_conv2d_fwd_tiling": (_I, [_DP, C.POINTER(C.c_int)]),
-    "acimg_set_ticket_buffer": (_I, [_P, _SZ]),
+    "acimg_config_default": (_I, [C.POINTER(Config)]),
+    "acimg_configure": (_I, [C.POINTER(Config)]),
     "acimg_conv2d_fwd_workspace": (_SZ, [_DP]),
     "acimg_conv2d_split3_weight_bytes": (_SZ, [_DP]),
     "acimg_conv2d_split3_prepare": (_I, [_DP, _P, _P, _P]),
@@ -54,13 +63,13 @@ PROTOTYPES = {
     "acimg_bn_relu_split": (_I, [_P, _P, _P, _I, _P, _SZ, _L, _I, _P]),
     "acimg_bn_add_relu_split": (_I, [_P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "acimg_bn_relu_maxpool_split": (_I, [_P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "acimg_conv2d_dgrad": (_I, [_DP, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _SZ, _P]),
+    "acimg_conv2d_dgrad": (_I, [_DP, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _SZ, _P, _P]),
     "acimg_conv2d_dgrad_workspace": (_SZ, [_DP]),
     "acimg_conv2d_wgrad": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),
     "acimg_conv2d_wgrad_workspace": (_SZ, [_DP]),
     "acimg_conv2d_wgrad_split3": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),
-    "acimg_deconv_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _SZ, _P]),
-    "acimg_deconv_dgrad": (_I, [_DP, _P, _I, _P, _P, _P, _I, _P, _SZ, _P]),
+    "acimg_deconv_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _SZ, _P, _P]),
+    "acimg_deconv_dgrad": (_I, [_DP, _P, _I, _P, _P, _P, _I, _P, _SZ, _P, _P]),
     "acimg_deconv_wgrad": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),
     "acimg_deconv_workspace": (_SZ, [_DP]),
     "acimg_bn_finalize": (_I, [_P, _I, _I, _I, _D, _P, _P, _P, _P, _F, _F, _I, _P, _P, _P, _P, _P]),
@@ -140,7 +149,39 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    configure_from_env()
     return lib
+
+
+def configure(**kw):
+    """acimg_configure with the compiled-in defaults overridden by `kw` (AcimgConfig field names)"""
+    cfg = Config()
+    check(_lib.acimg_config_default(C.byref(cfg)), "config_default")
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise AcimgError("unknown tuning field %r" % k)
+        setattr(cfg, k, int(v))
+    check(_lib.acimg_configure(C.byref(cfg)), "configure")
+    return cfg
+
+
+def configure_from_env(env=None):
+    """The experiment switches of tools/ (ACIMG_* environment variables) are read HERE, once, when the library is
+    loaded, and handed to acimg_configure: the library itself never reads the environment."""
+    env = os.environ if env is None else env
+    kw = {}
+    for var, field in (("ACIMG_SPLITK_CUT", "splitk_cut"), ("ACIMG_SPLITK_TARGET", "splitk_target"),
+                       ("ACIMG_WGRAD_MINPIX", "wgrad_minpix"), ("ACIMG_TAIL_S", "tail_s")):
+        if env.get(var):
+            kw[field] = int(env[var])
+    for var, field in (("ACIMG_NO_SPLITK_HANDOFF", "splitk_handoff"), ("ACIMG_NO_WGRAD_HALO", "wgrad_halo"),
+                       ("ACIMG_NO_TAIL_SPLIT", "tail_split")):
+        if env.get(var):
+            kw[field] = 0
+    if env.get("ACIMG_SPLIT3_TILE"):
+        bm, bn = env["ACIMG_SPLIT3_TILE"].lower().split("x")
+        kw["split3_tile_bm"], kw["split3_tile_bn"] = int(bm), int(bn)
+    return configure(**kw) if kw else None
 
 
 def last_error():

@@ -52,6 +52,15 @@ class Workspace(object):
         self.need = 256
         self.buf = None
         self.version = 0
+        self._tickets = None
+
+    @property
+    def tickets(self):
+        """ACIMG_TICKET_WORDS zeroed ints for the in-kernel split-K combine (include/acimg.h): owned by this
+        workspace, i.e. by the one stream its plans run on; every launch leaves them at zero"""
+        if self._tickets is None and torch.device(self.device).type == "cuda":
+            self._tickets = torch.zeros(TICKET_WORDS, dtype=torch.int32, device=self.device)
+        return self._tickets
 
     def require(self, nbytes):
         self.need = max(self.need, int(nbytes))
@@ -69,6 +78,16 @@ class Workspace(object):
     @property
     def nbytes(self):
         return self.buf.numel()
+
+
+TICKET_WORDS = 4096   # ACIMG_TICKET_WORDS
+
+
+class _Tickets(object):
+    """resolves to the workspace's ticket block (None without a GPU, or when `off`)"""
+
+    def __init__(self, ws, off=False):
+        self.ws, self.off = ws, off
 
 
 class _WsPtr(object):
@@ -92,6 +111,9 @@ def _resolve(a):
         return a.ws.ptr
     if isinstance(a, _WsBytes):
         return a.ws.nbytes
+    if isinstance(a, _Tickets):
+        t = None if a.off else a.ws.tickets
+        return None if t is None else t.data_ptr()
     if isinstance(a, _JobsArg):
         return a.value()
     return a
@@ -143,7 +165,6 @@ class Plan(object):
 
     def __init__(self, device=None, eager=False, ws=None):
         self.device = device
-        ensure_tickets(device)
         self.eager = eager
         self.ws = ws if ws is not None else Workspace(device)
         self.calls = []      # (name, fn, raw args); args None => host hook
@@ -285,7 +306,7 @@ def conv2d_fwd(plan, d, x, w, bias, y, in_scale=None, in_shift=None, in_relu=0, 
     L = _L()
     plan.ws.require(L.acimg_conv2d_fwd_workspace(C.byref(d)))
     plan.add("conv2d_fwd", L.acimg_conv2d_fwd, C.byref(d), x, w, bias, y, in_scale, in_shift,
-             int(in_relu), stats, _WsPtr(plan.ws), _WsBytes(plan.ws))
+             int(in_relu), stats, _WsPtr(plan.ws), _WsBytes(plan.ws), _Tickets(plan.ws))
 
 
 def conv2d_split3_weight_bytes(d):
@@ -360,7 +381,7 @@ def conv2d_dgrad(plan, d, gy, ldgy, w, dx, residual=None, ldres=0, mask=None, ld
     L = _L()
     plan.ws.require(L.acimg_conv2d_dgrad_workspace(C.byref(d)))
     plan.add("conv2d_dgrad", L.acimg_conv2d_dgrad, C.byref(d), gy, int(ldgy), w, dx, int(lddx), residual,
-             int(ldres), mask, int(ldmask), _WsPtr(plan.ws), _WsBytes(plan.ws))
+             int(ldres), mask, int(ldmask), _WsPtr(plan.ws), _WsBytes(plan.ws), _Tickets(plan.ws))
 
 
 def conv2d_wgrad(plan, d, x, gy, ldgy, dw, db=None):
@@ -381,14 +402,14 @@ def deconv_fwd(plan, d, x, w, bias, y):
     L = _L()
     plan.ws.require(L.acimg_deconv_workspace(C.byref(d)))
     plan.add("deconv_fwd", L.acimg_deconv_fwd, C.byref(d), x, w, bias, y, _WsPtr(plan.ws),
-             _WsBytes(plan.ws))
+             _WsBytes(plan.ws), _Tickets(plan.ws))
 
 
 def deconv_dgrad(plan, d, gy, ldgy, w, dx, mask=None, ldmask=0):
     L = _L()
     plan.ws.require(L.acimg_deconv_workspace(C.byref(d)))
     plan.add("deconv_dgrad", L.acimg_deconv_dgrad, C.byref(d), gy, int(ldgy), w, dx, mask,
-             int(ldmask), _WsPtr(plan.ws), _WsBytes(plan.ws))
+             int(ldmask), _WsPtr(plan.ws), _WsBytes(plan.ws), _Tickets(plan.ws))
 
 
 def deconv_wgrad(plan, d, x, gy, ldgy, dw, db=None):
@@ -540,21 +561,6 @@ def clip_softmax_ce(plan, logits, ldl, clips, F, K, labels, out, g_logits, ldg):
 
 
 _LOSS_SCRATCH = {}
-_TICKETS = {}
-
-
-def ensure_tickets(device):
-    """register (once per process; one process per GPU) the zeroed ticket words that let split-K launches combine
-    their K ranges inside the kernel (acimg_set_ticket_buffer); kept alive for the life of the process"""
-    if device is None or torch.device(device).type != "cuda" or not torch.cuda.is_available():
-        return
-    key = str(torch.device(device))
-    if key not in _TICKETS:
-        _TICKETS[key] = torch.zeros(16384, dtype=torch.uint8, device=device)
-        _lib.check(_L().acimg_set_ticket_buffer(_TICKETS[key].data_ptr(), 16384), "set_ticket_buffer")
-
-
-
 
 def loss_scratch(device):
     """the dedicated, zero-initialised hand-off buffer that makes acimg_recon_loss / acimg_sumsq bit-reproducible (one

@@ -635,11 +635,14 @@ static TileCfg pick_cfg(int M, int Ngemm) {
     return {128, 128};
 }
 
+// Tuning record (acimg_configure): plain ints, defaults compiled in, written only by acimg_configure and never by a
+// launch; the launch heuristics below read it instead of the process environment.
+static AcimgConfig g_cfg = {320, 768, 1, 128, 1, 0, 0, 1, 0};
+
 static int pick_splits(int M, int Ngemm, TileCfg c, int kiters) {
     // measured on the generator's 12x16 layers (192-288 tiles of 64x64, 36+ K steps: tools/splitk_sweep.sh):
     // below ~1.25 workgroups per CU a K split towards ~3 per CU pays for its reduce pass
-    static const int cut = getenv("ACIMG_SPLITK_CUT") ? atoi(getenv("ACIMG_SPLITK_CUT")) : 320;
-    static const int target = getenv("ACIMG_SPLITK_TARGET") ? atoi(getenv("ACIMG_SPLITK_TARGET")) : 768;
+    const int cut = g_cfg.splitk_cut, target = g_cfg.splitk_target;
     const long tiles = (long)cdiv(M, c.bm) * cdiv(Ngemm, c.bn);
     if (tiles >= cut || kiters < 8) return 1;
     long s = (target + tiles - 1) / tiles;
@@ -648,11 +651,6 @@ static int pick_splits(int M, int Ngemm, TileCfg c, int kiters) {
     if (s < 1) s = 1;
     return (int)s;
 }
-
-// caller-owned ticket words for the in-kernel split-K hand-off (acimg_set_ticket_buffer): zero-initialised once,
-// dedicated to this library, every launch leaves them at zero
-static int* g_tickets = nullptr;
-static size_t g_ticket_words = 0;
 
 static size_t igemm_ws_bytes(int M, int Ngemm, int kiters) {
     TileCfg c = pick_cfg(M, Ngemm);
@@ -682,7 +680,8 @@ static void launch_cfg(const IgemmParams& p, bool nt, bool cal, dim3 grid, hipSt
     }
 }
 
-static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipStream_t st) {
+// tickets: ACIMG_TICKET_WORDS zeroed ints owned by the caller (or nullptr: split-K combines through a reduce launch)
+static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, void* tickets, hipStream_t st) {
     if (p.M <= 0 || p.Ngemm <= 0) return fail(ACIMG_EINVAL, "igemm: empty problem");
     if ((p.C & 3) || (p.lda & 3) || (p.ldb & 3))
         return fail(ACIMG_EINVAL, "igemm: C=%d lda=%d ldb=%d must be multiples of 4", p.C, p.lda, p.ldb);
@@ -723,12 +722,14 @@ static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipSt
     if (p.splits > 1) {
         size_t need = (size_t)p.splits * p.M * p.slab_ld * sizeof(float);
         const size_t tiles = (size_t)grid.x * grid.y;
-        const bool handoff = g_tickets != nullptr && tiles <= g_ticket_words && !getenv("ACIMG_NO_SPLITK_HANDOFF");
+        if (tickets && (reinterpret_cast<uintptr_t>(tickets) & 15))
+            return fail(ACIMG_EINVAL, "igemm: ticket words must be 16-byte aligned");
+        const bool handoff = tickets != nullptr && tiles <= ACIMG_TICKET_WORDS && g_cfg.splitk_handoff;
         if (handoff) need = (size_t)p.splits * tiles * c.bm * c.bn * sizeof(float);
         if (ws == nullptr || ws_bytes < need)
             return fail(ACIMG_EWORKSPACE, "igemm: workspace %zu < %zu", ws_bytes, need);
         p.slab = static_cast<float*>(ws);
-        if (handoff) p.ts_counters = g_tickets;
+        if (handoff) p.ts_counters = static_cast<int*>(tickets);
     }
     if (c.bm == 128 && c.bn == 128) launch_cfg<128, 128, 2, 4, 512>(p, nt, cal, grid, st);
     else if (c.bm == 128 && c.bn == 64) launch_cfg<128, 64, 2, 2, 256>(p, nt, cal, grid, st);
@@ -755,7 +756,7 @@ static int launch_igemm(IgemmParams p, bool nt, void* ws, size_t ws_bytes, hipSt
 static int pick_wgrad_splits(int M, int KK, int Ngemm, int bmo, int bn) {
     const long tiles = (long)cdiv(KK, bmo) * cdiv(Ngemm, bn);
     long s = (512 + tiles - 1) / tiles;   // ~2 workgroups per CU; every split costs a KK x N slab round trip
-    static const int minpix = getenv("ACIMG_WGRAD_MINPIX") ? atoi(getenv("ACIMG_WGRAD_MINPIX")) : 128;
+    const int minpix = g_cfg.wgrad_minpix;
     const long maxs = (M + minpix - 1) / minpix;  // at least `minpix` pixels per split
     long cap = 128;
     if ((long)KK * Ngemm <= 8192) {       // few-channel layers (the RGB / spectrogram U-Nets: 72 x 8 ... 288 x 32
@@ -984,7 +985,7 @@ static size_t wgrad_halo_lds(int R, int S, int C, int Kp, int stride) {
 static bool wgrad_halo_ok(const WgradParams& p) {
     return (p.C == 4 || p.C == 8 || p.C == 16) && p.Nld <= 16 && p.Ngemm == p.Nld && p.stride == 1 && p.R <= 3 && p.S <= 3 && (long)p.M >= 65536 && (p.ldx & 3) == 0 && (p.ldg & 3) == 0 &&
            (p.KK + 1 + 15) / 16 <= WH_MAXT && wgrad_halo_lds(p.R, p.S, p.C, p.Nld, p.stride) <= 65536 &&
-           !getenv("ACIMG_NO_WGRAD_HALO");
+           g_cfg.wgrad_halo;
 }
 
 // db (optional): fused bias gradient, db[n] = sum_m G[m][n] for n < Ngemm
@@ -1174,11 +1175,22 @@ int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
     return ACIMG_OK;
 }
 
-int acimg_set_ticket_buffer(void* tickets, size_t bytes) {
-    if (tickets && (bytes < 4096 || (reinterpret_cast<uintptr_t>(tickets) & 15)))
-        return fail(ACIMG_EINVAL, "set_ticket_buffer: need >= 4096 zeroed bytes, 16-byte aligned");
-    g_tickets = static_cast<int*>(tickets);
-    g_ticket_words = tickets ? bytes / sizeof(int) : 0;
+int acimg_config_default(AcimgConfig* c) {
+    if (!c) return fail(ACIMG_EINVAL, "config_default: null");
+    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0};
+    return ACIMG_OK;
+}
+
+int acimg_configure(const AcimgConfig* c) {
+    if (!c) return fail(ACIMG_EINVAL, "configure: null");
+    if (c->splitk_cut < 0 || c->splitk_target < 1 || c->wgrad_minpix < 1 || c->tail_s < 0)
+        return fail(ACIMG_EINVAL, "configure: negative / zero tuning value");
+    if (c->split3_tile_bm || c->split3_tile_bn) {
+        const int bm = c->split3_tile_bm, bn = c->split3_tile_bn;
+        if (!((bm == 128 && bn == 128) || (bm == 64 && bn == 128) || (bm == 128 && bn == 64)))
+            return fail(ACIMG_EINVAL, "configure: split3 tile %dx%d is not an instantiated tile", bm, bn);
+    }
+    g_cfg = *c;
     return ACIMG_OK;
 }
 
@@ -1190,7 +1202,7 @@ size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d) {
 
 int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
                      float* y, const float* in_scale, const float* in_shift, int in_relu,
-                     float* stats, void* ws, size_t ws_bytes, void* stream) {
+                     float* stats, void* ws, size_t ws_bytes, void* tickets, void* stream) {
     int rc = check_desc(d, "conv2d_fwd");
     if (rc) return rc;
     if (d->ldw < d->K) return fail(ACIMG_EINVAL, "conv2d_fwd: ldw < K");
@@ -1222,7 +1234,7 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
     p.B = w; p.ldb = d->ldw; p.Nld = d->ldw; p.Ngemm = d->K; p.tap_stride = 0; p.flip = 0;
     p.e.Y = y; p.e.ldy = d->ldy; p.e.M = p.M; p.e.Nstore = d->K; p.e.bias = bias; p.e.act = d->act;
     p.e.stats = stats; p.e.stats_ld = d->ldw;
-    return launch_igemm(p, false, ws, ws_bytes, (hipStream_t)stream);
+    return launch_igemm(p, false, ws, ws_bytes, tickets, (hipStream_t)stream);
 }
 
 static bool dgrad_is_patch(const AcimgConvDesc* d) {
@@ -1249,7 +1261,7 @@ size_t acimg_conv2d_dgrad_workspace(const AcimgConvDesc* d) {
 
 int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
                        float* dx, int lddx, const float* residual, int ldres, const float* mask,
-                       int ldmask, void* ws, size_t ws_bytes, void* stream) {
+                       int ldmask, void* ws, size_t ws_bytes, void* tickets, void* stream) {
     int rc = check_desc(d, "conv2d_dgrad");
     if (rc) return rc;
     const int ca = up4(d->K);
@@ -1276,7 +1288,7 @@ int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
         AcimgConvDesc d1 = *d;
         d1.stride = 1; d1.OH = OH1; d1.OW = OW1;
         return acimg_conv2d_dgrad(&d1, static_cast<const float*>(ws), ca, w, dx, lddx, residual, ldres, mask, ldmask,
-                                  static_cast<char*>(ws) + db, ws_bytes - db, stream);
+                                  static_cast<char*>(ws) + db, ws_bytes - db, tickets, stream);
     }
     if (d->stride == 1 && direct_ok(ca, d->C, lddx, ldres, dx, nullptr, residual, false, mask) &&
         (long)d->N * d->H * d->W >= 65536) {
@@ -1310,7 +1322,7 @@ int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
         p.e.scatter = 1; p.e.Ko = d->C; p.e.Sq = d->S; p.e.sc = d->stride;
         p.e.YH = d->H; p.e.YW = d->W; p.e.AH = d->OH; p.e.AW = d->OW;
     }
-    return launch_igemm(p, true, ws, ws_bytes, (hipStream_t)stream);
+    return launch_igemm(p, true, ws, ws_bytes, tickets, (hipStream_t)stream);
 }
 
 size_t acimg_conv2d_wgrad_workspace(const AcimgConvDesc* d) {
@@ -1349,7 +1361,7 @@ size_t acimg_deconv_workspace(const AcimgConvDesc* d) {
 }
 
 int acimg_deconv_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
-                     float* y, void* ws, size_t ws_bytes, void* stream) {
+                     float* y, void* ws, size_t ws_bytes, void* tickets, void* stream) {
     int rc = check_desc(d, "deconv_fwd");
     if (rc) return rc;
     if (d->ldw < d->C || (d->K & 3)) return fail(ACIMG_EINVAL, "deconv_fwd: ldw<C or K%%4");
@@ -1377,7 +1389,7 @@ int acimg_deconv_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
         p.tap_stride = (long)d->K * d->ldw; p.flip = 1;
         p.Ngemm = d->K;
         p.e.Y = y; p.e.ldy = d->ldy; p.e.M = p.M; p.e.Nstore = d->K; p.e.bias = bias; p.e.act = d->act;
-        return launch_igemm(p, true, static_cast<char*>(ws) + db, ws_bytes - db, (hipStream_t)stream);
+        return launch_igemm(p, true, static_cast<char*>(ws) + db, ws_bytes - db, tickets, (hipStream_t)stream);
     }
     if (d->OH != d->H * d->stride || d->OW != d->W * d->stride)
         return fail(ACIMG_EINVAL, "deconv_fwd: kernel<=stride needs OH=H*stride");
@@ -1388,7 +1400,7 @@ int acimg_deconv_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
     p.e.Y = y; p.e.ldy = d->ldy; p.e.M = p.M; p.e.Nstore = p.Ngemm; p.e.bias = bias; p.e.act = d->act;
     p.e.scatter = 1; p.e.Ko = d->K; p.e.Sq = d->S; p.e.sc = d->stride;
     p.e.YH = d->OH; p.e.YW = d->OW; p.e.AH = d->H; p.e.AW = d->W;
-    rc = launch_igemm(p, true, ws, ws_bytes, (hipStream_t)stream);
+    rc = launch_igemm(p, true, ws, ws_bytes, tickets, (hipStream_t)stream);
     if (rc) return rc;
     if (d->R < d->stride || d->S < d->stride) {
         const long pixels = (long)d->N * d->OH * d->OW;
@@ -1401,7 +1413,7 @@ int acimg_deconv_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
 
 int acimg_deconv_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
                        float* dx, const float* mask, int ldmask, void* ws, size_t ws_bytes,
-                       void* stream) {
+                       void* tickets, void* stream) {
     int rc = check_desc(d, "deconv_dgrad");
     if (rc) return rc;
     const int ca = up4(d->K);
@@ -1425,7 +1437,7 @@ int acimg_deconv_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
     p.rowrun = (d->S > 1 && ldgy == ca) ? 1 : 0;
     p.B = w; p.ldb = d->ldw; p.Nld = d->ldw; p.Ngemm = d->C;
     p.e.Y = dx; p.e.ldy = d->ldx; p.e.M = p.M; p.e.Nstore = d->C; p.e.mask = mask; p.e.ldmask = ldmask;
-    return launch_igemm(p, false, ws, ws_bytes, (hipStream_t)stream);
+    return launch_igemm(p, false, ws, ws_bytes, tickets, (hipStream_t)stream);
 }
 
 int acimg_deconv_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
@@ -1457,11 +1469,8 @@ struct Split3Cfg { int bm, bn; };
 static Split3Cfg pick_split3(int M, int K, bool allow32 = false) {
     if (K <= 32 && allow32) return {128, 32};     // on-the-fly kernel only (32-channel U-Net layers)
     if (K <= 64) return {128, 64};
-    if (const char* ov = getenv("ACIMG_SPLIT3_TILE")) {   // experiments only: "BMxBN"
-        int bm = 0, bn = 0;
-        if (sscanf(ov, "%dx%d", &bm, &bn) == 2 && ((bm == 128 && bn == 128) || (bm == 64 && bn == 128) ||
-                                                   (bm == 128 && bn == 64)))
-            return {bm, bn};
+    if (g_cfg.split3_tile_bm) {   // experiments only (acimg_configure validated the pair)
+        return {g_cfg.split3_tile_bm, g_cfg.split3_tile_bn};
     }
     if ((long)cdiv(M, 128) * cdiv(K, 128) < 200) return {64, 128};
     return {128, 128};
@@ -1647,9 +1656,9 @@ static int resident_slots(int which, const void* fn, int threads, size_t lds) {
 static TailPlan pick_tail(int T, int P, int KI, int max_units) {
     const int rem = T % P;
     TailPlan best{T, 1, 0};
-    if (rem == 0 || getenv("ACIMG_NO_TAIL_SPLIT")) return best;
-    if (const char* f = getenv("ACIMG_TAIL_S")) {   // experiments only: force the number of K ranges
-        const int s = atoi(f);
+    if (rem == 0 || !g_cfg.tail_split) return best;
+    if (g_cfg.tail_s) {   // experiments only: force the number of K ranges
+        const int s = g_cfg.tail_s;
         if (s > 1 && KI / s >= 1 && (long)rem * s <= max_units) return TailPlan{T - rem, s, rem};
         return best;
     }

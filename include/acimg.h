@@ -9,8 +9,11 @@
  * Conventions (all entry points):
  *   - return 0 on success, a negative ACIMG_E* code otherwise; acimg_last_error() holds text;
  *     nothing is thrown across the boundary;
- *   - the CALLER owns every buffer (device pointers, 16-byte aligned), including workspace;
- *     the library allocates nothing and keeps no mutable global state;
+ *   - the CALLER owns every buffer (device pointers, 16-byte aligned), including workspace and the
+ *     ticket words of the in-kernel reductions (explicit `tickets` / scratch arguments); the library
+ *     allocates nothing.  Its only process-wide state is the tuning record of acimg_configure() (nine
+ *     plain ints with compiled-in defaults, written by that call alone, never by a launch, and never
+ *     read from the process environment) and the per-thread text of acimg_last_error();
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*), no host sync;
  *   - tensors are NHWC float32; a tensor is (ptr, C, ld): C logical channels per pixel and
  *     ld >= C the pixel stride in floats, so producers can write straight into channel slices
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ACIMG_VERSION 100
+#define ACIMG_VERSION 200
 
 #define ACIMG_OK 0
 #define ACIMG_EINVAL (-1)     /* bad descriptor / shape / alignment */
@@ -70,17 +73,35 @@ typedef struct AcimgConvDesc {
  *           slim layers.conv2d / resnet_utils.conv2d_same   models/resnet50.py:109-121,205-209 */
 int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
                      float* y, const float* in_scale, const float* in_shift, int in_relu,
-                     float* stats, void* ws, size_t ws_bytes, void* stream);
+                     float* stats, void* ws, size_t ws_bytes, void* tickets, void* stream);
 int acimg_conv2d_stats_rows(const AcimgConvDesc* d);
 /* out[3] = {BM, BN, split-K factor} the forward launch will use (profiling / roofline bookkeeping) */
 int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out);
-/* Optional, once per process (one process per GPU): hand the library `bytes` (>= 4096) of ZEROED device memory that
- * nothing else touches.  Split-K launches of acimg_conv2d_fwd / _dgrad (and the transposed-conv entries built on
- * them) then combine their K ranges inside the kernel — ticket per output tile, the last arriver adds the ranges in
- * range order and runs the epilogue — instead of through a separate reduce launch; every launch leaves the words at
- * zero.  Results are bit-identical to the reduce-launch path.  The launches that use it must be ordered against
- * each other (one stream, as the recorded plans are); NULL switches it off. */
-int acimg_set_ticket_buffer(void* tickets, size_t bytes);
+/* `tickets` argument of acimg_conv2d_fwd / _dgrad and acimg_deconv_fwd / _dgrad: NULL, or ACIMG_TICKET_WORDS ints of
+ * ZEROED device memory (16-byte aligned) owned by the caller and written by nothing else.  With it, a split-K launch
+ * combines its K ranges inside the kernel — one ticket per output tile, the last arriver adds the ranges in range
+ * order and runs the epilogue — instead of through a separate reduce launch; every launch leaves the words at zero and
+ * results are bit-identical to the reduce-launch path.  Launches sharing one ticket block must be ordered against each
+ * other (one stream, as the recorded plans are): use one block per stream. */
+#define ACIMG_TICKET_WORDS 4096
+
+/* Tuning record of the launch heuristics.  acimg_config_default() fills in the compiled-in values;
+ * acimg_configure() installs a record (validate, copy).  Call it before the first launch, from one thread; launches
+ * only read it.  The library never reads the process environment (the Python host maps ACIMG_* variables onto this
+ * call once, at load time: acimg/_lib.py). */
+typedef struct AcimgConfig {
+    int32_t splitk_cut;      /* f32 implicit GEMM: no K split at or above this many output tiles (320) */
+    int32_t splitk_target;   /* ... otherwise split towards this many workgroups (768) */
+    int32_t splitk_handoff;  /* 1: combine K ranges in-kernel when `tickets` is given; 0: always the reduce launch */
+    int32_t wgrad_minpix;    /* weight gradients: at least this many pixels per slab (128) */
+    int32_t wgrad_halo;      /* 1: few-channel weight gradients on the halo kernel */
+    int32_t split3_tile_bm;  /* 0 = per-shape choice; else force the split-MFMA tile (experiments): 128x128, 64x128, */
+    int32_t split3_tile_bn;  /*     128x64 */
+    int32_t tail_split;      /* 1: trunk kernel cuts the tiles of the last partial round into K ranges */
+    int32_t tail_s;          /* 0 = cost model; else force that many K ranges (experiments) */
+} AcimgConfig;
+int acimg_config_default(AcimgConfig* cfg);
+int acimg_configure(const AcimgConfig* cfg);
 size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d);
 
 /* f16x3 ("split fp16") forward convolution for frozen weights (the ResNet-50 trunk): x and w are fp32,
@@ -159,7 +180,7 @@ int acimg_bn_relu_maxpool_split(const float* x, const float* scale, const float*
  *           (trainer/mfcctrainer.py:72-79). */
 int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
                        float* dx, int lddx, const float* residual, int ldres, const float* mask,
-                       int ldmask, void* ws, size_t ws_bytes, void* stream);
+                       int ldmask, void* ws, size_t ws_bytes, void* tickets, void* stream);
 size_t acimg_conv2d_dgrad_workspace(const AcimgConvDesc* d);
 
 /* Weight + bias gradient: dw[R][S][C][ldw] = sum_pixels x (*) gy, db[k] = sum gy (db optional).
@@ -181,10 +202,10 @@ int acimg_conv2d_wgrad_split3(const AcimgConvDesc* d, const float* x, const floa
  * Every input pixel writes a disjoint RxS patch; the remaining positions get the bias only.
  * Replaces: tf.layers.conv2d_transpose  models/unet_acresnet.py:210-217 (call :86). */
 int acimg_deconv_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
-                     float* y, void* ws, size_t ws_bytes, void* stream);
+                     float* y, void* ws, size_t ws_bytes, void* tickets, void* stream);
 int acimg_deconv_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
                        float* dx, const float* mask, int ldmask, void* ws, size_t ws_bytes,
-                       void* stream);
+                       void* tickets, void* stream);
 int acimg_deconv_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
                        float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
 size_t acimg_deconv_workspace(const AcimgConvDesc* d);

@@ -104,3 +104,67 @@ def test_classifier_on_generated_images_step():
         assert moved == k.startswith("DualCamNet/"), k
     ev = tr.eval_step(None, eps)
     assert abs(ev["loss"] - tr.train_step(None, eps)["loss"]) < 1e-5
+
+
+def test_configs4_classifier_step_at_60_frames():
+    """BASELINE configs[4] at its per-GPU size (60 frames = 5 clips of 12 per GPU, global 480 on 8 GPUs):
+    the train step of trainer/trainer_reconstructed_class.py:31-75 — ResNet-50-mod + UNetAcRes in inference mode
+    (is_training 0, :183-186), clips of 12 generated frames (:44), DualCamNet per frame, clip-mean logits (:47-51),
+    softmax CE (:52-56), Adam on DualCamNet/* (:61,71-73) — against the oracle on identical weights, inputs and noise:
+    generated images 1e-3, loss / accuracy, every DualCamNet gradient 1e-3, TF-1 Adam update."""
+    from acimg.dualcamnet import DualCamHybridModel
+    from acimg.flags import FLAGS
+    from acimg.session import Session
+    from acimg.trainer_class import TrainerClass
+    from acimg.unet_acresnet import UNetAc
+    from acimg.vision import ResNet50Model
+    from oracle import dualcamnet as odc
+    from oracle import tfsem
+    from oracle import trainer as otr
+
+    dev = torch.device("cuda:0")
+    FLAGS.model, FLAGS.ae = "DualCamNet", 0
+    NF, K, lr = 60, 14, 1e-3
+    clips = NF // 12
+    sess = Session(dev)
+    m = DualCamHybridModel(input_shape=[36, 48, 12], num_classes=K)
+    tr = TrainerClass(m, ResNet50Model(input_shape=[224, 298, 3], num_classes=None),
+                      UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=1), learning_rate=lr, session=sess)
+    g = tr._build_functions(batch_size=NF)
+    orc = otr.Oracle(num_skip=1, randomize=True)
+    params = odc.init_params(K, seed=11, dtype=torch.float32, std=0.05, bias_std=0.05)
+    state = dict(orc.state_dict())
+    state.update(params)
+    sess.store.load_state(m._to_internal(state), strict=True)
+    _, mfcc, video, eps = otr.synthetic_batch(NF, seed=123)
+    labels = torch.tensor([1, 5, 0, 13, 7])
+    before = sess.store.state_dict()
+    got = tr.train_step((mfcc, video, labels), eps)
+    with torch.no_grad():
+        _, _, gen_ref, _ = orc.forward(video, mfcc, eps, False)
+    assert rel(tr.model_encoder_acoustic.output, gen_ref) < 1e-3, "generated frames"
+    masks = {"conv1": (m.relu1.t > 0).cpu(), "conv2": (m.relu2.t > 0).cpu(), "conv3": (m.relu3.t > 0).cpu(),
+             "full1": (m.relu4 > 0).cpu()}
+    # the classifier differentiates from OUR generated frames (the generator is checked above, and frozen here)
+    x = tr.model_encoder_acoustic.output.detach().cpu().double()
+    p64 = {k: v.double() for k, v in params.items()}
+    ref = odc.train_step_grads(p64, x, labels, relu_masks=masks)
+    free = odc.train_step_grads(p64, gen_ref.double(), labels)
+    flips = sum(int((masks[k].reshape(-1) != free["masks"][k].reshape(-1)).sum()) for k in masks)
+    elems = sum(v.numel() for v in masks.values())
+    assert flips <= max(8, 3.2e-6 * elems), (flips, elems)
+    assert abs(got["loss"] - ref["loss"]) <= 1e-4 * abs(ref["loss"]), (got, ref["loss"])
+    assert abs(got["loss"] - free["loss"]) <= 1e-3 * abs(free["loss"])
+    assert abs(got["accuracy"] - ref["accuracy"]) < 1e-6
+    assert rel(m.logits[:, :K], ref["frame_logits"]) < 1e-4
+    grads = sess.store.grad_dict()
+    for name, gref in ref["grads"].items():
+        assert rel(grads[name].reshape(gref.shape), gref) < 1e-3, (name, rel(grads[name].reshape(gref.shape), gref))
+    after = sess.store.state_dict()
+    for k in before:
+        if k.startswith("DualCamNet/"):
+            p2, _, _ = tfsem.adam_tf1(before[k].double(), grads[k].double().reshape(before[k].shape),
+                                      torch.zeros_like(before[k]).double(), torch.zeros_like(before[k]).double(), 1, lr)
+            assert float((after[k].double() - p2).abs().max()) <= 2e-6 * max(float(p2.abs().max()), 1e-3), k
+        else:
+            assert torch.equal(before[k], after[k]), "frozen variable moved: " + k

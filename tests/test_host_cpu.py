@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (acimg_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
-    assert lib.acimg_version() == 100
+    assert lib.acimg_version() == 200
 
 
 def test_host_side_queries_need_no_gpu(lib):
@@ -71,7 +71,7 @@ def test_error_codes_and_text(lib):
     from acimg import _lib, ops
 
     d = ops.conv_desc(1, 4, 4, 6, 8, 3, 3)     # C not a multiple of 4: rejected before any launch
-    rc = lib.acimg_conv2d_fwd(C.byref(d), 16, 16, None, 16, None, None, 0, None, None, 0, None)
+    rc = lib.acimg_conv2d_fwd(C.byref(d), 16, 16, None, 16, None, None, 0, None, None, 0, None, None)
     assert rc == -1 and "multiples of 4" in _lib.last_error()
     with pytest.raises(_lib.AcimgError):
         _lib.check(rc, "conv2d_fwd")
@@ -237,3 +237,37 @@ def test_bench_contract_on_cpu():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0",
                             "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "{" not in r.stdout, r.stdout[-500:]
+
+
+def test_library_reads_no_environment_and_configure_validates(lib):
+    """include/acimg.h: the only process-wide state is the tuning record of acimg_configure; the library never calls
+    getenv (the Python host maps ACIMG_* variables onto acimg_configure once, at load time)"""
+    import ctypes as C
+
+    from acimg import _lib, ops
+
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", _lib.LIB_PATH]).decode()
+    assert "getenv" not in und
+    assert "acimg_set_ticket_buffer" not in set(_lib.PROTOTYPES)
+    cfg = _lib.Config()
+    assert lib.acimg_config_default(C.byref(cfg)) == 0
+    assert (cfg.splitk_cut, cfg.splitk_target, cfg.splitk_handoff, cfg.wgrad_minpix, cfg.wgrad_halo, cfg.split3_tile_bm,
+            cfg.split3_tile_bn, cfg.tail_split, cfg.tail_s) == (320, 768, 1, 128, 1, 0, 0, 1, 0)
+    d = ops.conv_desc(4, 12, 16, 128, 128, 3, 3)
+    base = ops.conv2d_fwd_tiling(d)
+    assert base[2] > 1
+    try:
+        got = _lib.configure_from_env({"ACIMG_SPLITK_CUT": "1", "ACIMG_NO_TAIL_SPLIT": "1", "ACIMG_SPLIT3_TILE": "64x128"})
+        assert (got.splitk_cut, got.tail_split, got.split3_tile_bm, got.split3_tile_bn) == (1, 0, 64, 128)
+        assert ops.conv2d_fwd_tiling(d)[2] == 1            # the heuristics read the record, not the environment
+        os.environ["ACIMG_SPLITK_CUT"] = "320"
+        assert ops.conv2d_fwd_tiling(d)[2] == 1
+    finally:
+        os.environ.pop("ACIMG_SPLITK_CUT", None)
+        _lib.configure()
+    assert ops.conv2d_fwd_tiling(d) == base
+    bad = _lib.Config()
+    lib.acimg_config_default(C.byref(bad))
+    bad.split3_tile_bm, bad.split3_tile_bn = 96, 96
+    assert lib.acimg_configure(C.byref(bad)) == -1 and "tile" in _lib.last_error()
+    assert lib.acimg_configure(None) == -1

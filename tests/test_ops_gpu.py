@@ -708,12 +708,13 @@ def test_error_reporting(device):
     dx = torch.zeros(1, 17, 23, 8, device=device)
     tiny = torch.zeros(64, device=device)
     rc = L.acimg_conv2d_dgrad(C.byref(d2), gy.data_ptr(), 8, w2.data_ptr(), dx.data_ptr(), 8, None, 0, None, 0,
-                              tiny.data_ptr(), 256, st)
+                              tiny.data_ptr(), 256, None, st)
     assert rc == -2 and "workspace" in _lib.last_error()
     # transposed conv: kernel > stride needs the matching TF output size
     d3 = ops.deconv_desc(1, 5, 6, 8, 8, 3, 3, 2)
     d3.OH = 10
-    rc = L.acimg_deconv_fwd(C.byref(d3), dx.data_ptr(), w2.data_ptr(), None, dx.data_ptr(), tiny.data_ptr(), 256, st)
+    rc = L.acimg_deconv_fwd(C.byref(d3), dx.data_ptr(), w2.data_ptr(), None, dx.data_ptr(), tiny.data_ptr(), 256, None,
+                            st)
     assert rc == -1 and "OH" in _lib.last_error()
     # batch-norm backward: channel count not a multiple of 4; clip cross-entropy: too many classes
     rc = L.acimg_bn_bwd(dx.data_ptr(), 6, dx.data_ptr(), 6, None, None, None, None, None, 10, 6, dx.data_ptr(), 6,
@@ -883,9 +884,12 @@ def test_split3_prepare_multi_equals_single_launches(device):
 
 
 def test_splitk_handoff_equals_reduce_launch(device):
-    """split-K combined inside the kernel (acimg_set_ticket_buffer: ticket per tile, last arriver adds the K ranges in
-    range order) is bit-identical to the separate reduce launch, forward (bias + ReLU epilogue) and data gradient
-    (residual + mask epilogue), and leaves its ticket words at zero"""
+    """split-K combined inside the kernel (the explicit `tickets` argument: ticket per tile, last arriver adds the K
+    ranges in range order) is bit-identical to the separate reduce launch (tickets = NULL, or the splitk_handoff switch
+    of acimg_configure off), forward (bias + ReLU epilogue) and data gradient (residual + mask epilogue), and leaves
+    the caller's ticket words at zero"""
+    import ctypes as C
+
     from acimg import _lib, ops
     L = _lib.load()
     g = torch.Generator().manual_seed(31)
@@ -895,26 +899,45 @@ def test_splitk_handoff_equals_reduce_launch(device):
     x, w, b = dev(rnd(g, N, H, W, Cin), device), dev(rnd(g, 3, 3, Cin, K) * 0.05, device), dev(rnd(g, K), device)
     gy = dev(rnd(g, N, H, W, K), device)
     res = dev(rnd(g, N, H, W, Cin), device)
+    st = ops.current_stream_handle(device)
+    ws = torch.zeros(int(max(L.acimg_conv2d_fwd_workspace(C.byref(d)), L.acimg_conv2d_dgrad_workspace(C.byref(d)))),
+                     dtype=torch.uint8, device=device)
+    tick = torch.zeros(ops.TICKET_WORDS, dtype=torch.int32, device=device)
     outs = []
-    for handoff in (True, False):
-        plan = ops.Plan(device, eager=True)              # registers the ticket words
-        tick = ops._TICKETS[str(torch.device(device))]
-        if not handoff:
-            _lib.check(L.acimg_set_ticket_buffer(None, 0), "set_ticket_buffer")
+    for mode in ("handoff", "null", "configured-off"):
+        if mode == "configured-off":
+            _lib.configure(splitk_handoff=0)
+        t = None if mode == "null" else tick.data_ptr()
         y = torch.zeros(N, H, W, K, device=device)
         dx = torch.zeros(N, H, W, Cin, device=device)
-        ops.conv2d_fwd(plan, d, x, w, b, y)
-        ops.conv2d_dgrad(plan, d, gy, K, w, dx, res, Cin, x, Cin)
+        _lib.check(L.acimg_conv2d_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, None, 0,
+                                      None, ws.data_ptr(), ws.numel(), t, st), "conv2d_fwd")
+        _lib.check(L.acimg_conv2d_dgrad(C.byref(d), gy.data_ptr(), K, w.data_ptr(), dx.data_ptr(), Cin, res.data_ptr(),
+                                        Cin, x.data_ptr(), Cin, ws.data_ptr(), ws.numel(), t, st), "conv2d_dgrad")
         torch.cuda.synchronize()
         outs.append((y.clone(), dx.clone()))
-        assert int(tick.view(torch.int32).abs().max()) == 0
-        _lib.check(L.acimg_set_ticket_buffer(tick.data_ptr(), tick.numel()), "set_ticket_buffer")
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert int(tick.abs().max()) == 0
+        _lib.configure()                                  # back to the defaults
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
     ref = torch.relu(torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().permute(3, 2, 0, 1).cpu(),
                                                  b.double().cpu(), padding=1)).permute(0, 2, 3, 1)
     close(outs[0][0], ref, tol=1e-5, what="split-K forward")
-    assert L.acimg_set_ticket_buffer(tick.data_ptr(), 16) != 0       # too small
-    _lib.check(L.acimg_set_ticket_buffer(tick.data_ptr(), tick.numel()), "set_ticket_buffer")
+    # the plans' own path: the workspace owns a ticket block and hands it to every split-K call
+    plan = ops.Plan(device, eager=True)
+    y = torch.zeros(N, H, W, K, device=device)
+    ops.conv2d_fwd(plan, d, x, w, b, y)
+    torch.cuda.synchronize()
+    assert torch.equal(y, outs[0][0]) and int(plan.ws.tickets.abs().max()) == 0
+    # misaligned ticket words are refused
+    rc = L.acimg_conv2d_fwd(C.byref(d), x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None, None, 0, None,
+                            ws.data_ptr(), ws.numel(), tick.data_ptr() + 4, st)
+    assert rc == -1 and "ticket" in _lib.last_error()
+    # acimg_configure validates
+    with pytest.raises(_lib.AcimgError):
+        _lib.configure(split3_tile_bm=96, split3_tile_bn=96)
+    with pytest.raises(_lib.AcimgError):
+        _lib.configure(splitk_target=0)
 
 
 def test_deconv_dgrad_few_channels_direct(device):
