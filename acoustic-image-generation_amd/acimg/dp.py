@@ -34,6 +34,44 @@ def make_buckets(ranges, boundaries):
     return buckets
 
 
+def is_writer(group=None):
+    """True on the one rank that writes checkpoints / model.txt / test_accuracy files (rank 0), and on a
+    single-process run.  The reference is single-process (trainer/mfcctrainer.py:400-406): under data parallelism
+    every rank holds the same weights after each step, so exactly one of them saves."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group) == 0
+    return True
+
+
+def average_moving_statistics(flat_state, moving_ranges, group=None):
+    """Batch-norm moving statistics are per replica during training (each rank normalises with its local batch and
+    advances its own moving mean / variance: SURVEY §5 'BN x DP').  At checkpoint / evaluation time every rank calls
+    this (a collective): the `moving_ranges` [(offset, numel)] of the flat state buffer are replaced by their mean
+    over ranks, so that all ranks — and the checkpoint rank 0 writes — hold ONE set of statistics.  gamma / beta in
+    the same buffer are frozen and identical on every rank and are left untouched."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return flat_state
+    world = dist.get_world_size(group)
+    tmp = flat_state.clone()
+    dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+    for off, n in moving_ranges:
+        flat_state[off:off + n].copy_(tmp[off:off + n] / world)
+    return flat_state
+
+
+def shards_per_rank(global_batch, shard, world):
+    """Strong scaling: a FIXED global batch is cut into shards of `shard` images (the batch-norm group size: every
+    shard is normalised with its own batch statistics, on whichever rank it runs); each rank takes
+    global_batch / shard / world of them per step, accumulates their gradients, and the ranks exchange once.  The
+    arithmetic of a step is therefore the same for every world size that divides the shard count."""
+    if global_batch % shard:
+        raise ValueError("global batch %d is not a multiple of the shard size %d" % (global_batch, shard))
+    n = global_batch // shard
+    if n % world:
+        raise ValueError("%d shards of %d images do not divide over %d ranks" % (n, shard, world))
+    return n // world
+
+
 class GradComm(object):
     """Bucketed, stream-overlapped all-reduce of a flat gradient buffer."""
 
@@ -67,6 +105,13 @@ class GradComm(object):
 
     def hook(self, i):
         return lambda: self.bucket_ready(i)
+
+    def allreduce_all(self):
+        """the whole flat gradient in one exchange (gradient-accumulation steps: the buckets of the individual
+        micro-batches are not final, so nothing can be overlapped before the last one has been added)"""
+        if self.world > 1 or self.enabled:
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def wait(self):
         """make the compute stream wait for every outstanding bucket (before the optimiser)"""

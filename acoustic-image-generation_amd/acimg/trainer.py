@@ -53,6 +53,8 @@ class Trainer(object):
         self.comm = None
         self.noise_seed = 1237
         self.log = print
+        self.hold_exchange = False     # True while micro-batch gradients are being accumulated (train_step_sharded)
+        self._acc = None
 
     # ------------------------------------------------------------------------------------------------
     # graph construction
@@ -116,12 +118,12 @@ class Trainer(object):
 
         def on_ready(name, p=p):
             if name in ready:
-                p.add_hook(lambda i=ready[name]: self.comm is not None and self.comm.bucket_ready(i))
+                p.add_hook(lambda i=ready[name]: self._bucket_ready(i))
 
         modelac.record_backward(p, g.g_logit, modelimages.g_output, FLAGS.latent_loss / N if not ae else 0.0,
                                 on_ready=on_ready)
         modelimages.record_backward(p)
-        p.add_hook(lambda: self.comm is not None and self.comm.bucket_ready(0))
+        p.add_hook(lambda: self._bucket_ready(0))
         g.plan_train = p
         # ---- evaluation step (is_training = 0: moving statistics; MSE only, :411-442) ----
         e = sess.new_plan()
@@ -152,6 +154,10 @@ class Trainer(object):
         ma._register = _reuse
         return self._build_graph(N, mi, ma)
 
+    def _bucket_ready(self, i):
+        if self.comm is not None and not self.hold_exchange:
+            self.comm.bucket_ready(i)
+
     def enable_data_parallel(self, group=None):
         """All-reduce the flat gradient across ranks (torch.distributed must be initialised): five
         contiguous buckets, each fired from its hook in the recorded backward plan."""
@@ -159,7 +165,16 @@ class Trainer(object):
         self.buckets = dp.make_buckets(store.train_ranges(), self.bucket_boundaries)
         assert len(self.buckets) == 5, self.buckets
         self.comm = dp.GradComm(store.grad, self.buckets, group)
+        self.group = group
         return self.comm
+
+    def sync_moving_statistics(self):
+        """collective: every rank ends up with the mean over ranks of the trunk's BN moving statistics
+        (per-replica while training; one set for checkpoints and evaluation: SURVEY §8(e))"""
+        store = self.session.store
+        rng = [(v.offset, v.numel) for n, v in store.vars.items() if v.group == "state" and "/moving_" in n]
+        dp.average_moving_statistics(store.flat["state"], rng, getattr(self, "group", None))
+        store.version += 1
 
     # ------------------------------------------------------------------------------------------------
     # the step
@@ -211,6 +226,49 @@ class Trainer(object):
         if not sync:
             return g.losses
         return self._scalars(g)
+
+    def train_step_sharded(self, shards, eps=None, probe=None):
+        """Strong-scaling step: `shards` = this rank's micro-batches (each of the primary graph's size: the BN group),
+        run one after the other with their gradients accumulated; ONE exchange of the accumulated gradient, ONE Adam
+        update with scale 1 / (shards * world).  With one shard per rank this is `train_step` (overlapped buckets)."""
+        if len(shards) == 1:
+            return self.train_step(shards[0], eps=None if eps is None else eps[0], sync=probe is None, probe=probe)
+        store = self.session.store
+        g = self.primary
+        if self._acc is None:
+            self._acc = torch.zeros_like(store.grad)
+        L = _lib.load()
+        st = ops.current_stream_handle(self.session.device)
+        self.hold_exchange = True
+        tot = None
+        try:
+            for i, b in enumerate(shards):
+                self._feed(g, b, None if eps is None else eps[i])
+                if probe is None:
+                    g.plan_train.run()
+                else:
+                    g.plan_train.run_probed(probe[0], probe[1])
+                if i == 0:
+                    self._acc.copy_(store.grad)
+                else:
+                    _lib.check(L.acimg_axpy(1.0, store.grad.data_ptr(), self._acc.data_ptr(), store.grad.numel(), st),
+                               "axpy")
+                tot = g.losses[:5].clone() if tot is None else tot + g.losses[:5]
+        finally:
+            self.hold_exchange = False
+        store.grad.copy_(self._acc)
+        world = 1
+        if self.comm is not None and self.comm.enabled:
+            self.comm.allreduce_all()
+            world = self.comm.world
+        self.global_step += 1
+        lr_t = ops.adam_lr_t(self.learning_rate, self.global_step)
+        rc = L.acimg_adam_step(store.flat["train"].data_ptr(), store.grad.data_ptr(), store.adam_m.data_ptr(),
+                               store.adam_v.data_ptr(), store.train_numel(), lr_t, 0.9, 0.999, 1e-8,
+                               1.0 / (len(shards) * world), st)
+        _lib.check(rc, "adam_step")
+        v = (tot / len(shards)).tolist()
+        return OrderedDict(mse=v[0], huber=v[1], latent=v[2], reg=v[3], loss=v[4])
 
     def _scalars(self, g):
         v = g.losses[:5].tolist()
@@ -267,18 +325,46 @@ class Trainer(object):
         session.store.load_state(state, strict=False)
 
     def _save_checkpoint(self, session, epoch):
+        """`self.saver.save(session, '<checkpoint_dir>/<exp_name>/epoch_<n>.ckpt')` of trainer/mfcctrainer.py:400-406,
+        :81 (Saver(max_to_keep=11)): a TensorFlow Saver-V2 bundle (epoch_<n>.ckpt.index + .data-00000-of-00001 + the
+        `checkpoint` state file) holding what the reference's Saver holds — every model variable under its TF name,
+        the Adam slots `<var>/Adam`, `<var>/Adam_1`, `beta1_power`, `beta2_power` and `global_step` — so the
+        reference's own `_restore_model` / `init_model` (:214-247) can read it.  Data-parallel: every rank calls this
+        (the BN moving statistics are averaged over ranks first, a collective); only rank 0 writes."""
+        from . import tfio
+        if self.comm is not None and self.comm.enabled:
+            self.sync_moving_statistics()
+        if not dp.is_writer(getattr(self, "group", None)):
+            return None
         checkpoint_dir = '{}/{}'.format(FLAGS.checkpoint_dir, FLAGS.exp_name)
         os.makedirs(checkpoint_dir, exist_ok=True)
         model_name = 'epoch_{}.ckpt'.format(epoch)
         self.log('{}: {} - Saving model to {}/{}'.format(datetime.now(), FLAGS.exp_name, checkpoint_dir, model_name))
         store = session.store
-        torch.save({"model": store.state_dict(), "adam_m": store.slot_dict("m"), "adam_v": store.slot_dict("v"),
-                    "global_step": self.global_step}, '{}/{}'.format(checkpoint_dir, model_name))
-        self._saved = getattr(self, "_saved", []) + ['{}/{}'.format(checkpoint_dir, model_name)]
+        import numpy as np
+        tensors = OrderedDict((k, v.numpy()) for k, v in store.state_dict().items())
+        train = set(n for n in store.grad_dict())
+        for which, sfx in (("m", "/Adam"), ("v", "/Adam_1")):
+            for k, v in store.slot_dict(which).items():
+                if k in train:
+                    tensors[k + sfx] = v.numpy()
+        t = max(int(self.global_step), 0)
+        tensors["beta1_power"] = np.float32(0.9 ** (t + 1))     # TF-1 Adam: the powers start at beta and are
+        tensors["beta2_power"] = np.float32(0.999 ** (t + 1))   # multiplied once per apply_gradients
+        tensors["global_step"] = np.int64(t)
+        path = '{}/{}'.format(checkpoint_dir, model_name)
+        tfio.write_checkpoint(path, tensors)
+        self._saved = [p for p in getattr(self, "_saved", []) if p != path] + [path]
         while len(self._saved) > 11:   # Saver(max_to_keep=11), :81
             old = self._saved.pop(0)
-            if os.path.exists(old) and old not in self._saved:
-                os.remove(old)
+            for f in (old + ".index", old + ".data-00000-of-00001"):
+                if os.path.exists(f):
+                    os.remove(f)
+        with open(os.path.join(checkpoint_dir, "checkpoint"), "w") as f:   # tf.train.CheckpointState, text format
+            f.write('model_checkpoint_path: "%s"\n' % os.path.basename(self._saved[-1]))
+            for p in self._saved:
+                f.write('all_model_checkpoint_paths: "%s"\n' % os.path.basename(p))
+        return path
 
     def train(self, train_data=None, valid_data=None):
         assert train_data is not None
@@ -309,9 +395,10 @@ class Trainer(object):
                 if total_loss <= best_loss:
                     best_epoch, best_loss = epoch, total_loss
                     self._save_checkpoint(session, epoch)
-                    with open('{}/{}'.format(FLAGS.checkpoint_dir, FLAGS.exp_name) + "/model.txt", "w") as outfile:
-                        outfile.write('{}: {}\nBest Epoch: {}\nValidation_mse_Loss: {:6f}\n'.format(
-                            datetime.now(), FLAGS.exp_name, best_epoch, best_loss))
+                    if dp.is_writer(getattr(self, "group", None)):
+                        with open('{}/{}'.format(FLAGS.checkpoint_dir, FLAGS.exp_name) + "/model.txt", "w") as outfile:
+                            outfile.write('{}: {}\nBest Epoch: {}\nValidation_mse_Loss: {:6f}\n'.format(
+                                datetime.now(), FLAGS.exp_name, best_epoch, best_loss))
             elif total_loss <= best_loss:
                 best_epoch, best_loss = epoch, total_loss
         self.log('{}: {} - Best Epoch: {}\t Validation_mse_Loss: {:6f}'.format(datetime.now(), FLAGS.exp_name,
@@ -353,7 +440,7 @@ class Trainer(object):
         test_loss, l0, l1, l2, l3 = [s / data_set_size for s in sums]
         line = '{} - Testing_Loss: {:6f}\t  Testing_Loss0: {:6f}\t Testing_Loss1: {:6f}\t Testing_Loss2: {:6f}\t ' \
                'Testing_Loss3: {:6f}'.format(datetime.now(), test_loss, l0, l1, l2, l3)
-        if FLAGS.restore_checkpoint is not None:
+        if FLAGS.restore_checkpoint is not None and dp.is_writer(getattr(self, "group", None)):
             name_folder = str.join('/', FLAGS.restore_checkpoint.split('/')[:-1])
             tag = FLAGS.restore_checkpoint.split('/')[-1].split('.')[0].split('_')[-1]
             with open('{}'.format(name_folder) + "/test_accuracy_{}.txt".format(tag), "w") as outfile:

@@ -9,8 +9,10 @@ Workload (BASELINE.json metric "train-step images/sec"): the `Train
 reference — modified ResNet-50 image encoder (224x298x3, BN in batch-statistics mode) + UNetAcRes
 generator (1 skip) -> 36x48x12, MSE + Huber + 1e-6*KL + slim L2, backward through the generator and
 conv_map, TF-1 Adam — per-GPU batch 32, synthetic seeded inputs ALREADY RESIDENT in HBM, random-init
-weights.  N > 1: one process per GPU, weak scaling (32 images per GPU), bucketed RCCL all-reduce of
-the 43 MB gradient overlapped with backward.
+weights.  N > 1: one process per GPU, weak scaling by default (32 images per GPU: the series ends on configs[3]'s
+8 x 32 = 256), bucketed RCCL all-reduce of the 43 MB gradient overlapped with backward.  `--scaling strong
+--global-batch 256`: the SAME 256 images per step at every N, as shards of 32 (the batch-norm group) run one after
+the other on each rank with accumulated gradients — the arithmetic of a step does not depend on N.
 
 One JSON line on rank 0.  `roofline` is for the dominant kernel (the 128x128-tile implicit-GEMM
 forward conv that runs the ResNet trunk (LDS-DMA staged, XCD-aware tile order): split-fp16 "f16x3" MFMA by default, exact-f32 MFMA with
@@ -51,17 +53,29 @@ def parse():
                     help="trainer_mask (default: the north-star path, BASELINE configs[2]/[3]); unet_rgb / unet_sound: the "
                          "single-modality U-Net VAEs of configs[1] / [0]; classifier: DualCamNet on generated images, "
                          "configs[4]'s head")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch images per GPU (configs[3] = 8 x 32); strong: a fixed --global-batch cut into "
+                         "shards of --batch images (the batch-norm group), each rank runs its share one after the other "
+                         "with accumulated gradients, one exchange + one Adam per step")
+    ap.add_argument("--global-batch", type=int, default=256, help="strong scaling: images per step over all GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] (UNet RGB VAE) side measurement")
-    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the configs[1] (UNet RGB VAE) and configs[2] (2-skip, batch 64) side measurements")
+    ap.add_argument("--cpu-batch", type=int, default=32, help="BASELINE.md §3: the CPU leg runs the GPU leg's batch")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every host core this process may run on")
     return ap.parse_args()
 
 
 def cpu_baseline(args):
-    """CPU oracle train step on a bounded sample (batch 8, 1 warm-up + 3 timed steps, ~10-30 s)."""
+    """CPU oracle train step: the SAME step as the GPU leg — same generator variant (--num-skip), same
+    batch (32) — on a bounded sample: 1 warm-up + 3 timed steps (about 20 s each on the GPU box's host cores, so
+    the default bench.py run stays within a few minutes; BASELINE.md's 3 + 10 steps would not).  `cores` = the thread
+    count actually set with torch.set_num_threads."""
     from oracle import trainer as otr
 
+    n = args.cpu_threads if getattr(args, "cpu_threads", 0) else len(os.sched_getaffinity(0))
+    torch.set_num_threads(n)
     n = torch.get_num_threads()
     orc = otr.Oracle(num_skip=args.num_skip, learning_rate=1e-4)
     ac, mf, vid, eps = otr.synthetic_batch(args.cpu_batch, seed=1234)
@@ -70,9 +84,38 @@ def cpu_baseline(args):
     for _ in range(args.cpu_steps):
         orc.train_step(ac, mf, vid, eps)
     dt = time.perf_counter() - t0
-    return {"value": args.cpu_batch * args.cpu_steps / dt, "unit": "images/s", "cores": n, "kind": "port",
-            "sample": "CPU oracle (PyTorch fp32 restatement of the TF-1 graph; TF-1 unavailable offline): "
-                      "same train step, batch %d, %d timed steps after 1 warm-up" % (args.cpu_batch, args.cpu_steps)}
+    rate = args.cpu_batch * args.cpu_steps / dt
+    return {"value": rate, "unit": "images/s", "cores": n, "kind": "port",
+            "gflops": rate * 41.7,
+            "sample": "CPU oracle (PyTorch fp32 restatement of the TF-1 graph; TF-1 unavailable offline): the same "
+                      "TrainerMask train step, %d-skip generator, batch %d, %d timed steps after 1 warm-up, %d threads"
+                      % (args.num_skip, args.cpu_batch, args.cpu_steps, n)}
+
+
+def load_traffic_profile(kernel_name):
+    """HBM bytes from the newest PMC summary committed under profiles/ (tools/pmc_traffic.sh + tools/pmc_summary.py:
+    FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc passes of THIS bench at batch 32
+    f16x3).  Returns {file, commit, step_bytes, kernel_bytes_per_launch} or None: nothing is hard-coded here."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic_*.txt")),
+                   key=lambda f: (int(re.search(r"profiles/r(\d+)/", f).group(1)), os.path.getmtime(f), f))
+    if not files:
+        return None
+    f = files[-1]
+    out = {"file": os.path.relpath(f, ROOT), "commit": None, "step_bytes": None, "kernel_bytes_per_launch": None}
+    want = kernel_name.replace(" ", "")
+    for ln in open(f):
+        m = re.match(r"commit (\S+)", ln)
+        if m:
+            out["commit"] = m.group(1)
+        m = re.match(r"total ([0-9.]+) GB/step", ln)
+        if m:
+            out["step_bytes"] = float(m.group(1)) * 1e9
+        m = re.match(r"(.+?)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", ln)
+        if m and m.group(1).replace(" ", "") == want:
+            out["kernel_bytes_per_launch"] = (float(m.group(3)) + float(m.group(4))) * 1e6
+    return out
 
 
 def secondary_unet_rgb(args):
@@ -94,6 +137,55 @@ def secondary_unet_rgb(args):
     dt = (time.perf_counter() - t0) / 10
     return {"workload": "BASELINE configs[1]: UNet RGB VAE train step (models/unet_architecture.py + trainer/trainer.py), "
                         "224x298x3, batch 32", "value": 32 / dt, "unit": "images/s", "ms_per_step": dt * 1e3, "dtype": "f32"}
+
+
+def secondary_configs2(args):
+    """BASELINE configs[2]: the TrainerMask step with the 2-skip generator at batch 64 on one GPU"""
+    from acimg.flags import FLAGS
+    from acimg.session import Session
+    from acimg.trainer import Trainer
+    from acimg.unet_acresnet import UNetAc
+    from acimg.vision import ResNet50Model
+    dev = torch.device("cuda", torch.cuda.current_device())
+    FLAGS.model, FLAGS.ae, FLAGS.num_skip_conn = "UNet", 0, 2
+    B = 64
+    tr = Trainer(UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=2),
+                 ResNet50Model(input_shape=[224, 298, 3], num_classes=None, precision=args.precision),
+                 learning_rate=1e-4, session=Session(dev))
+    g = tr._build_functions(batch_size=B)
+    tr.modelimages.initialize(seed=1238)
+    tr.modelac.initialize(seed=1239)
+    fill_inputs(g, B, 4321)
+    for _ in range(3):
+        tr.train_step(sync=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        tr.train_step(sync=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    return {"workload": "BASELINE configs[2]: TrainerMask train step, ResNet-50-mod + UNetAcRes 2-skip "
+                        "(models/unet_acresnet2skip.py), batch 64", "value": B / dt, "unit": "images/s",
+            "ms_per_step": dt * 1e3, "dtype": "f32", "final_loss": tr._scalars(g)["loss"]}
+
+
+def synthetic_inputs(B, seed):
+    gen = torch.Generator().manual_seed(seed)
+    vid = torch.rand(B, 224, 298, 3, generator=gen)
+    mf = torch.rand(B, 12, generator=gen)
+    mf = (mf - mf.amin(1, keepdim=True))
+    mf = mf / mf.amax(1, keepdim=True)
+    ac = torch.rand(B, 36, 48, 12, generator=gen)
+    ac = ac - ac.amin((1, 2, 3), keepdim=True)
+    ac = ac / ac.amax((1, 2, 3), keepdim=True)
+    return ac, mf, vid
+
+
+def fill_inputs(g, B, seed):
+    ac, mf, vid = synthetic_inputs(B, seed)
+    g.video.copy_(vid)
+    g.mfcc.copy_(mf)
+    g.acoustic.copy_(ac)
 
 
 def other_workload(args):
@@ -195,17 +287,15 @@ def main():
     if world > 1 or force_dp:
         tr.enable_data_parallel()
     # synthetic inputs, resident in HBM before the timed region (seed differs per rank)
-    gen = torch.Generator().manual_seed(1234 + rank)
-    vid = torch.rand(B, 224, 298, 3, generator=gen)
-    mf = torch.rand(B, 12, generator=gen)
-    mf = (mf - mf.amin(1, keepdim=True))
-    mf = mf / mf.amax(1, keepdim=True)
-    ac = torch.rand(B, 36, 48, 12, generator=gen)
-    ac = ac - ac.amin((1, 2, 3), keepdim=True)
-    ac = ac / ac.amax((1, 2, 3), keepdim=True)
-    g.video.copy_(vid)
-    g.mfcc.copy_(mf)
-    g.acoustic.copy_(ac)
+    fill_inputs(g, B, 1234 + rank)
+    strong = args.scaling == "strong"
+    shards = None
+    if strong:
+        from acimg import dp
+        nsh = dp.shards_per_rank(args.global_batch, B, world)
+        # this rank's shards, resident in HBM: (acoustic, mfcc, video) device tensors, fed by device-to-device copies
+        shards = [tuple(t.to(dev) for t in synthetic_inputs(B, 1234 + 1000 * rank + i)) for i in range(nsh)]
+    images_per_step = args.global_batch if strong else world * B
 
     # the dominant kernel = the trunk forward-conv kernel instance (tile shape) that carries the most FLOPs
     f16 = args.precision == "f16x3"
@@ -225,11 +315,21 @@ def main():
     tile = max(cand, key=lambda k: sum(f for _, f in cand[k]))
     probe_idx = set(i for i, _ in cand[tile])
     flops = dict(cand[tile])
+    alg_bytes = {}
+    for i in probe_idx:
+        d = g.plan_train.calls[i][2][0]._obj
+        alg_bytes[i] = 4.0 * (d.N * d.H * d.W * d.C + d.K * d.R * d.S * d.C + d.N * d.OH * d.OW * d.K)
     TILE_THREADS = {(128, 128): "2,4,512", (64, 128): "1,4,256", (128, 64): "2,2,256"}
     kernel_name = ("igemm_split3d_kernel<%d,%d,%s,2,2>" % (tile[0], tile[1], TILE_THREADS[tile[:2]]) if f16
                    else "igemm_f32_kernel<%d,%d,...,false,true>" % (tile[0], tile[1]))
+    def one_step(probe=None):
+        if strong:
+            tr.train_step_sharded(shards, probe=probe)
+        else:
+            tr.train_step(sync=False, probe=probe)
+
     for _ in range(args.warmup):
-        tr.train_step(sync=False)
+        one_step()
     events = []
 
     def barrier():
@@ -241,7 +341,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tr.train_step(sync=False, probe=(probe_idx, events))
+        one_step(probe=(probe_idx, events))
     barrier()
     dt = time.perf_counter() - t0
     last = tr._scalars(g)
@@ -251,6 +351,8 @@ def main():
         dt = float(t.item())
 
     roof = None
+    prof = load_traffic_profile(kernel_name) if f16 else None
+    prof_ok = bool(prof and prof["kernel_bytes_per_launch"] and B == 32 and not strong)
     if events:
         ms = sum(e0.elapsed_time(e1) for _, e0, e1 in events)
         fl = sum(flops[i] for i, _, _ in events)
@@ -263,47 +365,60 @@ def main():
                 "hw_flop_factor": 3 if f16 else 1,
                 # matrix-core utilisation: the 3 MFMAs issued per algorithmic product, against the same peak
                 "hw_frac": achieved * (3 if f16 else 1) / peak,
-                # HBM bytes per launch of this kernel from the PMC pass committed under profiles/ (FETCH_SIZE x2 per
-                # the gfx950 correction + WRITE_SIZE, batch 32, f16x3): not re-measured by this run
-                "traffic": 252.0e6 if (f16 and B == 32 and tile[:2] == (128, 128)) else None,
-                "traffic_source": "profiles/r01/hbm_traffic_v10.txt" if (f16 and B == 32 and tile[:2] == (128, 128)) else None,
+                # algorithmic HBM bytes per launch: the pre-split input tensor (two fp16 planes = 4 B per element) and the
+                # split weights read once, the fp32 output written once, averaged over this kernel's launches
+                "alg_bytes": sum(alg_bytes[i] for i in probe_idx) / len(probe_idx),
+                # HBM bytes per launch from the PMC summary committed under profiles/ (FETCH_SIZE x2 per the gfx950
+                # correction + WRITE_SIZE, batch 32, f16x3; collected by tools/pmc_traffic.sh, not by this run)
+                "traffic": prof["kernel_bytes_per_launch"] if prof_ok else None,
+                "traffic_source": prof["file"] if prof_ok else None,
+                "traffic_commit": prof["commit"] if prof_ok else None,
                 "launches_per_step": len(probe_idx),
                 "avg_launch_ms": ms / len(events), "avg_launch_gflop": fl / len(events) / 1e9,
                 "share_of_step_time": (ms / args.steps) / (dt / args.steps * 1e3)}
 
     if rank == 0:
         out = {
-            "metric": "train-step images/sec", "value": world * B * args.steps / dt, "unit": "images/s",
+            "metric": "train-step images/sec", "value": images_per_step * args.steps / dt, "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dtype_note": ("fp32 tensors everywhere; trunk conv products on fp16 matrix cores as a 3-term hi/lo split "
                            "(22 mantissa bits per operand, fp32 accumulate), parity 1e-3 vs the fp32 oracle"
                            if f16 else "fp32 tensors, exact-f32 MFMA"),
             "config": {"workload": "TrainerMask train step: ResNet-50-mod 224x298x3 (BN batch stats) + UNetAcRes "
                                    "%d-skip -> 36x48x12, MSE+Huber+KL+L2, backward, TF-1 Adam" % args.num_skip,
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "launches_per_step": len(g.plan_train) + 2},
+                       "per_gpu_batch": images_per_step // world, "global_batch": images_per_step,
+                       "bn_group": B, "shards_per_gpu_per_step": len(shards) if strong else 1,
+                       "parallelism": "dp%d" % world, "launches_per_step": len(g.plan_train) + 2},
             "final_loss": last["loss"], "final_mse": last["mse"],
             "roofline": roof,
         }
         # the whole step against both chip roofs (41.7 GFLOP algorithmic per image; HBM bytes per step
         # from the PMC pass under profiles/, batch 32 f16x3 only)
-        per_gpu_rate = B * args.steps / dt
+        per_gpu_rate = images_per_step / world * args.steps / dt
+        sb = prof["step_bytes"] if (prof_ok and prof["step_bytes"]) else None
         out["step"] = {"alg_tflops": 41.7e9 * per_gpu_rate / 1e12,
-                       "hbm_GBps": (28.67e9 / (dt / args.steps) / 1e9) if (f16 and B == 32) else None,
-                       "hbm_frac": (28.67e9 / (dt / args.steps) / 8.0e12) if (f16 and B == 32) else None,
-                       "hbm_source": "profiles/r01/hbm_traffic_v10.txt (28.67 GB/step)" if (f16 and B == 32) else None}
+                       # 0.45 GB algorithmic per image with fp32 trunk activations
+                       "alg_bytes": 0.45e9 * B,
+                       "hbm_bytes": sb, "traffic_ratio": (sb / (0.45e9 * B)) if sb else None,
+                       "hbm_GBps": (sb / (dt / args.steps) / 1e9) if sb else None,
+                       "hbm_frac": (sb / (dt / args.steps) / 8.0e12) if sb else None,
+                       "hbm_source": prof["file"] if sb else None, "hbm_commit": prof["commit"] if sb else None,
+                       "hbm_note": "counter bytes (incl. Infinity-Cache hits) from the committed PMC pass divided by "
+                                   "THIS run's step time: derived, not re-measured"}
         if roof is not None and roof.get("traffic"):
+            roof["traffic_ratio"] = roof["traffic"] / roof["alg_bytes"]
             roof["hbm_GBps"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9
             roof["hbm_frac"] = roof["hbm_GBps"] * 1e9 / 8.0e12
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         if world == 1 and not args.no_secondary:
             # BASELINE configs[1] (the RGB U-Net VAE at batch 32) timed next to the north-star path, for reference
-            try:
-                out["secondary"] = secondary_unet_rgb(args)
-            except Exception as e:   # never lose the primary line
-                out["secondary"] = {"error": repr(e)}
+            for key, fn in (("secondary", secondary_unet_rgb), ("secondary2", secondary_configs2)):
+                try:
+                    out[key] = fn(args)
+                except Exception as e:   # never lose the primary line
+                    out[key] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1 or force_dp:
         dist.barrier()

@@ -176,6 +176,27 @@ exp = torch.arange(n, dtype=torch.float32) * 3
 assert torch.equal(flat, exp), (flat - exp).abs().max()
 s = comm.allreduce_scalars(torch.tensor([float(rank)]))
 assert abs(float(s) - 0.5) < 1e-6
+# gradient-accumulation (strong-scaling) steps exchange the whole flat buffer once
+flat2 = torch.full((n,), float(rank + 1))
+comm2 = dp.GradComm(flat2, buckets)
+comm2.allreduce_all()
+assert torch.equal(flat2, torch.full((n,), 3.0))
+assert dp.shards_per_rank(256, 32, 2) == 4 and dp.shards_per_rank(256, 32, 8) == 1
+for bad in ((250, 32, 2), (96, 32, 2)):
+    try:
+        dp.shards_per_rank(*bad); raise SystemExit("accepted %%r" %% (bad,))
+    except ValueError:
+        pass
+# checkpoint time: ONE writer; per-replica BN moving statistics averaged, frozen gamma/beta untouched
+assert dp.is_writer() == (rank == 0)
+state = torch.cat([torch.full((8,), 0.1), torch.full((8,), float(rank)), torch.full((8,), 10.0 * (rank + 1))])
+dp.average_moving_statistics(state, [(8, 8), (16, 8)])
+assert torch.equal(state[:8], torch.full((8,), 0.1)) and torch.equal(state[8:16], torch.full((8,), 0.5))
+assert torch.equal(state[16:], torch.full((8,), 15.0))
+import tempfile
+marker = os.path.join(%(tmp)r, "writer_%%d" %% rank)
+if dp.is_writer():
+    open(marker, "w").write("x")
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -184,13 +205,24 @@ print("rank", rank, "ok")
 def test_gradient_exchange_two_ranks_gloo(tmp_path):
     """N>1 path on CPU: 2 processes, gloo, bucketed all-reduce of a flat gradient buffer"""
     script = tmp_path / "dp_worker.py"
-    script.write_text(DP_WORKER % {"root": ROOT, "port": 29500 + os.getpid() % 2000})
+    script.write_text(DP_WORKER % {"root": ROOT, "port": 29500 + os.getpid() % 2000, "tmp": str(tmp_path)})
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert all("ok" in o for o in outs)
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("writer_")) == ["writer_0"]
+
+
+def test_single_process_dp_helpers():
+    from acimg import dp
+    import torch
+
+    assert dp.is_writer()
+    t = torch.arange(6.0)
+    assert dp.average_moving_statistics(t, [(0, 6)]) is t and torch.equal(t, torch.arange(6.0))
+    assert dp.shards_per_rank(256, 32, 1) == 8
 
 
 def test_frontend_tables_match_oracle():
@@ -228,10 +260,20 @@ def test_bench_contract_on_cpu():
         sys.argv = argv
     assert (args.gpus, args.batch, args.workload, args.precision) == (1, 32, "trainer_mask", "f16x3")
     assert args.steps * 0.01 < 60 and args.warmup >= 1          # minutes at ~10 ms / step
-    small = types.SimpleNamespace(num_skip=1, cpu_batch=1, cpu_steps=1)
+    assert (args.cpu_batch, args.scaling, args.global_batch) == (32, "weak", 256)    # CPU leg at the GPU leg's batch
+    small = types.SimpleNamespace(num_skip=1, cpu_batch=1, cpu_steps=1, cpu_threads=2)
     cb = bench.cpu_baseline(small)
-    assert set(cb) == {"value", "unit", "cores", "kind", "sample"} and cb["kind"] == "port" and cb["value"] > 0
-    assert cb["unit"] == "images/s" and cb["cores"] >= 1
+    assert set(cb) >= {"value", "unit", "cores", "kind", "sample"} and cb["kind"] == "port" and cb["value"] > 0
+    assert cb["unit"] == "images/s" and cb["cores"] == 2 and "1-skip" in cb["sample"]
+    import torch
+    torch.set_num_threads(len(os.sched_getaffinity(0)))
+    # the roofline's counter traffic comes from a committed PMC summary, never from a literal in bench.py
+    src = open(os.path.join(root, "bench.py")).read()
+    assert "252.0e6" not in src and "28.67e9" not in src
+    prof = bench.load_traffic_profile("igemm_split3d_kernel<128,128,2,4,512,2,2>")
+    if prof is not None:
+        assert prof["file"].startswith("profiles/r") and prof["step_bytes"] > 1e9
+        assert prof["kernel_bytes_per_launch"] is None or prof["kernel_bytes_per_launch"] > 1e6
     import torch
     if not torch.cuda.is_available():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0",

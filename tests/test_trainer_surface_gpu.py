@@ -1,0 +1,116 @@
+"""The reference's trainer surface around the hot loop, end to end on the device:
+`Trainer.train()` (trainer/mfcctrainer.py:249-398: _init_model, 'epoch_random' checkpoint, epoch loop over the loader,
+validation, every-10-epochs and best-loss checkpoints, model.txt), `_save_checkpoint` (:400-406, a TensorFlow Saver-V2
+bundle with the reference Saver's variable set), `_restore_model` (:236-247), `test()` (:476-536, the
+test_accuracy_<epoch>.txt line with the four per-3-channel losses), `_evaluate` (:411-442)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make(device, lr=1e-3, epochs=1):
+    from acimg.flags import FLAGS
+    from acimg.session import Session
+    from acimg.trainer import Trainer
+    from acimg.unet_acresnet import UNetAc
+    from acimg.vision import ResNet50Model
+
+    FLAGS.model, FLAGS.ae, FLAGS.latent_loss = "UNet", 0, 1e-6
+    sess = Session(device)
+    tr = Trainer(UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=1),
+                 ResNet50Model(input_shape=[224, 298, 3], num_classes=None), display_freq=1, learning_rate=lr,
+                 num_epochs=epochs, session=sess)
+    return tr, sess
+
+
+def test_train_checkpoint_restore_test(device, tmp_path):
+    from acimg import tfio
+    from acimg.data import SyntheticDataLoader
+    from acimg.flags import FLAGS
+
+    FLAGS.checkpoint_dir, FLAGS.exp_name = str(tmp_path), "exp"
+    FLAGS.restore_checkpoint = FLAGS.init_checkpoint = None
+    FLAGS.acoustic_init_checkpoint = FLAGS.visual_init_checkpoint = None
+    tr, sess = make(device, epochs=3)
+    lines = []
+    tr.log = lines.append
+    train_data = SyntheticDataLoader(5, 2, seed=10)       # batches of 2, 2, 1: the partial batch gets its own plans
+    valid_data = SyntheticDataLoader(3, 2, seed=20)
+    best = tr.train(train_data, valid_data)
+    d = os.path.join(str(tmp_path), "exp")
+    # --- log lines: 3 iterations per epoch, one validation line per epoch, the final best-epoch line (:352-357,:369-398)
+    it = [ln for ln in lines if "Training_mse_Loss" in ln]
+    va = [float(re.search(r"Validation_mse_Loss: ([0-9.]+)", ln).group(1)) for ln in lines if "- Epoch:" in ln]
+    assert len(it) == 9 and len(va) == 3 and tr.global_step == 9
+    assert re.search(r"Iteration: \[  0\]\t Training_mse_Loss: [0-9.]+\t Training_Loss: [0-9.]+", it[0])
+    # --- best-epoch rule of :380-395: `<=`, so a later epoch wins ties; model.txt names it
+    best_epoch = max(i for i, v in enumerate(va) if v == min(va))
+    assert abs(best - min(va)) < 1e-6
+    txt = open(os.path.join(d, "model.txt")).read()
+    assert "Best Epoch: %d\n" % best_epoch in txt and "Validation_mse_Loss: %.6f\n" % min(va) in txt and "exp\n" in txt
+    assert "Best Epoch: %d" % best_epoch in lines[-1]
+    # --- checkpoints: 'random' before the loop (:322), epoch 0 (epoch %% 10 == 0 and first best), every new best
+    saved = sorted(f[:-6] for f in os.listdir(d) if f.endswith(".index"))
+    expect = {"epoch_random.ckpt", "epoch_0.ckpt"}
+    run_best = 1e9
+    for i, v in enumerate(va):
+        if v <= run_best:
+            run_best = v
+            expect.add("epoch_%d.ckpt" % i)
+    assert set(saved) == expect, (saved, expect)
+    state = open(os.path.join(d, "checkpoint")).read()
+    assert 'model_checkpoint_path: "epoch_%d.ckpt"' % best_epoch in state
+    # --- the bundle holds the reference Saver's variable set under TF names
+    ck = tfio.read_checkpoint(os.path.join(d, "epoch_%d.ckpt" % best_epoch), verify=True)
+    sd = sess.store.state_dict()
+    assert set(sd) <= set(ck)
+    assert "UNetAcRes/layer6/conv_1/kernel/Adam" in ck and "UNetAcRes/mean/kernel/Adam_1" in ck
+    assert "resnet_v1_50/conv_map/weights/Adam" in ck and "resnet_v1_50/block1/unit_1/bottleneck_v1/conv1/weights/Adam" not in ck
+    assert ck["global_step"].dtype == np.int64 and int(ck["global_step"]) == 3 * (best_epoch + 1)
+    assert abs(float(ck["beta1_power"]) - 0.9 ** (3 * (best_epoch + 1) + 1)) < 1e-7
+    assert ck["UNetAcRes/mean/kernel"].shape == (12, 16, 145, 150) and ck["UNetAcRes/upsample_1/kernel"].shape == (2, 2, 128, 128)
+    rnd = tfio.read_checkpoint(os.path.join(d, "epoch_random.ckpt"))
+    assert int(rnd["global_step"]) == 0 and float(np.abs(rnd["UNetAcRes/dense/kernel/Adam"]).max()) == 0
+    assert not np.array_equal(rnd["UNetAcRes/dense/kernel"], ck["UNetAcRes/dense/kernel"])      # training moved it
+    assert np.array_equal(rnd["resnet_v1_50/conv1/weights"], ck["resnet_v1_50/conv1/weights"])  # trunk frozen
+    assert not np.array_equal(rnd["resnet_v1_50/conv1/BatchNorm/moving_mean"],
+                              ck["resnet_v1_50/conv1/BatchNorm/moving_mean"])                    # UPDATE_OPS ran
+    # --- save the CURRENT weights, evaluate, then restore into a fresh trainer and run test()
+    tr._save_checkpoint(sess, 99)
+    test_data = SyntheticDataLoader(5, 2, seed=30)
+    tr._noise_calls = 0
+    want = tr._evaluate(sess, "test", test_data)
+    FLAGS.restore_checkpoint = os.path.join(d, "epoch_99.ckpt")
+    tr2, sess2 = make(device)
+    out = []
+    tr2.log = out.append
+    got = tr2.test(test_data)
+    assert abs(got - want) <= 1e-6 * want, (got, want)
+    for k, v in sess.store.state_dict().items():
+        assert torch.equal(v, sess2.store.state_dict()[k]), k
+    line = open(os.path.join(d, "test_accuracy_99.txt")).read()
+    m = re.match(r".* - Testing_Loss: ([0-9.]+)\t  Testing_Loss0: ([0-9.]+)\t Testing_Loss1: ([0-9.]+)\t "
+                 r"Testing_Loss2: ([0-9.]+)\t Testing_Loss3: ([0-9.]+)$", line)
+    assert m, line
+    vals = [float(x) for x in m.groups()]
+    assert abs(vals[0] - got) < 1e-6 and abs(sum(vals[1:]) / 4 - vals[0]) < 2e-6     # 4 x 3 channels partition the 12
+    assert out[-1] == line
+    # --- _init_model: --init_checkpoint loads the generator only (:188-212); trunk stays as initialised
+    FLAGS.restore_checkpoint = None
+    FLAGS.init_checkpoint = os.path.join(d, "epoch_99.ckpt")
+    tr3, sess3 = make(device)
+    tr3._build_functions(batch_size=2)
+    tr3._init_model(sess3)
+    sd3 = sess3.store.state_dict()
+    assert torch.equal(sd3["UNetAcRes/final/kernel"], sess.store.state_dict()["UNetAcRes/final/kernel"])
+    FLAGS.init_checkpoint = None
+    # --- Saver(max_to_keep=11): the oldest bundles are deleted
+    for e in range(100, 112):
+        tr._save_checkpoint(sess, e)
+    left = [f for f in os.listdir(d) if f.endswith(".index")]
+    assert len(left) == 11 and "epoch_random.ckpt.index" not in left and "epoch_111.ckpt.index" in left

@@ -1,6 +1,6 @@
 """HBM traffic per kernel from the two rocprofv3 --pmc passes of tools/pmc_traffic.sh (FETCH_SIZE, WRITE_SIZE; KB per
 dispatch).  FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (128-B requests of
-16-B/lane streams are tallied at 64 B).  usage: python tools/pmc_summary.py <dir with fetch/ and write/> [steps]"""
+16-B/lane streams are tallied at 64 B).  usage: python tools/pmc_summary.py <dir with fetch/ and write/> [steps] [commit]"""
 import csv, os, sys, collections
 root = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -19,6 +19,15 @@ def load(sub, counter):
     return acc
 
 
+def head_commit():
+    import subprocess
+    try:
+        return subprocess.check_output(["git", "-C", os.path.dirname(os.path.abspath(__file__)), "rev-parse", "--short", "HEAD"],
+                                       stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return os.environ.get("ACIMG_COMMIT", "unknown")
+
+
 rd, wr = load("fetch", "FETCH_SIZE"), load("write", "WRITE_SIZE")
 rows = []
 for k, (n, kb) in rd.items():
@@ -27,6 +36,7 @@ for k, (n, kb) in rd.items():
     wmb = wkb / max(wn, 1) / 1e3
     rows.append((k, n / steps, rmb, wmb, (rmb + wmb) * n / steps / 1e3))
 rows.sort(key=lambda r: -r[4])
+print("commit %s   (tree the PMC passes ran on; bench.py reads this file: load_traffic_profile)" % (sys.argv[3] if len(sys.argv) > 3 else head_commit()))
 print("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
       "(%d steps, batch 32)" % steps)
 print("FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests of 16-B/lane streams at 64 B); "
