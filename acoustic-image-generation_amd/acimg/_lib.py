@@ -31,6 +31,14 @@ class Config(C.Structure):
         "split3_tile_bn", "tail_split", "tail_s")]
 
 
+class SequenceDims(C.Structure):
+    """Mirror of AcimgSequenceDims (include/acimg.h)."""
+
+    _fields_ = [(n, C.c_int64) for n in (
+        "classes", "location", "audio_height", "audio_width", "audio_depth", "mics", "samples", "video_height",
+        "video_width", "video_depth", "audio_image_steps", "audio_data_steps", "video_steps", "audio_data_values")]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_long
@@ -115,8 +123,17 @@ PROTOTYPES = {
     "acimg_axpy": (_I, [_F, _P, _P, _L, _P]),
     "acimg_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
     "acimg_mfcc_frontend": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "acimg_mfcc_frontend_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "acimg_stft_mag": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "acimg_absmax": (_I, [_P, _I, _I, _P, _P]),
+    "acimg_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "acimg_filtfilt": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _SZ, _P]),
+    "acimg_filtfilt_workspace": (_SZ, [_I, _I]),
     "acimg_find_logen": (_I, [_P, _P, _P, _L, _P]),
     "acimg_mask_iou": (_I, [_P, _P, _I, _I, _P, _P]),
+    "acimg_gzip_inflate": (_I, [_P, _SZ, _P, _SZ, C.POINTER(_SZ)]),
+    "acimg_tfrecord_index": (_L, [_P, _SZ, _P, _P, _L, _I]),
+    "acimg_sequence_example_decode": (_I, [_P, _SZ, C.POINTER(SequenceDims), _P, _SZ, _P, _SZ, _P, _SZ]),
     "acimg_crc32c": (C.c_uint32, [_P, _SZ, C.c_uint32]),
 }
 

@@ -615,8 +615,8 @@ def adam_step(plan, p, g, m, v, n, lr_t, beta1=0.9, beta2=0.999, eps=1e-8, grad_
 
 
 def mfcc_frontend(plan, frames, window, melfb, dctl, out, nframes, normalize=False):
-    plan.add("mfcc_frontend", _L().acimg_mfcc_frontend, frames, window, melfb, dctl, out, int(nframes),
-             int(bool(normalize)))
+    fn = _L().acimg_mfcc_frontend if frames.dtype == torch.int32 else _L().acimg_mfcc_frontend_f32
+    plan.add("mfcc_frontend", fn, frames, window, melfb, dctl, out, int(nframes), int(bool(normalize)))
 
 
 def find_logen(plan, mfcc_img, idct, out, pixels):
@@ -630,3 +630,22 @@ def mask_iou(plan, map_a, map_b, N, P, iou):
 def adam_lr_t(lr, step, beta1=0.9, beta2=0.999):
     """TF-1 Adam effective step size for 1-based step t."""
     return lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+
+
+def stft_mag(plan, wav, norm, window, twiddle, out, clips, nsamples, frame_len, step, fft_len=512):
+    plan.add("stft_mag", _L().acimg_stft_mag, wav, norm, window, twiddle, out, int(clips), int(nsamples), int(frame_len),
+             int(step), int(fft_len))
+
+
+def absmax(plan, x, rows, n, out):
+    plan.add("absmax", _L().acimg_absmax, x, int(rows), int(n), out)
+
+
+def resize_bilinear(plan, x, y, N, H, W, Cn, OH, OW):
+    plan.add("resize_bilinear", _L().acimg_resize_bilinear, x, y, int(N), int(H), int(W), int(Cn), int(OH), int(OW))
+
+
+def filtfilt(plan, x, rows, n, ba, zi, out):
+    plan.ws.require(_L().acimg_filtfilt_workspace(int(rows), int(n)))
+    plan.add("filtfilt", _L().acimg_filtfilt, x, int(x.dtype == torch.int32), int(rows), int(n), ba, zi, out,
+             _WsPtr(plan.ws), _WsBytes(plan.ws))

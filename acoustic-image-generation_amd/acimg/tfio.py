@@ -426,3 +426,51 @@ def build_sequence_example(context, feature_lists):
     fls = b"".join(_ld(1, _ld(1, k.encode("utf-8")) + _ld(2, b"".join(_ld(1, _build_feature(x)) for x in steps)))
                    for k, steps in feature_lists.items())
     return _ld(1, ctx) + _ld(2, fls)
+
+
+# ---- native reader (libacimg.so: csrc/records.hip) -----------------------------------------------------------------
+def read_tfrecord_native(path, verify=True):
+    """[record payload bytes] of a (GZIP or plain) TFRecord file through the C++ reader behind the C ABI
+    (acimg_gzip_inflate + acimg_tfrecord_index): the whole file is inflated into ONE caller-owned buffer and indexed;
+    records are zero-copy memoryviews of it."""
+    lib = _lib.load()
+    raw = np.fromfile(path, dtype=np.uint8)
+    produced = ctypes.c_size_t(0)
+    rc = lib.acimg_gzip_inflate(raw.ctypes.data, raw.size, None, 0, ctypes.byref(produced))
+    if rc not in (0, -2):
+        _lib.check(rc, "gzip_inflate")
+    buf = np.empty(max(produced.value, 1), dtype=np.uint8)
+    _lib.check(lib.acimg_gzip_inflate(raw.ctypes.data, raw.size, buf.ctypes.data, buf.size, ctypes.byref(produced)),
+               "gzip_inflate")
+    n = produced.value
+    count = lib.acimg_tfrecord_index(buf.ctypes.data, n, None, None, 0, int(bool(verify)))
+    if count < 0:
+        raise IOError(_lib.last_error())
+    off = np.zeros(max(count, 1), dtype=np.uint64)
+    ln = np.zeros(max(count, 1), dtype=np.uint64)
+    lib.acimg_tfrecord_index(buf.ctypes.data, n, off.ctypes.data, ln.ctypes.data, count, 0)
+    mv = memoryview(buf)
+    return [mv[int(off[i]):int(off[i]) + int(ln[i])] for i in range(count)]
+
+
+def decode_sequence_example_native(record):
+    """One serialized SequenceExample -> what `_parse_sequence` (dataloader/outdoor_data_mfcc.py:263-343) returns:
+    dict(audio_images float32 [steps,H,W,D] (flipped LR + UD), audio_samples int32 [-1, samples], video_images uint8
+    [steps,H,W,D], action, location) via acimg_sequence_example_decode."""
+    lib = _lib.load()
+    rec = np.frombuffer(record, dtype=np.uint8)
+    dims = _lib.SequenceDims()
+    _lib.check(lib.acimg_sequence_example_decode(rec.ctypes.data, rec.size, ctypes.byref(dims), None, 0, None, 0,
+                                                 None, 0), "sequence_example_decode")
+    ai = np.empty((dims.audio_image_steps, dims.audio_height, dims.audio_width, dims.audio_depth), np.float32)
+    sa = np.empty(dims.audio_data_values, np.int32)
+    vi = np.empty((dims.video_steps, dims.video_height, dims.video_width, dims.video_depth), np.uint8)
+    _lib.check(lib.acimg_sequence_example_decode(rec.ctypes.data, rec.size, ctypes.byref(dims),
+                                                 ai.ctypes.data if ai.size else None, ai.size,
+                                                 sa.ctypes.data if sa.size else None, sa.size,
+                                                 vi.ctypes.data if vi.size else None, vi.size),
+               "sequence_example_decode")
+    if dims.samples > 0:
+        sa = sa.reshape(-1, dims.samples)
+    return dict(audio_images=ai, audio_samples=sa, video_images=vi, action=int(dims.classes),
+                location=int(dims.location), dims=dims)

@@ -64,32 +64,61 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=32, help="BASELINE.md §3: the CPU leg runs the GPU leg's batch")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every host core this process may run on")
+    ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds of timed CPU work after which no further "
+                                                                     "timed step starts")
     return ap.parse_args()
+
+
+def host_cores():
+    """host cores this process can really use: the CPU affinity mask, capped by the cgroup CPU quota (a GPU box gives a
+    one-GPU job a share of the host, e.g. 16 of 128 cores; threads beyond the quota only get throttled)"""
+    n = len(os.sched_getaffinity(0))
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(f).read().split()
+            if f.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
 
 
 def cpu_baseline(args):
     """CPU oracle train step: the SAME step as the GPU leg — same generator variant (--num-skip), same
-    batch (32) — on a bounded sample: 1 warm-up + 3 timed steps (about 20 s each on the GPU box's host cores, so
-    the default bench.py run stays within a few minutes; BASELINE.md's 3 + 10 steps would not).  `cores` = the thread
-    count actually set with torch.set_num_threads."""
+    batch (32) — on a BOUNDED sample: 1 warm-up step, then up to --cpu-steps (3) timed steps, stopping early once
+    --cpu-budget seconds (default 150) of timed work are spent (at least one timed step), so the default bench.py run
+    stays within a few minutes; BASELINE.md's 3 + 10 steps would not.  `cores` = the thread count actually set with
+    torch.set_num_threads (affinity mask capped by the cgroup CPU quota).  Progress goes to stderr."""
     from oracle import trainer as otr
 
-    n = args.cpu_threads if getattr(args, "cpu_threads", 0) else len(os.sched_getaffinity(0))
+    n = args.cpu_threads if getattr(args, "cpu_threads", 0) else host_cores()
     torch.set_num_threads(n)
     n = torch.get_num_threads()
+    budget = float(getattr(args, "cpu_budget", 150.0))
     orc = otr.Oracle(num_skip=args.num_skip, learning_rate=1e-4)
     ac, mf, vid, eps = otr.synthetic_batch(args.cpu_batch, seed=1234)
-    orc.train_step(ac, mf, vid, eps)
     t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
+    orc.train_step(ac, mf, vid, eps)
+    print("[cpu_baseline] warm-up step (batch %d, %d threads): %.1f s" % (args.cpu_batch, n, time.perf_counter() - t0),
+          file=sys.stderr, flush=True)
+    done = 0
+    t0 = time.perf_counter()
+    while done < args.cpu_steps and (done == 0 or time.perf_counter() - t0 < budget):
         orc.train_step(ac, mf, vid, eps)
+        done += 1
+        print("[cpu_baseline] timed step %d: %.1f s so far" % (done, time.perf_counter() - t0), file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
-    rate = args.cpu_batch * args.cpu_steps / dt
+    rate = args.cpu_batch * done / dt
     return {"value": rate, "unit": "images/s", "cores": n, "kind": "port",
             "gflops": rate * 41.7,
             "sample": "CPU oracle (PyTorch fp32 restatement of the TF-1 graph; TF-1 unavailable offline): the same "
-                      "TrainerMask train step, %d-skip generator, batch %d, %d timed steps after 1 warm-up, %d threads"
-                      % (args.num_skip, args.cpu_batch, args.cpu_steps, n)}
+                      "TrainerMask train step, %d-skip generator, batch %d, %d timed steps (%.0f s) after 1 warm-up, "
+                      "%d threads" % (args.num_skip, args.cpu_batch, done, dt, n)}
 
 
 def load_traffic_profile(kernel_name):

@@ -421,6 +421,34 @@ int acimg_adam_step(float* p, const float* g, float* m, float* v, long n, float 
  * ---------------------------------------------------------------------------------------- */
 int acimg_mfcc_frontend(const int32_t* frames, const double* window, const double* melfb,
                         const double* dctl, float* out, int nframes, int normalize, void* stream);
+/* the same on float32 frames: the low-passed ("silence") waveform of butter_lowpass_filter, which the reference
+ * feeds to the same function (dataloader/outdoor_data_mfcc.py:791-792) */
+int acimg_mfcc_frontend_f32(const float* frames, const double* window, const double* melfb,
+                            const double* dctl, float* out, int nframes, int normalize, void* stream);
+
+/* STFT magnitude of the older audio path (dataloader/outdoor_data.py:844-851: tf.contrib.signal.stft(frame_length 246,
+ * frame_step 122, fft_length 512) + tf.abs): wav [clips][nsamples] float32 -> out [clips][frames][257] float32,
+ * frames = 1 + (nsamples - frame_len) / step (pad_end = False; 12288 samples -> 99 x 257).  window[frame_len]
+ * (periodic Hann, float32) and twiddle[256][2] (exp(-2 pi i j / 512), float32 from float64) are host tables.  norm
+ * (optional, [clips]) divides every sample first: the `wav / max |wav|` of _build_wav_py_function (:577-596); get it
+ * from acimg_absmax.  fp32 arithmetic like TensorFlow's rfft. */
+int acimg_stft_mag(const float* wav, const float* norm, const float* window, const float* twiddle, float* out,
+                   int clips, int nsamples, int frame_len, int step, int fft_len, void* stream);
+/* out[r] = max_i |x[r][i]|   (x: [rows][n]) */
+int acimg_absmax(const float* x, int rows, int n, float* out, void* stream);
+
+/* tf.image.resize_bilinear(x, [OH, OW], align_corners=False) with TF-1 sampling (src = dst * in/out, no half-pixel
+ * centres), NHWC float32.  Replaces: trainer/trainer.py:367-369 (99x257 spectrogram -> 193x257). */
+int acimg_resize_bilinear(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, void* stream);
+
+/* scipy.signal.filtfilt(b, a, x) along the last axis for 11-tap (order-10) IIR filters, default padding (odd
+ * extension, padlen 33), float64 arithmetic without fused multiply-adds, float32 out:
+ * dataloader/outdoor_data_mfcc.py:565-575 (butter_lowpass_filter, the "silence" variant of the MFCC input).
+ * x: [rows][n] int32 (x_is_int32 != 0, the raw audio frames) or float32; ba: b[11] then a[11] (a[0] = 1);
+ * zi: scipy.signal.lfilter_zi(b, a) [10]; ws: acimg_filtfilt_workspace(rows, n) bytes. */
+int acimg_filtfilt(const void* x, int x_is_int32, int rows, int n, const double* ba, const double* zi, float* out,
+                   void* ws, size_t ws_bytes, void* stream);
+size_t acimg_filtfilt_workspace(int rows, int n);
 
 /* find_logen energy map (iouenergythreshold.py:294-323): mfcc image [pixels,12] -> [pixels] */
 int acimg_find_logen(const float* mfcc_img, const double* idct /*12x24*/, float* out, long pixels,
@@ -429,6 +457,33 @@ int acimg_find_logen(const float* mfcc_img, const double* idct /*12x24*/, float*
 /* Mean-threshold IoU of two energy maps per sample (iouenergythreshold.py:213-229): m = map > mean(map),
  * iou[n] = |m_a & m_b| / |m_a | m_b|.  map_a, map_b: [N][P] float32 (acimg_find_logen outputs). */
 int acimg_mask_iou(const float* map_a, const float* map_b, int N, int P, float* iou, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dataset records (host side, no GPU work; caller-owned memory like everything else): the GZIP TFRecord files of
+ * tf.train.SequenceExample written by convert_data.py:247-279 and read by dataloader/outdoor_data_mfcc.py:62,263-343.
+ * ---------------------------------------------------------------------------------------- */
+/* Inflate a whole .tfrecord file image (GZIP auto-detected by its magic; anything else is copied).  *produced =
+ * the inflated size, also when `out` is NULL / too small (ACIMG_EWORKSPACE): call once to size, once to fill. */
+int acimg_gzip_inflate(const uint8_t* src, size_t src_len, uint8_t* out, size_t cap, size_t* produced);
+/* Walk the TFRecord framing [u64 len][u32 masked crc32c(len)][data][u32 masked crc32c(data)] of an inflated file
+ * image: returns the number of records (>= 0) and fills the payload offset / length of the first `cap` of them;
+ * verify != 0 checks both checksums of every record.  Negative = ACIMG_E* (truncated / corrupt). */
+long acimg_tfrecord_index(const uint8_t* buf, size_t len, uint64_t* offsets, uint64_t* lengths, long cap, int verify);
+/* What `_parse_sequence` (dataloader/outdoor_data_mfcc.py:263-343) extracts from one serialized SequenceExample. */
+typedef struct AcimgSequenceDims {
+    int64_t classes, location;                        /* context 'classes', 'location' */
+    int64_t audio_height, audio_width, audio_depth;   /* 'audio_image/{height,width,depth}' (0 if absent) */
+    int64_t mics, samples;                            /* 'audio_data/{mics,samples}' */
+    int64_t video_height, video_width, video_depth;   /* 'video/{height,width,depth}' */
+    int64_t audio_image_steps, audio_data_steps, video_steps;   /* feature-list lengths (12 = one second) */
+    int64_t audio_data_values;                        /* int32 values over all 'audio/data' steps */
+} AcimgSequenceDims;
+/* Decode one record: context scalars + list lengths into *dims; the raw tensors (tf.decode_raw) into the caller's
+ * buffers when given (NULL = sizes only; capacities in ELEMENTS): audio_images float32 [steps][H][W][D] already
+ * flipped left-right and up-down as :314-315 do, audio_samples int32 [values], video uint8 [steps][H][W][D]. */
+int acimg_sequence_example_decode(const uint8_t* rec, size_t len, AcimgSequenceDims* dims, float* audio_images,
+                                  size_t audio_images_cap, int32_t* audio_samples, size_t audio_samples_cap,
+                                  uint8_t* video, size_t video_cap);
 
 /* ------------------------------------------------------------------------------------------
  * Host-side helper (no GPU): CRC-32C (Castagnoli) of a byte range, continuing from `crc` (0 to start) — the

@@ -9,6 +9,12 @@ Restates dataloader/outdoor_data_mfcc.py:
   :565-575  butter_lowpass / butter_lowpass_filter (order-10 125 Hz, filtfilt)
 and iouenergythreshold.py:294-323 find_logen.
 Pinned by tests/golden/frontend_golden.npz (made from the reference's own functions).
+
+`stft_mag` / `resize_bilinear` restate the TensorFlow ops of the older spectrogram path
+(dataloader/outdoor_data.py:844-851, trainer/trainer.py:364-369) from their published definitions
+(tf.contrib.signal.stft: periodic Hann window, frames zero-padded to fft_length, rfft, pad_end=False;
+tf.image.resize_bilinear TF-1, align_corners=False: src = dst * in/out, no half-pixel centres).  TensorFlow is not
+installed here and the reference holds no fixture for them: PARITY UNPINNED for these two functions.
 """
 import numpy as np
 from scipy import signal
@@ -100,3 +106,43 @@ def mask_iou(real_img, gen_img):
     a = m1 > np.mean(m1)
     b = m2 > np.mean(m2)
     return np.sum(np.logical_and(a, b)) / np.sum(np.logical_or(a, b))
+
+
+def build_wav(audio_samples):
+    """dataloader/outdoor_data.py:577-596 `_build_wav_py_function`: float32, flatten, divide by max |.|"""
+    w = np.asarray(audio_samples).astype(np.float32).flatten("C")
+    return w / abs(max(w.min(), w.max(), key=abs))
+
+
+def stft_mag(wav, frame_length=246, frame_step=122, fft_length=512):
+    """float32 [..., nsamples] -> float64-accurate |STFT| rounded to float32, [..., frames, fft_length//2+1]"""
+    wav = np.asarray(wav, np.float32)
+    n = wav.shape[-1]
+    frames = 1 + (n - frame_length) // frame_step
+    win = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(frame_length) / frame_length)).astype(np.float32)
+    idx = np.arange(frame_length)[None, :] + frame_step * np.arange(frames)[:, None]
+    fr = (wav[..., idx] * win).astype(np.float32)                     # TF multiplies in float32
+    return np.abs(np.fft.rfft(fr.astype(np.float64), fft_length, axis=-1)).astype(np.float32)
+
+
+def resize_bilinear(x, oh, ow):
+    """NHWC float32, TF-1 legacy sampling, float32 arithmetic in the order of TF's kernel"""
+    x = np.asarray(x, np.float32)
+    N, H, W, C = x.shape
+    hs, ws = np.float32(H) / np.float32(oh), np.float32(W) / np.float32(ow)
+
+    def axis(out, size, scale):
+        src = (np.arange(out, dtype=np.float32) * scale).astype(np.float32)
+        lo = np.floor(src).astype(np.int64)
+        hi = np.minimum(lo + 1, size - 1)
+        return lo, hi, (src - lo.astype(np.float32)).astype(np.float32)
+
+    y0, y1, yl = axis(oh, H, hs)
+    x0, x1, xl = axis(ow, W, ws)
+    xl = xl[None, None, :, None]
+    yl = yl[None, :, None, None]
+    tl, tr = x[:, y0][:, :, x0], x[:, y0][:, :, x1]
+    bl, br = x[:, y1][:, :, x0], x[:, y1][:, :, x1]
+    top = (tl + ((tr - tl) * xl).astype(np.float32)).astype(np.float32)
+    bot = (bl + ((br - bl) * xl).astype(np.float32)).astype(np.float32)
+    return (top + ((bot - top) * yl).astype(np.float32)).astype(np.float32)

@@ -261,12 +261,13 @@ def test_bench_contract_on_cpu():
     assert (args.gpus, args.batch, args.workload, args.precision) == (1, 32, "trainer_mask", "f16x3")
     assert args.steps * 0.01 < 60 and args.warmup >= 1          # minutes at ~10 ms / step
     assert (args.cpu_batch, args.scaling, args.global_batch) == (32, "weak", 256)    # CPU leg at the GPU leg's batch
-    small = types.SimpleNamespace(num_skip=1, cpu_batch=1, cpu_steps=1, cpu_threads=2)
+    small = types.SimpleNamespace(num_skip=1, cpu_batch=1, cpu_steps=1, cpu_threads=2, cpu_budget=60.0)
     cb = bench.cpu_baseline(small)
     assert set(cb) >= {"value", "unit", "cores", "kind", "sample"} and cb["kind"] == "port" and cb["value"] > 0
     assert cb["unit"] == "images/s" and cb["cores"] == 2 and "1-skip" in cb["sample"]
     import torch
-    torch.set_num_threads(len(os.sched_getaffinity(0)))
+    torch.set_num_threads(bench.host_cores())
+    assert 1 <= bench.host_cores() <= len(os.sched_getaffinity(0))
     # the roofline's counter traffic comes from a committed PMC summary, never from a literal in bench.py
     src = open(os.path.join(root, "bench.py")).read()
     assert "252.0e6" not in src and "28.67e9" not in src

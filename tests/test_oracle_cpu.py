@@ -383,3 +383,43 @@ def test_joint_mlp_oracle_and_host_graph(which, widths):
     assert set(sd) == set(want) and all(tuple(sd[k].shape) == tuple(want[k]) for k in want)
     with pytest.raises(AssertionError):                       # inputs in the wrong order are not a concat
         getattr(multimodal, which)()._build_model(*parts[::-1], session=Session(torch.device("cpu")))
+
+
+def test_stft_and_resize_restatements_known_answers():
+    """oracle.frontend.stft_mag / resize_bilinear (TensorFlow definitions, unpinned): closed-form cases"""
+    n = 12288
+    t = np.arange(n, dtype=np.float32)
+    spec = frontend.stft_mag(np.cos(2 * np.pi * 32 * t / 512)[None, :].astype(np.float32))
+    assert spec.shape == (1, 99, 257)                                   # SURVEY App. B.13
+    assert np.all(spec[0].argmax(1) == 32)
+    # a windowed cosine on an exact bin: |X[32]| = sum(window) / 2 = 246 / 4 (periodic Hann sums to N / 2)
+    np.testing.assert_allclose(spec[0, :, 32], 61.5, rtol=2e-4)
+    # DC input: bin 0 = sum of the window = 123
+    dc = frontend.stft_mag(np.ones((1, 1000), np.float32))
+    assert dc.shape == (1, 7, 257)
+    np.testing.assert_allclose(dc[0, :, 0], 123.0, rtol=1e-6)
+    w = frontend.build_wav(np.array([[3, -8], [4, 2]], np.int32))
+    np.testing.assert_array_equal(w, np.array([3, -8, 4, 2], np.float32) / 8)
+    # resize: identity at equal size; 2 -> 4 rows samples src rows 0, .5, 1, 1(clamped)
+    x = np.arange(12, dtype=np.float32).reshape(1, 2, 3, 2)
+    np.testing.assert_array_equal(frontend.resize_bilinear(x, 2, 3), x)
+    up = frontend.resize_bilinear(x, 4, 3)
+    np.testing.assert_array_equal(up[0, :, 0, 0], [0, 3, 6, 6])
+    up = frontend.resize_bilinear(np.zeros((1, 99, 257, 1), np.float32), 193, 257)
+    assert up.shape == (1, 193, 257, 1)
+
+
+def test_host_butterworth_design_equals_scipy():
+    """acimg.frontend.butter_lowpass / lfilter_zi (NumPy-only host code of the product) reproduce SciPy's design of
+    dataloader/outdoor_data_mfcc.py:565-569 bit for bit, and SURVEY App. D's known answers"""
+    from scipy import signal
+
+    from acimg import frontend as fe
+
+    b, a = fe.butter_lowpass(125, 10)
+    b2, a2 = signal.butter(10, 125 / (0.5 * 12288), btype="low", analog=False)
+    np.testing.assert_array_equal(b, b2)
+    np.testing.assert_array_equal(a, a2)
+    np.testing.assert_array_equal(fe.lfilter_zi(b, a), signal.lfilter_zi(b2, a2))
+    assert len(b) == 11 and abs(b[0] - 9.0892e-16) < 1e-19 and abs(a[1] + 9.5914255) < 1e-6
+    np.testing.assert_allclose(fe.hann_window_periodic(246).sum(), 123.0, rtol=1e-6)

@@ -3,6 +3,7 @@ TFRecords of SequenceExamples.  Known answers pin the checksum (RFC 3720 CRC-32C
 constant and the SSTable magic; everything else is round-tripped and checked at the byte level where the format
 fixes the bytes."""
 import os
+from collections import OrderedDict
 import struct
 import sys
 
@@ -146,3 +147,90 @@ def test_iou_curve_host_arithmetic():
     assert acc[0] == 1.0 and acc[-1] == 0.0 and abs(acc[5] - 0.5) < 1e-12      # IoU > 0.5: 3 of 6
     want = metrics.auc(evaluate.THRESHOLDS[::-1], list(acc[::-1]))
     assert abs(evaluate.area_under_curve(acc) - want) < 1e-12
+
+
+def _dataset_record(rng, steps=12, with_acoustic=True):
+    """one SequenceExample in the layout of convert_data.py:247-279 / outdoor_data_mfcc.py:263-343"""
+    ai = rng.rand(steps, 36, 48, 12).astype(np.float32)
+    sa = (rng.randn(steps, 1024) * 1000).astype(np.int32)
+    vi = rng.randint(0, 256, size=(steps, 8, 10, 3)).astype(np.uint8)        # small frames keep the test light
+    ctx = OrderedDict([("classes", np.array([7])), ("location", np.array([2])),
+                       ("audio_data/mics", np.array([1])), ("audio_data/samples", np.array([1024])),
+                       ("video/height", np.array([8])), ("video/width", np.array([10])), ("video/depth", np.array([3]))])
+    lists = OrderedDict([("audio/data", [s.tobytes() for s in sa]), ("video/image", [v.tobytes() for v in vi])])
+    if with_acoustic:
+        ctx.update([("audio_image/height", np.array([36])), ("audio_image/width", np.array([48])),
+                    ("audio_image/depth", np.array([12]))])
+        lists["audio/image"] = [a.tobytes() for a in ai]
+    return tfio.build_sequence_example(ctx, lists), ai, sa, vi
+
+
+@pytest.mark.parametrize("compression", ["GZIP", None])
+def test_native_record_reader_equals_python_reader(tmp_path, compression):
+    """the C++ reader behind the C ABI (acimg_gzip_inflate, acimg_tfrecord_index, acimg_sequence_example_decode)
+    returns byte-for-byte what tfio.py's Python writer put in / its Python reader gets out, and decodes a record like
+    `_parse_sequence` (dataloader/outdoor_data_mfcc.py:263-343) incl. the left-right + up-down flip of :314-315"""
+    rng = np.random.RandomState(5)
+    recs, truth = [], []
+    for i in range(3):
+        r, ai, sa, vi = _dataset_record(rng, steps=12 if i < 2 else 5, with_acoustic=i != 1)
+        recs.append(r)
+        truth.append((ai if i != 1 else None, sa, vi))
+    recs.append(b"")                                            # an empty record is legal framing
+    path = str(tmp_path / "data.tfrecord")
+    tfio.write_tfrecord(path, recs, compression=compression)
+    py = list(tfio.read_tfrecord(path))
+    nat = tfio.read_tfrecord_native(path)
+    assert len(nat) == len(py) == 4
+    for a, b, c in zip(nat, py, recs):
+        assert bytes(a) == b == c
+    for i in range(3):
+        d = tfio.decode_sequence_example_native(nat[i])
+        ai, sa, vi = truth[i]
+        assert (d["action"], d["location"]) == (7, 2)
+        np.testing.assert_array_equal(d["audio_samples"], sa)
+        np.testing.assert_array_equal(d["video_images"], vi)
+        if ai is None:
+            assert d["audio_images"].size == 0 and d["dims"].audio_image_steps == 0
+        else:
+            np.testing.assert_array_equal(d["audio_images"], ai[:, ::-1, ::-1, :])
+        ctx, lists = tfio.parse_sequence_example(bytes(nat[i]))       # the Python parser sees the same values
+        assert int(ctx["classes"][0]) == d["action"] and len(lists["audio/data"]) == d["dims"].audio_data_steps
+    with pytest.raises(Exception):
+        tfio.decode_sequence_example_native(nat[3])             # no 'classes' / 'location': FixedLenFeature missing
+
+
+def test_native_record_reader_detects_corruption(tmp_path):
+    rng = np.random.RandomState(6)
+    rec, _, _, _ = _dataset_record(rng, steps=2)
+    good = str(tmp_path / "g.tfrecord")
+    tfio.write_tfrecord(good, [rec, rec])
+    raw = bytearray(open(good, "rb").read())
+    for pos, what in ((20 + 12, "payload"), (9, "length"), (len(raw) - 2, "payload")):
+        bad = bytearray(raw)
+        bad[pos] ^= 0x40
+        p = str(tmp_path / "bad.tfrecord")
+        open(p, "wb").write(bad)
+        with pytest.raises(IOError) as ei:
+            tfio.read_tfrecord_native(p)
+        assert what in str(ei.value), str(ei.value)
+        assert len(tfio.read_tfrecord_native(p, verify=False)) == 2 or what == "length"
+    p = str(tmp_path / "trunc.tfrecord")
+    open(p, "wb").write(raw[:len(raw) - 7])
+    with pytest.raises(IOError) as ei:
+        tfio.read_tfrecord_native(p)
+    assert "truncated" in str(ei.value)
+    # a truncated GZIP stream is an error too, not a short read
+    gz = str(tmp_path / "g.gz.tfrecord")
+    tfio.write_tfrecord(gz, [rec] * 3, compression="GZIP")
+    blob = open(gz, "rb").read()
+    open(gz, "wb").write(blob[:len(blob) // 2])
+    with pytest.raises(Exception) as ei:
+        tfio.read_tfrecord_native(gz)
+    assert "GZIP" in str(ei.value)
+    # malformed protobuf inside a well-framed record
+    with pytest.raises(Exception):
+        tfio.decode_sequence_example_native(bytes(rec[:len(rec) // 3]))
+    empty = str(tmp_path / "empty.tfrecord")
+    open(empty, "wb").close()
+    assert tfio.read_tfrecord_native(empty) == []
