@@ -234,3 +234,56 @@ def test_native_record_reader_detects_corruption(tmp_path):
     empty = str(tmp_path / "empty.tfrecord")
     open(empty, "wb").close()
     assert tfio.read_tfrecord_native(empty) == []
+
+
+def test_reader_on_hand_built_known_answer_bundle(tmp_path):
+    """f1: a Saver-V2 checkpoint built byte by byte from the published SSTable / tensor-bundle formats by
+    tests/golden/make_bundle_golden.py (own CRC-32C, no acimg code; index key of the block = LevelDB's short
+    successor, prefix-compressed keys, BundleHeaderProto / BundleEntryProto packed field by field) is read back
+    exactly.  Still NOT a TensorFlow-written file: unpinned against TF itself."""
+    import importlib.util
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_bundle_golden", os.path.join(gold, "make_bundle_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    prefix = os.path.join(gold, "bundle_known_answer", "model.ckpt")
+    # the committed fixture IS what the committed script writes
+    mk.OUT = str(tmp_path)
+    mk.main()
+    for sfx in (".index", ".data-00000-of-00001"):
+        assert open(prefix + sfx, "rb").read() == open(str(tmp_path / ("model.ckpt" + sfx)), "rb").read()
+    idx = open(prefix + ".index", "rb").read()
+    assert idx[-8:] == struct.pack("<Q", 0xdb4775248b80fb57) and len(idx) >= 48
+    assert idx[:3] == b"\x00\x00\x06" and idx[3:9] == b"\x08\x01\x1a\x02\x08\x01"     # "" -> BundleHeaderProto
+    entries = tfio.list_checkpoint(prefix, verify=True)
+    assert entries[""]["num_shards"] == 1
+    want = mk.tensors()
+    assert list(entries)[1:] == list(want)
+    off = 0
+    for name, a in want.items():
+        e = entries[name]
+        assert (e["offset"], e["size"], e["shard_id"], tuple(e["shape"])) == (off, a.nbytes, 0, a.shape), name
+        assert tfio.unmask_crc(e["crc32c"]) == tfio.crc32c_array(a) == mk.crc32c(a.tobytes()) or a.nbytes > 4096
+        off += a.nbytes
+    got = tfio.read_checkpoint(prefix, verify=True)
+    for name, a in want.items():
+        assert got[name].dtype == a.dtype and np.array_equal(got[name], a), name
+    assert int(got["global_step"]) == 42 and got["UNetAcRes/layer7/conv_2/kernel"].shape == (3, 3, 64, 64)
+    only = tfio.read_checkpoint(prefix, names=lambda n: n.startswith("UNetAcRes/"))
+    assert sorted(only) == sorted(n for n in want if n.startswith("UNetAcRes/"))
+    # the model-side loader accepts the prefix (trainer/mfcctrainer.py:214-225: saver.restore(session, prefix))
+    from acimg.vision import load_state_file
+    assert set(load_state_file(prefix)) == set(want)
+    # one flipped data byte fails the per-tensor checksum; one flipped index byte fails the block checksum
+    bad = str(tmp_path / "bad.ckpt")
+    raw = bytearray(open(prefix + ".data-00000-of-00001", "rb").read())
+    raw[5] ^= 1
+    open(bad + ".data-00000-of-00001", "wb").write(raw)
+    open(bad + ".index", "wb").write(idx)
+    with pytest.raises(IOError):
+        tfio.read_checkpoint(bad, verify=True)
+    bi = bytearray(idx)
+    bi[20] ^= 1
+    open(bad + ".index", "wb").write(bi)
+    with pytest.raises(IOError):
+        tfio.list_checkpoint(bad, verify=True)

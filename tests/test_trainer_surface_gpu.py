@@ -114,3 +114,38 @@ def test_train_checkpoint_restore_test(device, tmp_path):
         tr._save_checkpoint(sess, e)
     left = [f for f in os.listdir(d) if f.endswith(".index")]
     assert len(left) == 11 and "epoch_random.ckpt.index" not in left and "epoch_111.ckpt.index" in left
+
+
+def test_init_model_from_known_answer_bundle(device):
+    """`init_model(session, checkpoint_file)` of both models (models/unet_acresnet.py:33-41; models/vision.py:26-43
+    = trainer/mfcctrainer.py:214-225: restore resnet_v1_50/* EXCEPT logits and conv_map) on the hand-built Saver-V2
+    bundle of tests/golden/make_bundle_golden.py"""
+    import importlib.util
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_bundle_golden", os.path.join(gold, "make_bundle_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    want = mk.tensors()
+    prefix = os.path.join(gold, "bundle_known_answer", "model.ckpt")
+    tr, sess = make(device)
+    tr._build_functions(batch_size=2)
+    tr.modelimages.initialize(seed=1)
+    tr.modelac.initialize(seed=2)
+    before = sess.store.state_dict()
+    loaded_v = tr.modelimages.init_model(sess, prefix)
+    loaded_a = tr.modelac.init_model(sess, prefix)
+    after = sess.store.state_dict()
+    assert sorted(loaded_v) == ["resnet_v1_50/conv1/BatchNorm/gamma", "resnet_v1_50/conv1/BatchNorm/moving_mean"]
+    assert sorted(loaded_a) == ["UNetAcRes/final/bias", "UNetAcRes/layer7/conv_2/bias", "UNetAcRes/layer7/conv_2/kernel"]
+    for k in loaded_v + loaded_a:
+        assert np.array_equal(after[k].numpy(), want[k]), k
+    # conv_map is NOT restored from a visual checkpoint (:218-221), everything else is untouched
+    assert torch.equal(after["resnet_v1_50/conv_map/BatchNorm/beta"], before["resnet_v1_50/conv_map/BatchNorm/beta"])
+    for k in before:
+        if k not in loaded_v + loaded_a:
+            assert torch.equal(before[k], after[k]), k
+    # and the step still runs on the restored variables
+    from acimg.data import SyntheticDataLoader
+    b = next(iter(SyntheticDataLoader(2, 2, seed=3).data))
+    r = tr.train_step((b[0], b[1], b[2]))
+    assert np.isfinite(r["loss"])
