@@ -3,6 +3,8 @@
 // chain runs in fp64 here as well so the float32 results agree with NumPy to the last bits.
 // One 256-thread block per frame: radix-2 FFT in LDS (16 KiB), mel filter bank as 8-lane partial
 // dot products reduced with wave shuffles.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace acimg {
@@ -253,10 +255,13 @@ __global__ __launch_bounds__(64) void filtfilt_kernel(const T* x, int rows, int 
     const T* xr = x + (long)row * n;
     const int next = n + 2 * FF_PAD;
     const double x0 = (double)xr[0], xe = (double)xr[n - 1];
-    auto ext = [&](int i) -> double {                       // odd extension (scipy.signal._arraytools.odd_ext)
-        if (i < FF_PAD) return 2.0 * x0 - (double)xr[FF_PAD - i];
+    // odd extension (scipy.signal._arraytools.odd_ext): computed in the INPUT's dtype as NumPy does — exact for the
+    // loader's int32 frames, one float32 rounding for float32 input — then promoted to float64 by lfilter
+    auto edge = [](double v) -> double { return sizeof(T) == sizeof(float) && !std::is_integral<T>::value ? (double)(float)v : v; };
+    auto ext = [&](int i) -> double {
+        if (i < FF_PAD) return edge(2.0 * x0 - (double)xr[FF_PAD - i]);
         if (i < FF_PAD + n) return (double)xr[i - FF_PAD];
-        return 2.0 * xe - (double)xr[n - 2 - (i - FF_PAD - n)];
+        return edge(2.0 * xe - (double)xr[n - 2 - (i - FF_PAD - n)]);
     };
     const double e0 = ext(0);
 #pragma unroll

@@ -95,7 +95,7 @@ def test_lowpass_filtfilt_matches_reference_golden(device):
     b, a = signal.butter(10, 125 / (0.5 * 12288), btype="low", analog=False)
     want = np.float32(signal.filtfilt(b, a, x))
     got = fe.butter_lowpass_filter(torch.tensor(x, device=device)).cpu().numpy()
-    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-4 * np.abs(want).max())
+    np.testing.assert_array_equal(got, want)     # NumPy extends float32 input in float32; so does the kernel
     # a signal no longer than the padding is refused, like scipy's ValueError
     from acimg import _lib
     with pytest.raises(_lib.AcimgError):
