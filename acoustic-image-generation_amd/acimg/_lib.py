@@ -28,7 +28,7 @@ class Config(C.Structure):
 
     _fields_ = [(n, C.c_int32) for n in (
         "splitk_cut", "splitk_target", "splitk_handoff", "wgrad_minpix", "wgrad_halo", "split3_tile_bm",
-        "split3_tile_bn", "tail_split", "tail_s")]
+        "split3_tile_bn", "tail_split", "tail_s", "trunk_persistent")]
 
 
 class SequenceDims(C.Structure):
@@ -192,7 +192,7 @@ def configure_from_env(env=None):
         if env.get(var):
             kw[field] = int(env[var])
     for var, field in (("ACIMG_NO_SPLITK_HANDOFF", "splitk_handoff"), ("ACIMG_NO_WGRAD_HALO", "wgrad_halo"),
-                       ("ACIMG_NO_TAIL_SPLIT", "tail_split")):
+                       ("ACIMG_NO_TAIL_SPLIT", "tail_split"), ("ACIMG_NO_PERSISTENT", "trunk_persistent")):
         if env.get(var):
             kw[field] = 0
     if env.get("ACIMG_SPLIT3_TILE"):

@@ -14,6 +14,7 @@
 // unchanged.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t.
 #include "wgrad_split3_kernel.hpp"
 #include "igemm_split3d_kernel.hpp"
+#include "igemm_split3dp_kernel.hpp"
 #include <cstdlib>
 #include <algorithm>
 
@@ -637,7 +638,7 @@ static TileCfg pick_cfg(int M, int Ngemm) {
 
 // Tuning record (acimg_configure): plain ints, defaults compiled in, written only by acimg_configure and never by a
 // launch; the launch heuristics below read it instead of the process environment.
-static AcimgConfig g_cfg = {320, 768, 1, 128, 1, 0, 0, 1, 0};
+static AcimgConfig g_cfg = {320, 768, 1, 128, 1, 0, 0, 1, 0, 1};
 
 static int pick_splits(int M, int Ngemm, TileCfg c, int kiters) {
     // measured on the generator's 12x16 layers (192-288 tiles of 64x64, 36+ K steps: tools/splitk_sweep.sh):
@@ -1177,7 +1178,7 @@ int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
 
 int acimg_config_default(AcimgConfig* c) {
     if (!c) return fail(ACIMG_EINVAL, "config_default: null");
-    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0};
+    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1};
     return ACIMG_OK;
 }
 
@@ -1639,7 +1640,7 @@ int acimg_conv2d_dgrad_split3(const AcimgConvDesc* d, const float* gy, int ldgy,
 // ---- tail split of the trunk kernel: which tiles to cut, and into how many K ranges ------------------------
 struct TailPlan { int whole, s, rem; };
 static int resident_slots(int which, const void* fn, int threads, size_t lds) {
-    static int cache[3] = {0, 0, 0};
+    static int cache[4] = {0, 0, 0, 0};
     if (!cache[which]) {
         int dev = 0, ncu = 0, per = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -1647,7 +1648,7 @@ static int resident_slots(int which, const void* fn, int threads, size_t lds) {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, threads, lds) != hipSuccess || ncu <= 0 || per <= 0) {
             (void)hipGetLastError();
             ncu = 256;                    // MI355X; no device (CPU-side sizing queries): same answer
-            per = which == 0 ? 2 : 3;
+            per = (which == 0 || which == 3) ? 2 : 3;
         }
         cache[which] = ncu * per;
     }
@@ -1726,14 +1727,26 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
     const void* fn = which == 0 ? (const void*)igemm_split3d_kernel<128, 128, 2, 4, 512, 2, 2>
                    : which == 1 ? (const void*)igemm_split3d_kernel<64, 128, 1, 4, 256, 2, 2>
                                 : (const void*)igemm_split3d_kernel<128, 64, 2, 2, 256, 2, 2>;
+    if ((long)p.M * d->ldy * 4 >= (1L << 31)) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: output >= 2 GiB");
+    const bool persistent = which == 0 && g_cfg.trunk_persistent;
+    const size_t lds_p = 2 * 4 * 128 * 64 + 4 * 2 * 128 * 4;      // igemm_split3dp_kernel: 2 stages + statistics scratch
     TailPlan tp{T, 1, 0};
+    const int P = persistent ? resident_slots(3, (const void*)igemm_split3dp_kernel, 512, lds_p)
+                             : resident_slots(which, fn, which == 0 ? 512 : 256, lds_bytes);
     if (ws && ws_bytes >= acimg_conv2d_fwd_split3p_workspace(d) && which == 0)
-        tp = pick_tail(T, resident_slots(which, fn, 512, lds_bytes), p.kiters, TS_MAX_UNITS);
+        tp = pick_tail(T, P, p.kiters, TS_MAX_UNITS);
     p.ts_whole = tp.whole; p.ts_s = tp.s;
     p.ts_counters = static_cast<int*>(ws);
     p.ts_partial = ws ? reinterpret_cast<float*>(static_cast<char*>(ws) + TS_COUNTER_BYTES) : nullptr;
-    const dim3 grid(tp.whole + tp.rem * tp.s);
-    if (which == 0)
+    const int n_units = tp.whole + tp.rem * tp.s;
+    const dim3 grid(n_units);
+    if (persistent) {
+        // a workgroup per resident slot walks units blockIdx.x, blockIdx.x + P, ...: whole tiles first (with the
+        // next tile's first operand stage and addresses prepared under the current tile's last K step and output
+        // stores), then the K ranges of the tail tiles
+        const int nwg = std::min(n_units, P);
+        hipLaunchKernelGGL(igemm_split3dp_kernel, dim3(nwg), dim3(512), lds_p, st, p, n_units, nwg);
+    } else if (which == 0)
         hipLaunchKernelGGL((igemm_split3d_kernel<128, 128, 2, 4, 512, 2, 2>), grid, dim3(512), lds_bytes, st, p);
     else if (which == 1)
         hipLaunchKernelGGL((igemm_split3d_kernel<64, 128, 1, 4, 256, 2, 2>), grid, dim3(256), lds_bytes, st, p);

@@ -11,7 +11,7 @@
  *     nothing is thrown across the boundary;
  *   - the CALLER owns every buffer (device pointers, 16-byte aligned), including workspace and the
  *     ticket words of the in-kernel reductions (explicit `tickets` / scratch arguments); the library
- *     allocates nothing.  Its only process-wide state is the tuning record of acimg_configure() (nine
+ *     allocates nothing.  Its only process-wide state is the tuning record of acimg_configure() (ten
  *     plain ints with compiled-in defaults, written by that call alone, never by a launch, and never
  *     read from the process environment) and the per-thread text of acimg_last_error();
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*), no host sync;
@@ -99,6 +99,8 @@ typedef struct AcimgConfig {
     int32_t split3_tile_bn;  /*     128x64 */
     int32_t tail_split;      /* 1: trunk kernel cuts the tiles of the last partial round into K ranges */
     int32_t tail_s;          /* 0 = cost model; else force that many K ranges (experiments) */
+    int32_t trunk_persistent;/* 1: 128x128 trunk convs on the persistent kernel (a workgroup walks a tile list, the next
+                                tile's first loads and the output stores overlap the matrix work); 0: one tile per workgroup */
 } AcimgConfig;
 int acimg_config_default(AcimgConfig* cfg);
 int acimg_configure(const AcimgConfig* cfg);
