@@ -318,9 +318,10 @@ def conv2d_fwd_split3_stats_rows(d):
 
 
 def conv2d_fwd_split3_tiling(d):
-    out = (C.c_int * 2)()
+    """(BM, BN, persistent) of the pre-split forward conv launch for `d`"""
+    out = (C.c_int * 3)()
     _lib.check(_L().acimg_conv2d_fwd_split3_tiling(C.byref(d), out), "conv2d_fwd_split3_tiling")
-    return out[0], out[1]
+    return out[0], out[1], out[2]
 
 
 def conv2d_split3_prepare(plan, d, w, wsplit):

@@ -638,7 +638,7 @@ static TileCfg pick_cfg(int M, int Ngemm) {
 
 // Tuning record (acimg_configure): plain ints, defaults compiled in, written only by acimg_configure and never by a
 // launch; the launch heuristics below read it instead of the process environment.
-static AcimgConfig g_cfg = {320, 768, 1, 128, 1, 0, 0, 1, 0, 1};
+static AcimgConfig g_cfg = {320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0};
 
 static int pick_splits(int M, int Ngemm, TileCfg c, int kiters) {
     // measured on the generator's 12x16 layers (192-288 tiles of 64x64, 36+ K steps: tools/splitk_sweep.sh):
@@ -1178,7 +1178,7 @@ int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
 
 int acimg_config_default(AcimgConfig* c) {
     if (!c) return fail(ACIMG_EINVAL, "config_default: null");
-    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1};
+    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0};
     return ACIMG_OK;
 }
 
@@ -1186,6 +1186,11 @@ int acimg_configure(const AcimgConfig* c) {
     if (!c) return fail(ACIMG_EINVAL, "configure: null");
     if (c->splitk_cut < 0 || c->splitk_target < 1 || c->wgrad_minpix < 1 || c->tail_s < 0)
         return fail(ACIMG_EINVAL, "configure: negative / zero tuning value");
+    if (c->trunk_persistent < 0 || c->trunk_persistent > 2) return fail(ACIMG_EINVAL, "configure: trunk_persistent is 0, 1 or 2");
+    if (c->trunk_dma_pos < 0 || c->trunk_dma_pos > 1) return fail(ACIMG_EINVAL, "configure: trunk_dma_pos is 0 or 1");
+    if (c->trunk_stagger < 0 || c->trunk_stagger > 100) return fail(ACIMG_EINVAL, "configure: trunk_stagger is a percentage");
+    if (c->trunk_bk != 0 && c->trunk_bk != 32 && c->trunk_bk != 64)
+        return fail(ACIMG_EINVAL, "configure: trunk_bk must be 0 (per layer), 32 or 64");
     if (c->split3_tile_bm || c->split3_tile_bn) {
         const int bm = c->split3_tile_bm, bn = c->split3_tile_bn;
         if (!((bm == 128 && bn == 128) || (bm == 64 && bn == 128) || (bm == 128 && bn == 64)))
@@ -1482,11 +1487,22 @@ int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d) {
     return cdiv(M, pick_split3(M, d->K).bm);
 }
 
+// Persistent kernel or one tile per workgroup for the pre-split (trunk) forward conv (tools/trunk_shapes.py,
+// profiles/r02/trunk_shapes_*.txt): walking a tile list wins 2-9 % wherever there is at least one full round of whole
+// 128x128 tiles (most on short-K multi-round layers); when every tile belongs to the split tail (fewer tiles than
+// resident workgroups) the one-tile kernel's leaner code is 3-7 % faster.
+static bool split3p_persistent(const Split3Cfg& c, long tiles) {
+    if (c.bm != 128 || c.bn != 128) return false;
+    return g_cfg.trunk_persistent == 2 || (g_cfg.trunk_persistent == 1 && tiles >= 512);
+}
+
 int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out) {
     if (!d || !out) return fail(ACIMG_EINVAL, "conv2d_fwd_split3_tiling: null argument");
-    Split3Cfg c = pick_split3(d->N * d->OH * d->OW, d->K);
+    const int M = d->N * d->OH * d->OW;
+    Split3Cfg c = pick_split3(M, d->K);
     out[0] = c.bm;
     out[1] = c.bn;
+    out[2] = split3p_persistent(c, (long)cdiv(M, c.bm) * cdiv(d->K, c.bn)) ? 1 : 0;
     return ACIMG_OK;
 }
 
@@ -1640,7 +1656,7 @@ int acimg_conv2d_dgrad_split3(const AcimgConvDesc* d, const float* gy, int ldgy,
 // ---- tail split of the trunk kernel: which tiles to cut, and into how many K ranges ------------------------
 struct TailPlan { int whole, s, rem; };
 static int resident_slots(int which, const void* fn, int threads, size_t lds) {
-    static int cache[4] = {0, 0, 0, 0};
+    static int cache[5] = {0, 0, 0, 0, 0};
     if (!cache[which]) {
         int dev = 0, ncu = 0, per = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -1648,7 +1664,7 @@ static int resident_slots(int which, const void* fn, int threads, size_t lds) {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, threads, lds) != hipSuccess || ncu <= 0 || per <= 0) {
             (void)hipGetLastError();
             ncu = 256;                    // MI355X; no device (CPU-side sizing queries): same answer
-            per = (which == 0 || which == 3) ? 2 : 3;
+            per = which == 4 ? 1 : (which == 0 || which == 3) ? 2 : 3;
         }
         cache[which] = ncu * per;
     }
@@ -1680,6 +1696,19 @@ static TailPlan pick_tail(int T, int P, int KI, int max_units) {
 }
 static constexpr int TS_MAX_UNITS = 1024;      // partial slots (64 KiB each for a 128x128 tile)
 static constexpr size_t TS_COUNTER_BYTES = 4096;
+
+#ifdef ACIMG_STAMP
+static float* g_stamp_buf = nullptr;      // diagnostic build only (tools/build_stamp.sh): never in libacimg.so
+static int g_stamp_nostore = 0;           // ablation: the persistent kernel's output stores go out of range (dropped)
+extern "C" int acimg_debug_stamp_buffer(void* buf) {
+    g_stamp_buf = static_cast<float*>(buf);
+    return 0;
+}
+extern "C" int acimg_debug_no_output_stores(int on) {
+    g_stamp_nostore = on;
+    return 0;
+}
+#endif
 
 size_t acimg_conv2d_fwd_split3p_workspace(const AcimgConvDesc* d) {
     (void)d;
@@ -1728,11 +1757,17 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
                    : which == 1 ? (const void*)igemm_split3d_kernel<64, 128, 1, 4, 256, 2, 2>
                                 : (const void*)igemm_split3d_kernel<128, 64, 2, 2, 256, 2, 2>;
     if ((long)p.M * d->ldy * 4 >= (1L << 31)) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: output >= 2 GiB");
-    const bool persistent = which == 0 && g_cfg.trunk_persistent;
-    const size_t lds_p = 2 * 4 * 128 * 64 + 4 * 2 * 128 * 4;      // igemm_split3dp_kernel: 2 stages + statistics scratch
+    const bool persistent = split3p_persistent(c, T);
+    // K-step depth of the persistent kernel: 32 = the one-tile kernel's image (2 workgroups / CU); 64 = full 128-byte
+    // operand lines per DMA request, 1 workgroup / CU (measured slower on every trunk shape: experiments only)
+    const int bk = persistent && g_cfg.trunk_bk ? g_cfg.trunk_bk : 32;
+    if (persistent && bk == 64 && d->C % 64) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: trunk_bk 64 needs C %% 64 == 0");
+    p.kiters = p.ntaps * (d->C / bk);
+    const size_t lds_p = (size_t)2 * 4 * 128 * (bk * 2) + 4 * 2 * 128 * 4;    // 2 stages + statistics scratch
     TailPlan tp{T, 1, 0};
-    const int P = persistent ? resident_slots(3, (const void*)igemm_split3dp_kernel, 512, lds_p)
-                             : resident_slots(which, fn, which == 0 ? 512 : 256, lds_bytes);
+    const int P = !persistent ? resident_slots(which, fn, which == 0 ? 512 : 256, lds_bytes)
+                  : bk == 64  ? resident_slots(4, (const void*)igemm_split3dp_kernel<64, 0>, 512, lds_p)
+                              : resident_slots(3, (const void*)igemm_split3dp_kernel<32, 0>, 512, lds_p);
     if (ws && ws_bytes >= acimg_conv2d_fwd_split3p_workspace(d) && which == 0)
         tp = pick_tail(T, P, p.kiters, TS_MAX_UNITS);
     p.ts_whole = tp.whole; p.ts_s = tp.s;
@@ -1740,12 +1775,29 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
     p.ts_partial = ws ? reinterpret_cast<float*>(static_cast<char*>(ws) + TS_COUNTER_BYTES) : nullptr;
     const int n_units = tp.whole + tp.rem * tp.s;
     const dim3 grid(n_units);
+#ifdef ACIMG_STAMP
+    p.slab = g_stamp_buf;
+    p.flip = g_stamp_nostore;
+#endif
     if (persistent) {
+        p.splits = g_cfg.trunk_stagger > 0 ? g_cfg.trunk_stagger * (p.kiters * (bk == 64 ? 3400 : 2500) + 8000) / 100 : 1;
         // a workgroup per resident slot walks units blockIdx.x, blockIdx.x + P, ...: whole tiles first (with the
         // next tile's first operand stage and addresses prepared under the current tile's last K step and output
         // stores), then the K ranges of the tail tiles
         const int nwg = std::min(n_units, P);
-        hipLaunchKernelGGL(igemm_split3dp_kernel, dim3(nwg), dim3(512), lds_p, st, p, n_units, nwg);
+        if (bk == 64) {
+            static bool attr = false;    // > 64 KiB of dynamic LDS needs the opt-in once per process
+            if (!attr) {
+                (void)hipFuncSetAttribute((const void*)igemm_split3dp_kernel<64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds_p);
+                attr = true;
+            }
+            hipLaunchKernelGGL((igemm_split3dp_kernel<64, 0>), dim3(nwg), dim3(512), lds_p, st, p, n_units, nwg);
+        } else if (g_cfg.trunk_dma_pos == 1) {
+            hipLaunchKernelGGL((igemm_split3dp_kernel<32, 1>), dim3(nwg), dim3(512), lds_p, st, p, n_units, nwg);
+        } else {
+            hipLaunchKernelGGL((igemm_split3dp_kernel<32, 0>), dim3(nwg), dim3(512), lds_p, st, p, n_units, nwg);
+        }
     } else if (which == 0)
         hipLaunchKernelGGL((igemm_split3d_kernel<128, 128, 2, 4, 512, 2, 2>), grid, dim3(512), lds_bytes, st, p);
     else if (which == 1)

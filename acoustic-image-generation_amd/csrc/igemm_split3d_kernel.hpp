@@ -44,6 +44,16 @@ __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "add the immediate");
 }
 
+// sum over the 16 lanes of a DPP row (= the 16 pixel rows of an MFMA accumulator fragment), result in every lane:
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror - four v_add_f32 with a DPP operand, no LDS
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
 // linear workgroup id -> (row tile, column tile), see IgemmParams::ras_*
 __device__ __forceinline__ void raster_tile(const IgemmParams& p, int L, int& mt, int& nt) {
     const int T = p.ras_tiles_m * p.ras_tiles_n;
@@ -325,6 +335,31 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
         // accumulator-shaped writes and the row-shaped reads are bank-conflict free.
         constexpr int CH = BN / 4;
         f32x4* tile = reinterpret_cast<f32x4*>(smem);
+        float* red = smem + BM * BN;          // [WGM][2][BN] statistics partials of the wave rows
+        if (e.stats) {
+            // batch-norm partials straight from the accumulators (rows past M hold zeros): a lane adds its TM row
+            // blocks, a 16-lane DPP butterfly adds the 16 pixel rows of a fragment, the WGM wave rows meet in LDS -
+            // instead of every thread re-reading a column of the staged tile (BM / PARTS dependent LDS reads)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x4 s1 = acc[0][j], s2 = acc[0][j] * acc[0][j];
+#pragma unroll
+                for (int i = 1; i < TM; ++i) {
+                    s1 += acc[i][j];
+                    s2 += acc[i][j] * acc[i][j];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s1[k] = row16_sum(s1[k]);
+                    s2[k] = row16_sum(s2[k]);
+                }
+                if (li == 0) {
+                    const int n = wn * WTN + j * 16 + g * 4;
+                    *reinterpret_cast<f32x4*>(red + (wm * 2 + 0) * BN + n) = s1;
+                    *reinterpret_cast<f32x4*>(red + (wm * 2 + 1) * BN + n) = s2;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = wm * WTM + i * 16 + li;
@@ -335,43 +370,38 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
             }
         }
         __syncthreads();
+        constexpr int NIT = BM * CH / NTHR;
+        static_assert(BM * CH % NTHR == 0, "row store mapping");
 #pragma unroll
-        for (int t = tid; t < BM * CH; t += NTHR) {
-            const int row = t / CH, c = t - row * CH;
-            const int m = m0 + row, n = n0 + 4 * c;
-            if (m < e.M && n < e.Nstore) {
-                const f32x4 v = tile[row * CH + (c ^ (row & (CH - 1)))];
-                float* dst = e.Y + (long)m * e.ldy + n;
-                if (n + 3 < e.Nstore) *reinterpret_cast<f32x4*>(dst) = v;
-                else
-                    for (int k = 0; k < 4 && n + k < e.Nstore; ++k) dst[k] = v[k];
+        for (int t0 = 0; t0 < NIT; t0 += 4) {         // four row reads in flight before their stores
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = tid + (t0 + k) * NTHR;
+                const int row = t / CH, c = t - row * CH;
+                v[k] = tile[row * CH + (c ^ (row & (CH - 1)))];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = tid + (t0 + k) * NTHR;
+                const int row = t / CH, c = t - row * CH;
+                const int m = m0 + row, n = n0 + 4 * c;
+                if (m < e.M && n < e.Nstore) {
+                    float* dst = e.Y + (long)m * e.ldy + n;
+                    if (n + 3 < e.Nstore) *reinterpret_cast<f32x4*>(dst) = v[k];
+                    else
+                        for (int q = 0; q < 4 && n + q < e.Nstore; ++q) dst[q] = v[k][q];
+                }
             }
         }
         if (e.stats) {
-            // batch-norm partials of this row block: column sums / sums of squares straight from the staged tile
-            // (rows past M hold zeros), NTHR / BN row groups per column, combined in a fixed order
-            constexpr int PARTS = NTHR / BN, RPP = BM / PARTS;
-            static_assert(NTHR % BN == 0 && BM % PARTS == 0, "statistics mapping");
-            const int col = tid % BN, part = tid / BN;
-            const float* tf = smem;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
-            for (int r = part * RPP; r < (part + 1) * RPP; ++r) {
-                const float v = tf[(r * CH + ((col >> 2) ^ (r & (CH - 1)))) * 4 + (col & 3)];
-                s1 += v;
-                s2 += v * v;
-            }
-            float* red = smem + BM * BN;          // [PARTS][2][BN]
-            red[(part * 2 + 0) * BN + col] = s1;
-            red[(part * 2 + 1) * BN + col] = s2;
-            __syncthreads();
             for (int idx = tid; idx < 2 * BN; idx += NTHR) {
                 const int which = idx / BN, c = idx - which * BN;
                 const int n = n0 + c;
                 if (n < e.stats_ld) {
                     float sum = 0.f;
 #pragma unroll
-                    for (int w = 0; w < PARTS; ++w) sum += red[(w * 2 + which) * BN + c];
+                    for (int w = 0; w < WGM; ++w) sum += red[(w * 2 + which) * BN + c];
                     e.stats[((long)mt * 2 + which) * e.stats_ld + n] = sum;
                 }
             }

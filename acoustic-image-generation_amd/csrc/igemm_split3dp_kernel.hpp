@@ -17,50 +17,94 @@
 // Tiles of the last partial round are still cut into K ranges (tail split, unchanged protocol) and run after a
 // workgroup's whole tiles, without the overlap.
 //
-// LDS (68 KiB, 2 workgroups / CU): 2 stages x [A hi | A lo | B hi | B lo] x 8 KiB, then 4 KiB of statistics scratch.
+// Two K-step depths:
+//   BK = 32: the one-tile kernel's image (64-byte rows, 16 rows per 1-KiB DMA piece); 68 KiB of LDS, 2 workgroups / CU.
+//   BK = 64: FULL-LINE operand staging.  With 64-byte rows every DMA wave-instruction is sixteen 64-byte requests to
+//            the L2 (PMC, profiles/r01/pmc/dma: TCP_TCC_READ_REQ x 64 B = the operand bytes), and 64-byte requests use
+//            half of an L2 channel's 128 B/clk: at 2 x 32 KiB per K step and CU the K loop asks for ~22 TB/s of them,
+//            above what the L2 can serve that way, which is why the MFMA pipe is only ~53 % busy inside full rounds.
+//            Here a tile row holds 64 k-values = one whole 128-byte line per plane, a DMA piece is 8 rows x 128 B
+//            (lane l: row l >> 3, physical chunk l & 7, fetching logical chunk (l & 7) ^ (row & 7): conflict-free
+//            ds_read_b128 for the 16 rows of a fragment in the hardware's lane groups), a stage is 64 KiB
+//            (132 KiB of LDS, 1 workgroup / CU) and a K step is 48 MFMAs per wave between barriers.
+// LDS: 2 stages x [A hi | A lo | B hi | B lo], then 4 KiB of statistics scratch.
 #pragma once
 #include "igemm_split3d_kernel.hpp"
 
+// Diagnostic build only (tools/build_stamp.sh, -DACIMG_STAMP): every wave accumulates the shader cycles it spends in
+// each part of a K step and of the epilogue and leaves them in a debug buffer (cdna_hip_programming.md §7, in-kernel
+// stamps).  The product build contains none of this.
+#ifdef ACIMG_STAMP
+#define ACIMG_STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(); unsigned st_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_begin = st_last;
+#define ACIMG_STAMP_AT(i)                                              \
+    do {                                                               \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
+        st_acc[i] += (unsigned)(t_ - st_last);                         \
+        st_last = t_;                                                  \
+    } while (0)
+#else
+#define ACIMG_STAMP_DECL
+#define ACIMG_STAMP_AT(i)
+#endif
+
 namespace acimg {
 
+template <int PP>
 struct TileAddrP {
     int mt, nt;
-    int a_off, a_ih0, a_iw0;   // this lane's row of the A piece (one 16-row block per wave)
-    unsigned b_goff;           // this lane's row of the B piece, byte offset at k = 0 (or OOB)
+    int a_off[PP], a_ih0[PP], a_iw0[PP];   // this lane's row of each of the wave's A pieces
+    unsigned b_goff[PP];                   // this lane's row of each B piece, byte offset at k = 0 (or OOB)
 };
 
 struct KCursorP {
     int r, s, c0, q;           // tap row, tap column, first channel of the chunk, linear K step
 };
+template <int BK>
 __device__ __forceinline__ KCursorP kcursor_at(int step, int C, int S) {
     KCursorP k;
     k.q = step;
-    const int cpk = C / 32;
+    const int cpk = C / BK;
     const int tap = step / cpk;
-    k.c0 = (step - tap * cpk) * 32;
+    k.c0 = (step - tap * cpk) * BK;
     k.r = tap / S;
     k.s = tap - k.r * S;
     return k;
 }
+template <int BK>
 __device__ __forceinline__ KCursorP kcursor_next(KCursorP k, int C, int S) {
     KCursorP n;
     n.q = k.q + 1;
-    const bool wrap_c = k.c0 + 32 == C;
-    n.c0 = wrap_c ? 0 : k.c0 + 32;
+    const bool wrap_c = k.c0 + BK == C;
+    n.c0 = wrap_c ? 0 : k.c0 + BK;
     const bool wrap_s = wrap_c && k.s + 1 == S;
     n.s = wrap_c ? (wrap_s ? 0 : k.s + 1) : k.s;
     n.r = wrap_s ? k.r + 1 : k.r;
     return n;
 }
 
-__global__ __launch_bounds__(512, 4) void igemm_split3dp_kernel(const IgemmParams p, const int n_units, const int stride_units) {
-    constexpr int BM = 128, BN = 128, WGN = 4, NTHR = 512, BK = 32, ROWB = BK * 2;
-    constexpr int PLANE = BM * ROWB;                 // 8 KiB: one fp16 plane of one operand of one stage
+// DPOS: where a K step's DMA requests sit.  0: right after the step barrier, in one burst (all 8 waves of the workgroup
+// queue 4 KiB each at the CU's texture addresser at the same moment: the issuing waves stall ~200 cycles per request,
+// 30 % of a long-K layer's wave time - tools/stamp_probe.py - before any of them has an MFMA ready).  1: spread
+// under the MFMA block - the B pieces after the first of the three MFMA sweeps, the A pieces after the second - so a
+// wave that waits at the addresser has already queued matrix work and the others keep the pipe busy.
+template <int BK, int DPOS>
+__global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(const IgemmParams p, const int n_units,
+                                                                               const int stride_units) {
+    constexpr int BM = 128, BN = 128, WGN = 4, NTHR = 512, NW = 8, ROWB = BK * 2;
+    constexpr int PLANE = BM * ROWB;                 // one fp16 plane of one operand of one stage (8 / 16 KiB)
     constexpr int STAGE = 4 * PLANE;                 // [A hi | A lo | B hi | B lo]
     constexpr int WTM = 64, WTN = 32, TM = 4, TN = 2;
     constexpr int CH = BN / 4;                       // 16-byte chunks per output row
-    constexpr int NST = 2 * (BM / 2 * CH / NTHR) + 1;   // vector-memory stores a wave issues per tile epilogue (8 + 1)
-    static_assert(BM / 2 * CH % NTHR == 0, "half-tile store mapping");
+    constexpr int CPR = ROWB / 16;                   // 16-byte chunks per operand row (4 / 8)
+    constexpr int RPI = 64 / CPR;                    // operand rows per DMA wave-instruction (16 / 8)
+    constexpr int PP = BM / RPI / NW;                // pieces per plane and wave (1 / 2)
+    constexpr int KH = BK / 32;                      // 32-deep MFMA sweeps per K step
+    constexpr int HALVES = BM * BN * 4 / STAGE;      // the output tile leaves through one stage: in 2 / 1 passes
+    constexpr int RH = BM / HALVES;                  // tile rows per pass
+    constexpr int WH = WTM / HALVES;                 // ... of which per wave row
+    constexpr int NST = HALVES * (RH * CH / NTHR) + 1;  // vector-memory stores a wave issues per tile epilogue (8 + 1)
+    static_assert(RH * CH % NTHR == 0 && NST == 9, "output store mapping");
+    typedef TileAddrP<PP> Tile;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
@@ -70,9 +114,10 @@ __global__ __launch_bounds__(512, 4) void igemm_split3dp_kernel(const IgemmParam
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
     const int li = lane & 15, g = lane >> 4;
-    const int prow = lane >> 2, pch = lane & 3;
-    const int prow_t = wid * 16 + prow;              // tile row this lane fetches (A and B pieces alike)
-    const int kc_sw = pch ^ swz(prow_t);
+    const int prow = lane / CPR, pch = lane % CPR;  // this lane's row / physical chunk inside a DMA piece
+    // logical k chunk this lane fetches: the swizzle of its tile row, which depends on prow only (pieces start at
+    // multiples of 16 / 8 rows)
+    const int kc_sw = pch ^ (BK == 32 ? swz(prow) : (prow & 7));
     const int Ktot = p.ntaps * p.C;
     const int ohw = p.OH * p.OW;
     const unsigned b_lo_off = (unsigned)((long)p.Nld * Ktot * 2);
@@ -83,50 +128,70 @@ __global__ __launch_bounds__(512, 4) void igemm_split3dp_kernel(const IgemmParam
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
     const EpiParams& e = p.e;
 
-    auto setup = [&](int vt) -> TileAddrP {
-        TileAddrP t;
+    auto setup = [&](int vt) -> Tile {
+        Tile t;
         int mt_, nt_;
         raster_tile(p, vt, mt_, nt_);
         t.mt = mt_;
         t.nt = nt_;
-        const int m = t.mt * BM + prow_t;
-        if (m < p.M) {
-            const int img = m / ohw;
-            const int r2 = m - img * ohw;
-            const int oh = r2 / p.OW;
-            const int ow = r2 - oh * p.OW;
-            t.a_ih0 = oh * p.stride - p.pad_t;
-            t.a_iw0 = ow * p.stride - p.pad_l;
-            t.a_off = ((img * p.H + t.a_ih0) * p.W + t.a_iw0) * p.lda * 2 + kc_sw * 16;
-        } else {
-            t.a_ih0 = -(1 << 28);
-            t.a_iw0 = -(1 << 28);
-            t.a_off = 0;
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const int row = (wid + j * NW) * RPI + prow;
+            const int m = t.mt * BM + row;
+            if (m < p.M) {
+                const int img = m / ohw;
+                const int r2 = m - img * ohw;
+                const int oh = r2 / p.OW;
+                const int ow = r2 - oh * p.OW;
+                t.a_ih0[j] = oh * p.stride - p.pad_t;
+                t.a_iw0[j] = ow * p.stride - p.pad_l;
+                t.a_off[j] = ((img * p.H + t.a_ih0[j]) * p.W + t.a_iw0[j]) * p.lda * 2 + kc_sw * 16;
+            } else {
+                t.a_ih0[j] = -(1 << 28);
+                t.a_iw0[j] = -(1 << 28);
+                t.a_off[j] = 0;
+            }
+            const int n = t.nt * BN + row;
+            t.b_goff[j] = n < p.Nld ? (unsigned)(((long)n * Ktot + kc_sw * 8) * 2) : OOB;
         }
-        const int n = t.nt * BN + prow_t;
-        t.b_goff = n < p.Nld ? (unsigned)(((long)n * Ktot + kc_sw * 8) * 2) : OOB;
         return t;
     };
 
     // K cursor of the tile being requested: tap (row, column), channel chunk, linear step
     KCursorP kc{0, 0, 0, 0};
     // request K step `kc.q` of tile t into stage `slot` (B pieces before A pieces, 4 DMA instructions per wave)
-    auto issue = [&](const TileAddrP& t, int slot) {
-        char* st = lds + slot * STAGE + wid * 1024;
+    auto issue_b = [&](const Tile& t, int slot) {
+        char* st = lds + slot * STAGE;
         const unsigned kbyte = (unsigned)(kc.q * (BK * 2));
-        const unsigned boff = t.b_goff == OOB ? OOB : t.b_goff + kbyte;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(st + 2 * PLANE), 16, boff, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(st + 3 * PLANE), 16, boff, (int)b_lo_off, 0, 0);
-        const int tapoff = ((kc.r * p.W + kc.s) * p.lda + kc.c0) * 2;
-        const int ih = t.a_ih0 + kc.r, iw = t.a_iw0 + kc.s;
-        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        const unsigned aoff = ok ? (unsigned)(t.a_off + tapoff) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)st, 16, aoff, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(st + PLANE), 16, aoff, (int)p.a_lo_off, 0, 0);
-        kc = kcursor_next(kc, p.C, p.S);
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const unsigned boff = t.b_goff[j] == OOB ? OOB : t.b_goff[j] + kbyte;
+            char* dst = st + 2 * PLANE + (wid + j * NW) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)dst, 16, boff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + PLANE), 16, boff, (int)b_lo_off, 0, 0);
+        }
     };
-    auto cursor_set = [&](int step) { kc = kcursor_at(step, p.C, p.S); };
+    auto issue_a = [&](const Tile& t, int slot) {      // ... and moves the cursor on
+        char* st = lds + slot * STAGE;
+        const int tapoff = ((kc.r * p.W + kc.s) * p.lda + kc.c0) * 2;
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const int ih = t.a_ih0[j] + kc.r, iw = t.a_iw0[j] + kc.s;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const unsigned aoff = ok ? (unsigned)(t.a_off[j] + tapoff) : OOB;
+            char* dst = st + (wid + j * NW) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, aoff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + PLANE), 16, aoff, (int)p.a_lo_off, 0, 0);
+        }
+        kc = kcursor_next<BK>(kc, p.C, p.S);
+    };
+    auto issue = [&](const Tile& t, int slot) {
+        issue_b(t, slot);
+        issue_a(t, slot);
+    };
+    auto cursor_set = [&](int step) { kc = kcursor_at<BK>(step, p.C, p.S); };
 
+    ACIMG_STAMP_DECL
     f32x4 acc[TM][TN];
     auto zero_acc = [&]() {
 #pragma unroll
@@ -136,46 +201,72 @@ __global__ __launch_bounds__(512, 4) void igemm_split3dp_kernel(const IgemmParam
     };
     zero_acc();
 
-    auto compute = [&](int slot) {
+    // `req` (DPOS 1): whose next K step (cursor kc) this step requests into the other stage: 0 nobody, 1 `a`, 2 `b`
+    auto compute = [&](int slot, int req, const Tile& ta, const Tile& tb) {
         const char* sta = lds + slot * STAGE;
         const char* stb = sta + 2 * PLANE;
-        h16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = wm * WTM + i * 16 + li;
-            const int off = row * ROWB + ((g ^ swz(row)) << 4);
-            ah[i] = *reinterpret_cast<const h16x8*>(sta + off);
-            al[i] = *reinterpret_cast<const h16x8*>(sta + PLANE + off);
+        for (int kh = 0; kh < KH; ++kh) {
+            h16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * WTM + i * 16 + li;
+                const int off = row * ROWB + (((kh * 4 + g) ^ (BK == 32 ? swz(row) : (row & 7))) << 4);
+                ah[i] = *reinterpret_cast<const h16x8*>(sta + off);
+                al[i] = *reinterpret_cast<const h16x8*>(sta + PLANE + off);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * WTN + j * 16 + li;
+                const int off = row * ROWB + (((kh * 4 + g) ^ (BK == 32 ? swz(row) : (row & 7))) << 4);
+                bh[j] = *reinterpret_cast<const h16x8*>(stb + off);
+                bl[j] = *reinterpret_cast<const h16x8*>(stb + PLANE + off);
+            }
+            if (BK == 32) __builtin_amdgcn_sched_barrier(0);
+#ifdef ACIMG_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ACIMG_STAMP_AT(3);
+#endif
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            if (DPOS == 1 && kh == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (req == 1) issue_b(ta, slot ^ 1);
+                else if (req == 2) issue_b(tb, slot ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            if (DPOS == 1 && kh == 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (req == 1) issue_a(ta, slot ^ 1);
+                else if (req == 2) issue_a(tb, slot ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+            ACIMG_STAMP_AT(4);
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int row = wn * WTN + j * 16 + li;
-            const int off = row * ROWB + ((g ^ swz(row)) << 4);
-            bh[j] = *reinterpret_cast<const h16x8*>(stb + off);
-            bl[j] = *reinterpret_cast<const h16x8*>(stb + PLANE + off);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
     };
 
-    // Output tile through ONE stage buffer (32 KiB = 64 rows x 128 fp32), two halves: half h holds the accumulator
-    // rows i = 2h, 2h+1 of both wave rows, i.e. tile row (lr / 32) * 64 + h * 32 + lr % 32 at local row lr.  Image:
+    // Output tile through ONE stage buffer, in HALVES passes of RH tile rows (BK = 32: two passes of 64 rows through
+    // 32 KiB; BK = 64: the whole tile through 64 KiB): pass h holds the accumulator rows i in [h TM / HALVES,
+    // (h + 1) TM / HALVES) of both wave rows, i.e. tile row (lr / WH) * 64 + h * WH + lr % WH at local row lr.  Image:
     // 16-byte chunk c of local row lr at chunk c ^ (lr & 31): accumulator-shaped writes and row-shaped reads are both
     // conflict free.  Exactly NST vector-memory instructions per wave (out-of-range offsets instead of branches).
+    // Batch-norm partials come straight from the accumulators: a lane adds its 4 row blocks, a 16-lane DPP butterfly
+    // adds the 16 pixel rows of a fragment (the lanes of a DPP row ARE the pixel rows of the MFMA layout), and the two
+    // wave rows meet through 2 KiB of LDS - instead of every thread re-reading a column of the staged tile (32
+    // dependent-latency LDS reads per thread: 14-17 % of a short-K tile's time, tools/stamp_probe.py).
     auto epilogue = [&](const int mt, const int nt, int slot) {
         const __amdgpu_buffer_rsrc_t rsY =
             __builtin_amdgcn_make_buffer_rsrc(e.Y, 0, (unsigned)((long)e.M * e.ldy * 4), 0x00020000);
@@ -189,100 +280,142 @@ __global__ __launch_bounds__(512, 4) void igemm_split3dp_kernel(const IgemmParam
         asm volatile("" : "+v"(te));
         const int e_lane = te & 63, e_wid = te >> 6;
         const int e_wm = e_wid / WGN, e_wn = e_wid % WGN, e_li = e_lane & 15, e_g = e_lane >> 4;
-        const int col = te % BN, part = te / BN;        // statistics: 4 row groups per column
-        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int lr = e_wm * 32 + ii * 16 + e_li;
+            for (int j = 0; j < TN; ++j) acc[i][j] *= SPLIT3_OUTSCALE;
+        if (e.stats) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x4 s1 = acc[0][j], s2 = acc[0][j] * acc[0][j];
+#pragma unroll
+                for (int i = 1; i < TM; ++i) {
+                    s1 += acc[i][j];
+                    s2 += acc[i][j] * acc[i][j];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s1[k] = row16_sum(s1[k]);
+                    s2[k] = row16_sum(s2[k]);
+                }
+                if (e_li == 0) {     // rows past M hold exact zeros (their A pieces were out of range): they add nothing
+                    const int n = e_wn * WTN + j * 16 + e_g * 4;
+                    *reinterpret_cast<f32x4*>(red + (e_wm * 2 + 0) * BN + n) = s1;
+                    *reinterpret_cast<f32x4*>(red + (e_wm * 2 + 1) * BN + n) = s2;
+                }
+            }
+        }
+        ACIMG_STAMP_AT(12);                         // statistics from the accumulators
+#pragma unroll
+        for (int h = 0; h < HALVES; ++h) {
+#pragma unroll
+            for (int ii = 0; ii < TM / HALVES; ++ii) {
+                const int lr = e_wm * WH + ii * 16 + e_li;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int c = (e_wn * WTN + j * 16) / 4 + e_g;
-                    tile[lr * CH + (c ^ (lr & (CH - 1)))] = acc[2 * h + ii][j] * SPLIT3_OUTSCALE;
+                    tile[lr * CH + (c ^ (lr & (CH - 1)))] = acc[h * (TM / HALVES) + ii][j];
                 }
             }
+            ACIMG_STAMP_AT(8);                      // tile -> LDS writes issued
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ACIMG_STAMP_AT(9);                      // ... and completed
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            ACIMG_STAMP_AT(10);                     // barrier
+            f32x4 v[RH * CH / NTHR];
+            unsigned off[RH * CH / NTHR];
 #pragma unroll
-            for (int k = 0; k < BM / 2 * CH / NTHR; ++k) {
+            for (int k = 0; k < RH * CH / NTHR; ++k) {      // all row reads in flight before the first store
                 const int tt = te + k * NTHR;
                 const int lr = tt / CH, c = tt - lr * CH;
-                const int m = m0 + (lr >> 5) * 64 + h * 32 + (lr & 31), n = n0 + 4 * c;
-                const f32x4 v = tile[lr * CH + (c ^ (lr & (CH - 1)))];
-                const unsigned off = (m < e.M && n < e.Nstore) ? (unsigned)(((long)m * e.ldy + n) * 4) : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsY, off, 0, 0);
+                const int m = m0 + (lr / WH) * WTM + h * WH + (lr % WH), n = n0 + 4 * c;
+                v[k] = tile[lr * CH + (c ^ (lr & (CH - 1)))];
+#ifdef ACIMG_STAMP
+                off[k] = (p.flip == 0 && m < e.M && n < e.Nstore) ? (unsigned)(((long)m * e.ldy + n) * 4) : OOB;
+#else
+                off[k] = (m < e.M && n < e.Nstore) ? (unsigned)(((long)m * e.ldy + n) * 4) : OOB;
+#endif
             }
-            if (e.stats) {
-                // rows past M hold exact zeros (their A pieces were out of range): they add nothing
-                const float* tf = reinterpret_cast<const float*>(tile);
-#pragma unroll 8
-                for (int r = part * 16; r < part * 16 + 16; ++r) {
-                    const float v = tf[(r * CH + ((col >> 2) ^ (r & (CH - 1)))) * 4 + (col & 3)];
-                    s1 += v;
-                    s2 += v * v;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-        float sum = 0.f;
-        const int which = part & 1;
-        if (e.stats) {
-            red[(part * 2 + 0) * BN + col] = s1;
-            red[(part * 2 + 1) * BN + col] = s2;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
 #pragma unroll
-            for (int w = 0; w < 4; ++w) sum += red[(w * 2 + which) * BN + col];
+            for (int k = 0; k < RH * CH / NTHR; ++k)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[k]), rsY, off[k], 0, 0);
+            ACIMG_STAMP_AT(11);                     // row reads + output stores issued
+            if (h + 1 < HALVES) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();       // everyone has read this pass before the next one overwrites it
+                asm volatile("" ::: "memory");
+                ACIMG_STAMP_AT(13);                 // barrier
+            }
         }
+        // the two wave rows' partials (written before the first barrier above) -> this row block's statistics row
+        const int which = (te / BN) & 1, col = te % BN;
+        float sum = 0.f;
+        if (e.stats) sum = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col];
         {
             const int n = n0 + col;
-            const unsigned off = (e.stats && te < 2 * BN && n < e.stats_ld)
-                                     ? (unsigned)((((long)mt * 2 + which) * e.stats_ld + n) * 4) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), rsS, off, 0, 0);
+            const unsigned soff = (e.stats && te < 2 * BN && n < e.stats_ld)
+                                      ? (unsigned)((((long)mt * 2 + which) * e.stats_ld + n) * 4) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), rsS, soff, 0, 0);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
     // ================= whole tiles: units [0, ts_whole), this workgroup takes blockIdx.x + k * stride ============
     const int n_whole = p.ts_s > 1 ? p.ts_whole : n_units;
     int unit = blockIdx.x;
     int slot = 0;
+    if (p.splits > 1 && (int)blockIdx.x >= (stride_units >> 1)) {
+        // Stagger (p.splits = shader cycles): the second half of the grid - the workgroups that share a CU with one
+        // of the first half under in-order dispatch - starts late, so that the two co-resident workgroups are in
+        // different phases of a tile (one multiplies while the other stores) instead of in lockstep.  Pure timing:
+        // any placement gives the same results.
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.splits) __builtin_amdgcn_s_sleep(16);
+    }
     if (unit < n_whole) {
-        TileAddrP cur = setup(unit);
+        Tile cur = setup(unit);
         kc = KCursorP{0, 0, 0, 0};
         issue(cur, 0);
         bool pend = false;              // epilogue stores of the previous tile are younger than this tile's first DMA
         for (;;) {
             const int next = unit + stride_units;
             const bool has_next = next < n_whole;
-            TileAddrP nxt = cur;
+            Tile nxt = cur;
             for (int it = 0; it < p.kiters; ++it) {
                 // the next tile's addresses (integer divisions) are worked out right before the last K step, while
                 // this wave would only be waiting for that step's pieces
                 if (it + 1 == p.kiters && has_next) nxt = setup(next);
+                ACIMG_STAMP_AT(7);                  // everything not itemised below (setup, loop control)
                 if (it == 0 && pend) wait_vmcnt<NST>();
                 else wait_vmcnt<0>();
+                ACIMG_STAMP_AT(0);                  // own DMA pieces landed
                 __builtin_amdgcn_s_barrier();       // everyone's pieces of step `it` landed; everyone left step it-1
+                ACIMG_STAMP_AT(1);                  // barrier
+                int req = 0;
                 if (it + 1 < p.kiters) {
-                    issue(cur, slot ^ 1);
+                    req = 1;
                 } else if (has_next) {
                     kc = KCursorP{0, 0, 0, 0};
-                    issue(nxt, slot ^ 1);
+                    req = 2;
                 }
+                if (DPOS == 0) {
+                    if (req == 1) issue(cur, slot ^ 1);
+                    else if (req == 2) issue(nxt, slot ^ 1);
+                }
+                ACIMG_STAMP_AT(2);                  // DMA issue
                 __builtin_amdgcn_s_setprio(1);
-                compute(slot);
+                compute(slot, DPOS == 0 ? 0 : req, cur, nxt);
                 __builtin_amdgcn_s_setprio(0);
                 slot ^= 1;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();           // everyone has read the last stage: it becomes the output buffer
             asm volatile("" ::: "memory");
+            ACIMG_STAMP_AT(5);                      // end-of-tile barrier
             epilogue(cur.mt, cur.nt, slot ^ 1);
             zero_acc();
+            ACIMG_STAMP_AT(6);                      // epilogue
             pend = true;
             if (!has_next) break;
             cur = nxt;
@@ -291,6 +424,15 @@ __global__ __launch_bounds__(512, 4) void igemm_split3dp_kernel(const IgemmParam
         unit += stride_units;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+#ifdef ACIMG_STAMP
+    if (p.slab && lane == 0) {
+        unsigned* dbg = reinterpret_cast<unsigned*>(p.slab) + ((long)blockIdx.x * NW + wid) * 16;
+#pragma unroll
+        for (int i = 0; i < 14; ++i) dbg[i] = st_acc[i];
+        dbg[14] = (unsigned)(__builtin_amdgcn_s_memtime() - st_begin);
+        dbg[15] = (unsigned)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+    }
+#endif
     // ================= tail: K ranges of the tiles of the last partial round (no overlap) =========================
     if (p.ts_s <= 1) return;
     while (unit < n_whole) unit += stride_units;
@@ -302,7 +444,7 @@ __global__ __launch_bounds__(512, 4) void igemm_split3dp_kernel(const IgemmParam
         const int base = p.kiters / p.ts_s, extra = p.kiters - base * p.ts_s;
         const int it_begin = chunk * base + min(chunk, extra);
         const int it_end = it_begin + base + (chunk < extra ? 1 : 0);
-        const TileAddrP cur = setup(vt);
+        const Tile cur = setup(vt);
         __builtin_amdgcn_s_barrier();               // nobody still reads LDS from the previous unit
         cursor_set(it_begin);
         slot = 0;
@@ -312,7 +454,7 @@ __global__ __launch_bounds__(512, 4) void igemm_split3dp_kernel(const IgemmParam
             __builtin_amdgcn_s_barrier();
             if (it + 1 < it_end) issue(cur, slot ^ 1);
             __builtin_amdgcn_s_setprio(1);
-            compute(slot);
+            compute(slot, 0, cur, cur);
             __builtin_amdgcn_s_setprio(0);
             slot ^= 1;
         }

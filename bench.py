@@ -349,8 +349,12 @@ def main():
         d = g.plan_train.calls[i][2][0]._obj
         alg_bytes[i] = 4.0 * (d.N * d.H * d.W * d.C + d.K * d.R * d.S * d.C + d.N * d.OH * d.OW * d.K)
     TILE_THREADS = {(128, 128): "2,4,512", (64, 128): "1,4,256", (128, 64): "2,2,256"}
-    kernel_name = ("igemm_split3d_kernel<%d,%d,%s,2,2>" % (tile[0], tile[1], TILE_THREADS[tile[:2]]) if f16
-                   else "igemm_f32_kernel<%d,%d,...,false,true>" % (tile[0], tile[1]))
+    if not f16:
+        kernel_name = "igemm_f32_kernel<%d,%d,...,false,true>" % (tile[0], tile[1])
+    elif len(tile) > 2 and tile[2]:
+        kernel_name = "igemm_split3dp_kernel<32, 0>"       # the persistent form of the 128x128 trunk kernel
+    else:
+        kernel_name = "igemm_split3d_kernel<%d,%d,%s,2,2>" % (tile[0], tile[1], TILE_THREADS[tile[:2]])
     def one_step(probe=None):
         if strong:
             tr.train_step_sharded(shards, probe=probe)

@@ -11,7 +11,7 @@
  *     nothing is thrown across the boundary;
  *   - the CALLER owns every buffer (device pointers, 16-byte aligned), including workspace and the
  *     ticket words of the in-kernel reductions (explicit `tickets` / scratch arguments); the library
- *     allocates nothing.  Its only process-wide state is the tuning record of acimg_configure() (ten
+ *     allocates nothing.  Its only process-wide state is the tuning record of acimg_configure() (thirteen
  *     plain ints with compiled-in defaults, written by that call alone, never by a launch, and never
  *     read from the process environment) and the per-thread text of acimg_last_error();
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*), no host sync;
@@ -99,8 +99,15 @@ typedef struct AcimgConfig {
     int32_t split3_tile_bn;  /*     128x64 */
     int32_t tail_split;      /* 1: trunk kernel cuts the tiles of the last partial round into K ranges */
     int32_t tail_s;          /* 0 = cost model; else force that many K ranges (experiments) */
-    int32_t trunk_persistent;/* 1: 128x128 trunk convs on the persistent kernel (a workgroup walks a tile list, the next
-                                tile's first loads and the output stores overlap the matrix work); 0: one tile per workgroup */
+    int32_t trunk_persistent;/* 128x128 trunk convs on the persistent kernel (a workgroup walks a tile list; the next tile's
+                                first loads overlap the current tile's last K step and output stores): 0 never, 1 where it
+                                was measured to pay (short-K, multi-round layers), 2 always */
+    int32_t trunk_bk;        /* K-step depth of the persistent kernel: 0 / 32 = 64-byte operand rows, 2 workgroups / CU;
+                                64 = whole 128-byte lines, 1 workgroup / CU (experiments) */
+    int32_t trunk_stagger;   /* persistent kernel: start the second half of the grid this many percent of a tile's
+                                estimated time late (0 = together) */
+    int32_t trunk_dma_pos;   /* persistent kernel: a K step's operand requests 0 = in one burst after the step barrier,
+                                1 = spread under the MFMA block (B after the first sweep, A after the second) */
 } AcimgConfig;
 int acimg_config_default(AcimgConfig* cfg);
 int acimg_configure(const AcimgConfig* cfg);
@@ -128,7 +135,8 @@ int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* ws
 int acimg_conv2d_split3_prepare_multi(int n, const AcimgConvDesc* const* descs, const float* const* w, void* const* out,
                                       const int* mode, void* stream);
 int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d);
-int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out /* {BM, BN} */);
+/* out[3] = {BM, BN, 1 if acimg_conv2d_fwd_split3p runs this shape on the persistent kernel} */
+int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out);
 int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* wsplit, const float* bias,
                             float* y, const float* in_scale, const float* in_shift, int in_relu, float* stats,
                             void* stream);

@@ -958,3 +958,57 @@ def test_deconv_dgrad_few_channels_direct(device):
     ops.deconv_dgrad(plan, d, dev(gy, device), K, dev(w.detach(), device), dx)
     torch.cuda.synchronize()
     close(dx, x.grad, what="deconv dgrad (direct)")
+
+
+@pytest.mark.parametrize("case", [(32, 28, 38, 256, 1024, 1, 1, 1, "SAME"),     # 2128 tiles of 8 K steps: 4 whole rounds + a split tail
+                                  (8, 56, 75, 128, 128, 3, 3, 1, "SAME"),       # 263 tiles < resident slots: every tile is split
+                                  (5, 28, 38, 512, 256, 1, 1, 1, "SAME"),       # M = 5320: a row tail inside the last row tile
+                                  (32, 56, 75, 64, 256, 1, 1, 1, "SAME")])      # 2 K steps per tile
+def test_trunk_kernel_variants_agree(device, case):
+    """The trunk forward conv in its three forms — one tile per workgroup, persistent (a workgroup walks a tile list;
+    the next tile's first operand stage is requested under the current tile's last K step, output stores drain under
+    the next tile's MFMAs: counted vmcnt), persistent with 128-byte operand rows — against fp64 and against each
+    other: whole tiles bit-identical between the BK = 32 forms, tickets back at zero, statistics equal to rounding."""
+    from acimg import _lib, ops
+
+    N, H, W, Cc, K, R, S, stride, padding = case
+    g = torch.Generator().manual_seed(5 + Cc + K)
+    x = torch.rand(N, H, W, Cc, generator=g)
+    w = torch.randn(R, S, Cc, K, generator=g) * (2.0 / (R * S * Cc)) ** 0.5
+    d = ops.conv_desc(N, H, W, Cc, K, R, S, stride, padding)
+    rows = N * H * W
+    lo_off = -(-rows * Cc * 2 // 256) * 256
+    planes = torch.zeros(lo_off * 2, dtype=torch.uint8, device=device)
+    plan = ops.Plan(device, eager=True)
+    one, zero = torch.ones(Cc, device=device), torch.zeros(Cc, device=device)
+    ops.bn_relu_split(plan, x.to(device), one, zero, 1, planes, lo_off, rows, Cc)
+    wsplit = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=device)
+    ops.conv2d_split3_prepare(plan, d, w.to(device), wsplit)
+    srows = ops.conv2d_fwd_split3_stats_rows(d)
+    tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=device)
+    outs = {}
+    try:
+        for name, cfg in (("one-tile", dict(trunk_persistent=0)), ("persistent", dict(trunk_persistent=2)),
+                          ("staggered", dict(trunk_persistent=2, trunk_stagger=50)),
+                          ("bk64", dict(trunk_persistent=2, trunk_bk=64)), ("auto", dict())):
+            _lib.configure(**cfg)
+            y = torch.full((N, d.OH, d.OW, K), float("nan"), device=device)
+            st = torch.full((srows, 2, K), float("nan"), device=device)
+            for _ in range(2):                        # twice: tickets and stage state must be reusable
+                ops.conv2d_fwd_split3p(plan, d, planes, lo_off, wsplit, y, st, tail_ws=tws)
+            torch.cuda.synchronize()
+            assert int(tws[:4096].view(torch.int32).abs().sum()) == 0, name
+            outs[name] = (y, st)
+    finally:
+        _lib.configure()
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1),
+                                     padding=(R // 2, S // 2)).permute(0, 2, 3, 1)
+    for name, (y, st) in outs.items():
+        close(y, ref, tol=2e-6, what="trunk conv %s %s" % (name, case))
+        flat = ref.reshape(-1, K)
+        close(st[:, 0].sum(0), flat.sum(0), tol=2e-4, what="stats sum " + name)
+        close(st[:, 1].sum(0), (flat * flat).sum(0), tol=2e-4, what="stats sumsq " + name)
+    y0 = outs["one-tile"][0]
+    for name in ("persistent", "staggered", "auto"):   # same K ranges, same MFMA order: the same bits
+        assert torch.equal(outs[name][0], y0), name
+    assert float((outs["bk64"][0] - y0).abs().max()) <= 4e-6 * float(y0.abs().max())
