@@ -356,11 +356,13 @@ def conv2d_fwd_split3p_workspace(d):
     return int(_L().acimg_conv2d_fwd_split3p_workspace(C.byref(d)))
 
 
-def conv2d_fwd_split3p(plan, d, x_planes, x_lo_off, wsplit, y, stats=None, tail_ws=None):
-    """tail_ws: a uint8 buffer DEDICATED to split3p calls (tickets in its first 4 KiB must start, and stay, zero)"""
+def conv2d_fwd_split3p(plan, d, x_planes, x_lo_off, wsplit, y, stats=None, tail_ws=None, terms=3):
+    """tail_ws: a uint8 buffer DEDICATED to split3p calls (tickets in its first 4 KiB must start, and stay, zero);
+    terms = 1: fp16 operand storage (acimg_conv2d_fwd_split1p: hi planes only)"""
     nbytes = 0 if tail_ws is None else (tail_ws.numel() * tail_ws.element_size() if hasattr(tail_ws, "numel") else 0)
-    plan.add("conv2d_fwd_split3p", _L().acimg_conv2d_fwd_split3p, C.byref(d), x_planes, int(x_lo_off), wsplit, y,
-             stats, tail_ws, int(nbytes))
+    fn = _L().acimg_conv2d_fwd_split3p if terms == 3 else _L().acimg_conv2d_fwd_split1p
+    plan.add("conv2d_fwd_split3p" if terms == 3 else "conv2d_fwd_split1p", fn, C.byref(d), x_planes, int(x_lo_off),
+             wsplit, y, stats, tail_ws, int(nbytes))
 
 
 def bn_relu_split(plan, x, scale, shift, relu, out, lo_off, rows, Cn):

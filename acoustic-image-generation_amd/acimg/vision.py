@@ -34,11 +34,16 @@ class ResNet50Model(object):
 
     def __init__(self, input_shape=None, num_classes=None, precision="f16x3"):
         """precision: arithmetic of the frozen trunk convs — "f16x3" (split-fp16 MFMA, fp32-class
-        results, default) or "f32" (exact-f32 MFMA).  With "f16x3" the stem runs as a row-run conv and conv_map as a
-        tap GEMM on the same split-MFMA kernels (_stem_bn, _conv_map_tap)."""
+        results, default), "f32" (exact-f32 MFMA) or "f16" (fp16 OPERAND STORAGE: the same data path, but the 52 trunk
+        convs fetch and multiply only the hi fp16 plane of activations and weights — one MFMA per product, fp32
+        accumulation, fp32 batch-norm statistics; BASELINE configs[4]'s "fp16 with fp32 loss accumulation").  With
+        "f16x3" / "f16" the stem runs as a row-run conv and conv_map as a tap GEMM on the split-MFMA kernels
+        (_stem_bn, _conv_map_tap; those two layers keep the three-term product)."""
         self.scope = 'resnet_v1_50'
-        assert precision in ("f16x3", "f32")
+        assert precision in ("f16x3", "f32", "f16")
         self.precision = precision
+        self._split = precision in ("f16x3", "f16")
+        self._terms = 1 if precision == "f16" else 3
         self.num_classes = num_classes
         self.height = input_shape[0]
         self.width = input_shape[1]
@@ -161,7 +166,7 @@ class ResNet50Model(object):
         self.arena_r2 = z(mx_r2)
         self.arena_r3 = z(mx_r3)
         self.arena_sc = z(mx_r3)
-        if self.precision == "f16x3":
+        if self._split:
             # split-format arenas (two fp16 planes per tensor = the bytes of the fp32 tensor)
             u8 = lambda n: torch.zeros(int(n), dtype=torch.uint8, device=sess.device)  # noqa: E731
             self.planes_a, self.planes_b = u8(4 * mx_io + 512), u8(4 * mx_io + 512)
@@ -179,7 +184,7 @@ class ResNet50Model(object):
         self.g_raw_cm = z(N, fh, fw, 12)
         self.stats = None
         self._stats_need = 0
-        if self.precision == "f16x3":
+        if self._split:
             # stem as a row-run conv on the split-MFMA kernel: zero-padded 4-channel frame (+ slack for the last run),
             # kernel re-laid as [7][32 = 7 pixels x 4 channels + 4 zero rows][64]
             self.stem_frame = z(N * (H + 6) * (W + 6) * 4 + 64)
@@ -251,7 +256,7 @@ class ResNet50Model(object):
         """host hook at the head of the forward plans: re-split the frozen kernels iff they changed"""
         st = self.session.store
         if self._sp3_bytes and self._sp3_version != st.version:
-            if self.precision == "f16x3":      # [7][7][4][64] -> [7][28 of 32][64] (parameter plumbing, load time only)
+            if self._split:      # [7][7][4][64] -> [7][28 of 32][64] (parameter plumbing, load time only)
                 self.stem_w.view(7, 32, 64)[:, :28].copy_(st.p(self.scope + "/conv1/weights").reshape(7, 28, 64))
             self.plan_prepare.run()
             self._sp3_version = st.version
@@ -283,7 +288,7 @@ class ResNet50Model(object):
                                         device=self.session.device)
         ops.conv2d_fwd_split3p(plan, d, xplanes, self._lo_off(self.N * hw[0] * hw[1], cin),
                                ops.LazyPtr(lambda off=off: self.wsplit[off:]), out, stats if training else None,
-                               tail_ws=self._tail_ws)
+                               tail_ws=self._tail_ws, terms=self._terms)
         if not hasattr(self, "_aff_cache"):
             self._aff_cache = {}
         if scope not in self._aff_cache:
@@ -401,7 +406,7 @@ class ResNet50Model(object):
         return sc, sh
 
     def _record_forward(self, plan, training):
-        if self.precision == "f16x3":
+        if self._split:
             return self._record_forward_split(plan, training)
         N = self.N
         H, W = self.height, self.width
@@ -455,7 +460,7 @@ class ResNet50Model(object):
         ops.bn_relu_bwd(plan, self.raw_cm, self.output, self.g_output, P(cm + "/BatchNorm/gamma"),
                         self.save_mean, self.save_invstd, self.g_raw_cm, G(cm + "/BatchNorm/gamma"),
                         G(cm + "/BatchNorm/beta"), N * fh * fw, 12)
-        if self.precision == "f16x3":
+        if self._split:
             # tap-GEMM form: dWt[2048][144] = xfinal^T . (tap-scattered g_raw_cm), then back to HWIO + the L2 term
             ops.tapconv_scatter(plan, self._cm_d, self.g_raw_cm, 12, self.cm_gz, 144)
             ops.conv2d_wgrad_split3(plan, self._cm_d1, self.xfinal, self.cm_gz, 144, self.cm_dwt, None)

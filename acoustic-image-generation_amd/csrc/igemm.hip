@@ -1715,8 +1715,8 @@ size_t acimg_conv2d_fwd_split3p_workspace(const AcimgConvDesc* d) {
     return TS_COUNTER_BYTES + (size_t)TS_MAX_UNITS * 128 * 128 * sizeof(float);
 }
 
-int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
-                             float* y, float* stats, void* ws, size_t ws_bytes, void* stream) {
+static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit, float* y,
+                        float* stats, void* ws, size_t ws_bytes, void* stream, const int terms) {
     int rc = check_desc(d, "conv2d_fwd_split3p");
     if (rc) return rc;
     if (d->C % 32) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: C=%d must be a multiple of 32", d->C);
@@ -1760,7 +1760,7 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
     const bool persistent = split3p_persistent(c, T);
     // K-step depth of the persistent kernel: 32 = the one-tile kernel's image (2 workgroups / CU); 64 = full 128-byte
     // operand lines per DMA request, 1 workgroup / CU (measured slower on every trunk shape: experiments only)
-    const int bk = persistent && g_cfg.trunk_bk ? g_cfg.trunk_bk : 32;
+    const int bk = persistent && g_cfg.trunk_bk && terms == 3 ? g_cfg.trunk_bk : 32;
     if (persistent && bk == 64 && d->C % 64) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: trunk_bk 64 needs C %% 64 == 0");
     p.kiters = p.ntaps * (d->C / bk);
     const size_t lds_p = (size_t)2 * 4 * 128 * (bk * 2) + 4 * 2 * 128 * 4;    // 2 stages + statistics scratch
@@ -1793,11 +1793,20 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
                 attr = true;
             }
             hipLaunchKernelGGL((igemm_split3dp_kernel<64, 0>), dim3(nwg), dim3(512), lds_p, st, p, n_units, nwg);
+        } else if (terms == 1) {
+            hipLaunchKernelGGL((igemm_split3dp_kernel<32, 0, 1>), dim3(nwg), dim3(512), lds_p, st, p, n_units, nwg);
         } else if (g_cfg.trunk_dma_pos == 1) {
             hipLaunchKernelGGL((igemm_split3dp_kernel<32, 1>), dim3(nwg), dim3(512), lds_p, st, p, n_units, nwg);
         } else {
             hipLaunchKernelGGL((igemm_split3dp_kernel<32, 0>), dim3(nwg), dim3(512), lds_p, st, p, n_units, nwg);
         }
+    } else if (terms == 1) {
+        if (which == 0)
+            hipLaunchKernelGGL((igemm_split3d_kernel<128, 128, 2, 4, 512, 2, 2, 1>), grid, dim3(512), lds_bytes, st, p);
+        else if (which == 1)
+            hipLaunchKernelGGL((igemm_split3d_kernel<64, 128, 1, 4, 256, 2, 2, 1>), grid, dim3(256), lds_bytes, st, p);
+        else
+            hipLaunchKernelGGL((igemm_split3d_kernel<128, 64, 2, 2, 256, 2, 2, 1>), grid, dim3(256), lds_bytes, st, p);
     } else if (which == 0)
         hipLaunchKernelGGL((igemm_split3d_kernel<128, 128, 2, 4, 512, 2, 2>), grid, dim3(512), lds_bytes, st, p);
     else if (which == 1)
@@ -1805,6 +1814,16 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
     else
         hipLaunchKernelGGL((igemm_split3d_kernel<128, 64, 2, 2, 256, 2, 2>), grid, dim3(256), lds_bytes, st, p);
     return check_launch("conv2d_fwd_split3p");
+}
+
+int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
+                             float* y, float* stats, void* ws, size_t ws_bytes, void* stream) {
+    return fwd_presplit(d, x_planes, x_lo_off, wsplit, y, stats, ws, ws_bytes, stream, 3);
+}
+
+int acimg_conv2d_fwd_split1p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
+                             float* y, float* stats, void* ws, size_t ws_bytes, void* stream) {
+    return fwd_presplit(d, x_planes, x_lo_off, wsplit, y, stats, ws, ws_bytes, stream, 1);
 }
 
 /* ---- tap-GEMM helpers (see the kernels above) ---- */

@@ -73,7 +73,10 @@ __device__ __forceinline__ void raster_tile(const IgemmParams& p, int L, int& mt
     nt = ngroup * p.ras_gn + (r2 - mi * gn);
 }
 
-template <int BM, int BN, int WGM, int WGN, int NTHR, int NSA, int NSB>
+// TERMS = 3: the split product ah*wh + ah*wl + al*wh (fp32-class results).  TERMS = 1: fp16 OPERAND STORAGE - only the
+// hi planes are fetched and multiplied (one MFMA sweep, half the operand bytes): the arithmetic of an fp16-storage /
+// fp32-accumulate network (BASELINE configs[4]); activations and weights carry 11 significant bits.
+template <int BM, int BN, int WGM, int WGN, int NTHR, int NSA, int NSB, int TERMS = 3>
 __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p) {
     constexpr int BK = 32;
     constexpr int ROWB = BK * 2;
@@ -181,7 +184,8 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
             const unsigned off = ok ? (unsigned)(a_off[j] + tapoff) : OOB;
             char* dst = st + (wid + j * NW) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, off, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + A_BYTES), 16, off, (int)p.a_lo_off, 0, 0);
+            if (TERMS == 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + A_BYTES), 16, off, (int)p.a_lo_off, 0, 0);
         }
         ++qa;
         sa = sa + 1 == NSA ? 0 : sa + 1;
@@ -202,7 +206,8 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
             const unsigned off = b_goff[j] == OOB ? OOB : b_goff[j] + kbyte;
             char* dst = st + (wid + j * NW) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)dst, 16, off, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + B_BYTES), 16, off, (int)b_lo_off, 0, 0);
+            if (TERMS == 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + B_BYTES), 16, off, (int)b_lo_off, 0, 0);
         }
         ++qb;
         sb = sb + 1 == NSB ? 0 : sb + 1;
@@ -223,29 +228,31 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
             const int row = wm * WTM + i * 16 + li;
             const int off = row * ROWB + ((g ^ swz(row)) << 4);
             ah[i] = *reinterpret_cast<const h16x8*>(sta + off);
-            al[i] = *reinterpret_cast<const h16x8*>(sta + A_BYTES + off);
+            if (TERMS == 3) al[i] = *reinterpret_cast<const h16x8*>(sta + A_BYTES + off);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int row = wn * WTN + j * 16 + li;
             const int off = row * ROWB + ((g ^ swz(row)) << 4);
             bh[j] = *reinterpret_cast<const h16x8*>(stb + off);
-            bl[j] = *reinterpret_cast<const h16x8*>(stb + B_BYTES + off);
+            if (TERMS == 3) bl[j] = *reinterpret_cast<const h16x8*>(stb + B_BYTES + off);
         }
         // all 12 fragment reads are in flight before the first MFMA (one exposed LDS latency per step instead
         // of one per fragment pair), and the three terms of a product are issued a whole sweep apart so that no
         // MFMA waits on its predecessor's accumulator (the per-accumulator order lo*hi, hi*lo, hi*hi is kept)
         __builtin_amdgcn_sched_barrier(0);
+        if (TERMS == 3) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll

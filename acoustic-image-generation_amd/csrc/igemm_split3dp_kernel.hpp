@@ -87,7 +87,8 @@ __device__ __forceinline__ KCursorP kcursor_next(KCursorP k, int C, int S) {
 // 30 % of a long-K layer's wave time - tools/stamp_probe.py - before any of them has an MFMA ready).  1: spread
 // under the MFMA block - the B pieces after the first of the three MFMA sweeps, the A pieces after the second - so a
 // wave that waits at the addresser has already queued matrix work and the others keep the pipe busy.
-template <int BK, int DPOS>
+// TERMS: 3 = split product, 1 = fp16 operand storage (hi planes only), as in igemm_split3d_kernel.
+template <int BK, int DPOS, int TERMS = 3>
 __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(const IgemmParams p, const int n_units,
                                                                                const int stride_units) {
     constexpr int BM = 128, BN = 128, WGN = 4, NTHR = 512, NW = 8, ROWB = BK * 2;
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
             const unsigned boff = t.b_goff[j] == OOB ? OOB : t.b_goff[j] + kbyte;
             char* dst = st + 2 * PLANE + (wid + j * NW) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)dst, 16, boff, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + PLANE), 16, boff, (int)b_lo_off, 0, 0);
+            if (TERMS == 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + PLANE), 16, boff, (int)b_lo_off, 0, 0);
         }
     };
     auto issue_a = [&](const Tile& t, int slot) {      // ... and moves the cursor on
@@ -181,7 +183,8 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
             const unsigned aoff = ok ? (unsigned)(t.a_off[j] + tapoff) : OOB;
             char* dst = st + (wid + j * NW) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, aoff, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + PLANE), 16, aoff, (int)p.a_lo_off, 0, 0);
+            if (TERMS == 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + PLANE), 16, aoff, (int)p.a_lo_off, 0, 0);
         }
         kc = kcursor_next<BK>(kc, p.C, p.S);
     };
@@ -213,36 +216,40 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
                 const int row = wm * WTM + i * 16 + li;
                 const int off = row * ROWB + (((kh * 4 + g) ^ (BK == 32 ? swz(row) : (row & 7))) << 4);
                 ah[i] = *reinterpret_cast<const h16x8*>(sta + off);
-                al[i] = *reinterpret_cast<const h16x8*>(sta + PLANE + off);
+                if (TERMS == 3) al[i] = *reinterpret_cast<const h16x8*>(sta + PLANE + off);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn * WTN + j * 16 + li;
                 const int off = row * ROWB + (((kh * 4 + g) ^ (BK == 32 ? swz(row) : (row & 7))) << 4);
                 bh[j] = *reinterpret_cast<const h16x8*>(stb + off);
-                bl[j] = *reinterpret_cast<const h16x8*>(stb + PLANE + off);
+                if (TERMS == 3) bl[j] = *reinterpret_cast<const h16x8*>(stb + PLANE + off);
             }
             if (BK == 32) __builtin_amdgcn_sched_barrier(0);
 #ifdef ACIMG_STAMP
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             ACIMG_STAMP_AT(3);
 #endif
+            if (TERMS == 3) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            }
             if (DPOS == 1 && kh == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (req == 1) issue_b(ta, slot ^ 1);
                 else if (req == 2) issue_b(tb, slot ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (TERMS == 3) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            }
             if (DPOS == 1 && kh == 0) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (req == 1) issue_a(ta, slot ^ 1);

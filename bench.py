@@ -47,8 +47,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]/[3]: 32)")
     ap.add_argument("--num-skip", type=int, default=1)
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
-                    help="trunk conv arithmetic: split-fp16 MFMA (fp32-class results) or exact-f32 MFMA")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32", "f16"],
+                    help="trunk conv arithmetic: split-fp16 MFMA (fp32-class results), exact-f32 MFMA, or fp16 operand "
+                         "storage with fp32 accumulation (BASELINE configs[4]; --workload classifier only: a reduced-"
+                         "precision number is never the headline metric)")
     ap.add_argument("--workload", default="trainer_mask", choices=["trainer_mask", "unet_rgb", "unet_sound", "classifier"],
                     help="trainer_mask (default: the north-star path, BASELINE configs[2]/[3]); unet_rgb / unet_sound: the "
                          "single-modality U-Net VAEs of configs[1] / [0]; classifier: DualCamNet on generated images, "
@@ -273,7 +275,9 @@ def other_workload(args):
     print(json.dumps({
         "metric": "train-step images/sec", "value": B * args.steps / dt, "unit": "images/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 trunk operands, f32 accumulate / statistics / loss" if args.precision == "f16" else "f32",
+        "data": "synthetic",
         "config": {"workload": name, "per_gpu_batch": B, "global_batch": B, "parallelism": "dp1",
                    "launches_per_step": launches},
         "final": last(), "roofline": None}))
@@ -281,6 +285,8 @@ def other_workload(args):
 
 def main():
     args = parse()
+    if args.precision == "f16" and args.workload != "classifier":
+        raise SystemExit("--precision f16 (fp16 operand storage) is accepted for --workload classifier only")
     if args.workload != "trainer_mask":
         return other_workload(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -167,6 +167,12 @@ int acimg_conv2d_dgrad_split3(const AcimgConvDesc* d, const float* gy, int ldgy,
 size_t acimg_conv2d_fwd_split3p_workspace(const AcimgConvDesc* d);
 int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
                              float* y, float* stats, void* ws, size_t ws_bytes, void* stream);
+/* The same launch with fp16 OPERAND STORAGE (BASELINE configs[4]: "fp16 with fp32 loss accumulation"): only the hi
+ * planes of activations and weights are fetched and multiplied - one fp16 MFMA per product instead of three, half the
+ * operand bytes - with fp32 accumulation, fp32 batch-norm statistics and fp32 output.  Operands carry 11 significant
+ * bits; everything else (arguments, tiling, statistics rows, workspace) is as for acimg_conv2d_fwd_split3p. */
+int acimg_conv2d_fwd_split1p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
+                             float* y, float* stats, void* ws, size_t ws_bytes, void* stream);
 int acimg_bn_relu_split(const float* x, const float* scale, const float* shift, int relu, void* out,
                         size_t lo_off, long rows, int C, void* stream);
 int acimg_bn_add_relu_split(const float* a, const float* sa, const float* ta, const float* b32,

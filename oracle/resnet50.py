@@ -80,8 +80,16 @@ def init_params(seed=1238, dtype=torch.float32, randomize_bn=False):
     return p
 
 
-def _conv_bn(p, scope, x, stride, training, relu, updates, padding=None, mask=None):
+def _f16_operand(t, scale):
+    """the value an fp16-storage operand carries: round(t * scale) to fp16, rescaled (the product path's hi plane;
+    scale = 2^-2 for activations, 2^10 for weights: exact powers of two, they only move fp16's range)"""
+    return (t * scale).to(torch.float16).to(t.dtype) / scale
+
+
+def _conv_bn(p, scope, x, stride, training, relu, updates, padding=None, mask=None, f16_operands=False):
     w = p[scope + "/weights"]
+    if f16_operands:      # BASELINE configs[4] "fp16 storage, fp32 accumulation": both conv operands at 11 bits
+        x, w = _f16_operand(x, 0.25), _f16_operand(w, 1024.0)
     if padding == "VALID":
         y = tfsem.conv2d(x, w, None, stride, "VALID")
     elif w.shape[0] == 1:
@@ -99,10 +107,11 @@ def _conv_bn(p, scope, x, stride, training, relu, updates, padding=None, mask=No
     return torch.relu(y) if relu else y
 
 
-def forward(p, images, training, end_points=None, feat_mask=None):
+def forward(p, images, training, end_points=None, feat_mask=None, f16_operands=False):
     """images [N,224,298,3] -> features [N,12,16,12]; returns (features, moving-stat updates).
     Gradients flow only from conv_map on (the trunk is not in var_list, mfcctrainer.py:64): the trunk
-    runs under no_grad."""
+    runs under no_grad.  f16_operands: the 52 bottleneck convs see fp16-rounded activations and weights (the
+    product's precision="f16" mode; the stem and conv_map keep fp32 operands there as well)."""
     updates = OrderedDict()
     ep = end_points if end_points is not None else {}
     with torch.no_grad():
@@ -114,10 +123,10 @@ def forward(p, images, training, end_points=None, feat_mask=None):
             if din == d:
                 shortcut = tfsem.subsample(net, s)
             else:
-                shortcut = _conv_bn(p, scope + "/shortcut", net, s, training, False, updates)
-            r = _conv_bn(p, scope + "/conv1", net, 1, training, True, updates)
-            r = _conv_bn(p, scope + "/conv2", r, s, training, True, updates)
-            r = _conv_bn(p, scope + "/conv3", r, 1, training, False, updates)
+                shortcut = _conv_bn(p, scope + "/shortcut", net, s, training, False, updates, f16_operands=f16_operands)
+            r = _conv_bn(p, scope + "/conv1", net, 1, training, True, updates, f16_operands=f16_operands)
+            r = _conv_bn(p, scope + "/conv2", r, s, training, True, updates, f16_operands=f16_operands)
+            r = _conv_bn(p, scope + "/conv3", r, 1, training, False, updates, f16_operands=f16_operands)
             net = torch.relu(shortcut + r)
             ep[scope] = net
     net = _conv_bn(p, SCOPE + "/conv_map", net, 1, training, True, updates, padding="VALID", mask=feat_mask)

@@ -19,13 +19,14 @@ from . import resnet50, tfsem, unet_acresnet
 
 class Oracle(object):
     def __init__(self, num_skip=1, embedding=False, learning_rate=1e-4, latent_loss=1e-6,
-                 use_mse=True, use_huber=True, dtype=torch.float32, seed=1238, randomize=False):
+                 use_mse=True, use_huber=True, dtype=torch.float32, seed=1238, randomize=False, f16_operands=False):
         self.num_skip = num_skip
         self.embedding = bool(embedding)
         self.lr = learning_rate
         self.latent_w = latent_loss
         self.use_mse, self.use_huber = use_mse, use_huber
         self.dtype = dtype
+        self.f16_operands = f16_operands      # trunk convs on fp16-rounded operands (the product's precision="f16")
         self.res = resnet50.init_params(seed, dtype, randomize_bn=randomize)
         self.gen = unet_acresnet.init_params(seed + 1, num_skip, self.embedding, dtype,
                                              bias_std=0.05 if randomize else 0.0)
@@ -53,7 +54,8 @@ class Oracle(object):
         n = mfcc.shape[0]
         mfccmap = mfcc.reshape(n, 1, 1, 12).expand(n, 36, 48, 12).contiguous()
         rm = relu_masks or {}
-        feat, updates = resnet50.forward(self.res, video, training, end_points, feat_mask=rm.get("conv_map"))
+        feat, updates = resnet50.forward(self.res, video, training, end_points, feat_mask=rm.get("conv_map"),
+                                         f16_operands=self.f16_operands)
         mean, std, out = unet_acresnet.forward(self.gen, mfccmap, feat, eps, self.num_skip,
                                                self.embedding, end_points, relu_masks=relu_masks)
         return mean, std, out, updates

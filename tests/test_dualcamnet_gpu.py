@@ -4,6 +4,7 @@ train step of trainer/trainer_reconstructed_class.py end to end."""
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -168,3 +169,52 @@ def test_configs4_classifier_step_at_60_frames():
             assert float((after[k].double() - p2).abs().max()) <= 2e-6 * max(float(p2.abs().max()), 1e-3), k
         else:
             assert torch.equal(before[k], after[k]), "frozen variable moved: " + k
+
+
+def test_configs4_fp16_operand_storage():
+    """BASELINE configs[4] "fp16 with fp32 loss accumulation": ResNet50Model(precision="f16") runs the 52 trunk convs
+    on the hi fp16 plane of activations and weights only (one MFMA per product, fp32 accumulation, fp32 batch-norm
+    statistics, fp32 losses).  Checked against the oracle with the SAME operand rounding (oracle/resnet50.py
+    f16_operands): generated frames within 1e-3; and against the full-precision oracle to show what the storage costs
+    on the random-initialised trunk."""
+    from acimg.dualcamnet import DualCamHybridModel
+    from acimg.flags import FLAGS
+    from acimg.session import Session
+    from acimg.trainer_class import TrainerClass
+    from acimg.unet_acresnet import UNetAc
+    from acimg.vision import ResNet50Model
+    from oracle import dualcamnet as odc
+    from oracle import trainer as otr
+
+    dev = torch.device("cuda:0")
+    FLAGS.model, FLAGS.ae = "DualCamNet", 0
+    NF, K = 24, 14
+    sess = Session(dev)
+    m = DualCamHybridModel(input_shape=[36, 48, 12], num_classes=K)
+    tr = TrainerClass(m, ResNet50Model(input_shape=[224, 298, 3], num_classes=None, precision="f16"),
+                      UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=1), learning_rate=1e-3, session=sess)
+    tr._build_functions(batch_size=NF)
+    orc16 = otr.Oracle(num_skip=1, randomize=True, f16_operands=True)
+    orc32 = otr.Oracle(num_skip=1, randomize=True)
+    params = odc.init_params(K, seed=11, dtype=torch.float32, std=0.05, bias_std=0.05)
+    state = dict(orc16.state_dict())
+    state.update(params)
+    sess.store.load_state(m._to_internal(state), strict=True)
+    _, mfcc, video, eps = otr.synthetic_batch(NF, seed=55)
+    labels = torch.tensor([3, 9])
+    got = tr.train_step((mfcc, video, labels), eps)
+    with torch.no_grad():
+        ep16, ep32 = {}, {}
+        _, _, gen16, _ = orc16.forward(video, mfcc, eps, False, ep16)
+        _, _, gen32, _ = orc32.forward(video, mfcc, eps, False, ep32)
+    feat = tr.model_encoder_images.output
+    e_feat = rel(feat, ep16["resnet_v1_50/conv_map"])
+    e_gen = rel(tr.model_encoder_acoustic.output, gen16)
+    cost = rel(ep16["resnet_v1_50/conv_map"], ep32["resnet_v1_50/conv_map"])
+    print("fp16 operand storage: feature vs same-rounding oracle %.2e, frames %.2e; cost of the storage itself "
+          "(oracle f16 vs f32 feature) %.2e" % (e_feat, e_gen, cost))
+    # both sides round every conv operand to fp16, but a value within fp32 rounding of an fp16 tie rounds apart and
+    # the 53-layer random-init trunk amplifies that: the bar is 1e-2 on the feature, 1e-3 on the frames it conditions
+    assert e_feat < 1e-2 and e_gen < 1e-3, (e_feat, e_gen)
+    assert cost > 10 * e_feat or cost < 1e-2       # the storage format, not the kernel, is what moves the feature
+    assert np.isfinite(got["loss"]) and 0.0 <= got["accuracy"] <= 1.0

@@ -423,3 +423,27 @@ def test_host_butterworth_design_equals_scipy():
     np.testing.assert_array_equal(fe.lfilter_zi(b, a), signal.lfilter_zi(b2, a2))
     assert len(b) == 11 and abs(b[0] - 9.0892e-16) < 1e-19 and abs(a[1] + 9.5914255) < 1e-6
     np.testing.assert_allclose(fe.hann_window_periodic(246).sum(), 123.0, rtol=1e-6)
+
+
+def test_f16_operand_mode_of_the_trunk_oracle():
+    """oracle/resnet50.py f16_operands (the reference statement of the product's precision="f16"): conv operands
+    carry 11 significant bits, everything else stays fp32; the effect on the feature is real but bounded"""
+    from oracle import resnet50 as ores
+    from oracle import trainer as otr
+
+    t = torch.tensor([1.0, 1.0 + 2.0 ** -11, 1.0 + 2.0 ** -11 + 2.0 ** -20, 300.0, 1e-5])   # exact, tie -> even, above the tie
+    q = ores._f16_operand(t, 0.25)
+    assert q[0] == 1.0 and q[1] == 1.0 and q[2] == 1.0 + 2.0 ** -10 and abs(q[3] - 300.0) <= 0.125
+    assert abs(float(q[4]) - 1e-5) < 2.5e-7            # 2^-2 scaling keeps small activations out of fp16's subnormals
+    w = ores._f16_operand(torch.tensor([1e-3, 60.0]), 1024.0)
+    assert abs(float(w[0]) - 1e-3) < 1e-6 and float(w[1]) == 60.0
+    o32 = otr.Oracle(randomize=True)
+    o16 = otr.Oracle(randomize=True, f16_operands=True)
+    ac, mf, vid, eps = otr.synthetic_batch(1, seed=3)
+    with torch.no_grad():
+        f32_, _ = ores.forward(o32.res, vid, False)
+        f16a, _ = ores.forward(o16.res, vid, False, f16_operands=True)
+        f16b, _ = ores.forward(o16.res, vid, False, f16_operands=True)
+    assert torch.equal(f16a, f16b)
+    d = float((f16a - f32_).abs().max() / f32_.abs().max())
+    assert 1e-5 < d < 0.5, d
