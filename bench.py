@@ -358,9 +358,9 @@ def main():
     if not f16:
         kernel_name = "igemm_f32_kernel<%d,%d,...,false,true>" % (tile[0], tile[1])
     elif len(tile) > 2 and tile[2]:
-        kernel_name = "igemm_split3dp_kernel<32, 0>"       # the persistent form of the 128x128 trunk kernel
+        kernel_name = "igemm_split3dp_kernel<32, 0, 3>"    # the persistent form of the 128x128 trunk kernel
     else:
-        kernel_name = "igemm_split3d_kernel<%d,%d,%s,2,2>" % (tile[0], tile[1], TILE_THREADS[tile[:2]])
+        kernel_name = "igemm_split3d_kernel<%d,%d,%s,2,2,3>" % (tile[0], tile[1], TILE_THREADS[tile[:2]])
     def one_step(probe=None):
         if strong:
             tr.train_step_sharded(shards, probe=probe)
