@@ -17,10 +17,26 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
     const float* stats, int rows, int C, int ld, double count, const float* gamma, const float* beta,
     float* moving_mean, float* moving_var, float decay, float eps, int training, float* scale,
     float* shift, float* save_mean, float* save_invstd) {
+    // Latency-bound kernel (54 launches per step): (1) the per-channel constants are requested FIRST so that their
+    // global-load latency overlaps the partial-sum loads; (2) the row groups are combined by a 4-way split of the
+    // final loop instead of one thread walking all NRG partials of a channel through dependent LDS reads (that loop
+    // alone was ~3 us of the 6 us a launch took).
     constexpr int NRG = 1024 / CPB;
+    constexpr int Q = 4;                       // threads per channel in the final combine
+    static_assert(NRG % Q == 0, "row groups per combining thread");
     __shared__ double red[2][NRG][CPB];
+    __shared__ double red2[2][Q][CPB];
     const int cl = threadIdx.x % CPB, rg = threadIdx.x / CPB;
     const int c = blockIdx.x * CPB + cl;
+    float g = 1.f, b = 0.f, mm = 0.f, mv = 1.f;
+    if (rg == 0 && c < C) {
+        if (gamma) g = gamma[c];
+        if (beta) b = beta[c];
+        if (moving_mean) {
+            mm = moving_mean[c];
+            mv = moving_var[c];
+        }
+    }
     double s1 = 0.0, s2 = 0.0;
     if (training && c < C) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
@@ -42,18 +58,25 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
         s1 = ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
         s2 = ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
     }
-    red[0][rg][cl] = s1;
-    red[1][rg][cl] = s2;
-    __syncthreads();
-    if (rg != 0 || c >= C) return;
     float mean, var;
     if (training) {
-        s1 = 0.0;
-        s2 = 0.0;
-        for (int i = 0; i < NRG; ++i) {
-            s1 += red[0][i][cl];
-            s2 += red[1][i][cl];
+        red[0][rg][cl] = s1;
+        red[1][rg][cl] = s2;
+        __syncthreads();
+        if (rg < Q) {                          // Q threads per channel, NRG / Q partials each, in row-group order
+            double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NRG / Q; ++i) {
+                t1 += red[0][rg * (NRG / Q) + i][cl];
+                t2 += red[1][rg * (NRG / Q) + i][cl];
+            }
+            red2[0][rg][cl] = t1;
+            red2[1][rg][cl] = t2;
         }
+        __syncthreads();
+        if (rg != 0 || c >= C) return;
+        s1 = (red2[0][0][cl] + red2[0][1][cl]) + (red2[0][2][cl] + red2[0][3][cl]);
+        s2 = (red2[1][0][cl] + red2[1][1][cl]) + (red2[1][2][cl] + red2[1][3][cl]);
         const double m = s1 / count;
         double v = s2 / count - m * m;
         if (v < 0.0) v = 0.0;
@@ -61,18 +84,18 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
         var = (float)v;
         if (moving_mean) {
             const double unbiased = count > 1.0 ? v * (count / (count - 1.0)) : v;
-            moving_mean[c] = decay * moving_mean[c] + (1.f - decay) * mean;
-            moving_var[c] = decay * moving_var[c] + (1.f - decay) * (float)unbiased;
+            moving_mean[c] = decay * mm + (1.f - decay) * mean;
+            moving_var[c] = decay * mv + (1.f - decay) * (float)unbiased;
         }
     } else {
-        mean = moving_mean[c];
-        var = moving_var[c];
+        if (rg != 0 || c >= C) return;
+        mean = mm;
+        var = mv;
     }
     const float invstd = 1.f / sqrtf(var + eps);
-    const float g = gamma ? gamma[c] : 1.f;
     const float sc = g * invstd;
     scale[c] = sc;
-    shift[c] = (beta ? beta[c] : 0.f) - mean * sc;
+    shift[c] = b - mean * sc;
     if (save_mean) save_mean[c] = mean;
     if (save_invstd) save_invstd[c] = invstd;
 }

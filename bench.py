@@ -283,12 +283,37 @@ def other_workload(args):
         "final": last(), "roofline": None}))
 
 
+class _QuietStdout(object):
+    """The driver reads ONE JSON line from stdout.  Libraries write there too (RCCL prints a version banner when its
+    communicator comes up): everything written to file descriptor 1 before `release()` goes to stderr instead."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def release(self):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     args = parse()
     if args.precision == "f16" and args.workload != "classifier":
         raise SystemExit("--precision f16 (fp16 operand storage) is accepted for --workload classifier only")
+    quiet = _QuietStdout()
     if args.workload != "trainer_mask":
-        return other_workload(args)
+        try:
+            import contextlib
+            import io
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                other_workload(args)
+        finally:
+            quiet.release()
+        sys.stdout.write(buf.getvalue())
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -458,7 +483,9 @@ def main():
                     out[key] = fn(args)
                 except Exception as e:   # never lose the primary line
                     out[key] = {"error": repr(e)}
-        print(json.dumps(out))
+    quiet.release()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
