@@ -638,7 +638,7 @@ static TileCfg pick_cfg(int M, int Ngemm) {
 
 // Tuning record (acimg_configure): plain ints, defaults compiled in, written only by acimg_configure and never by a
 // launch; the launch heuristics below read it instead of the process environment.
-static AcimgConfig g_cfg = {320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 0};
+static AcimgConfig g_cfg = {320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0};
 
 static int pick_splits(int M, int Ngemm, TileCfg c, int kiters) {
     // measured on the generator's 12x16 layers (192-288 tiles of 64x64, 36+ K steps: tools/splitk_sweep.sh):
@@ -1178,7 +1178,7 @@ int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
 
 int acimg_config_default(AcimgConfig* c) {
     if (!c) return fail(ACIMG_EINVAL, "config_default: null");
-    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 0};
+    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0};
     return ACIMG_OK;
 }
 
@@ -1187,7 +1187,6 @@ int acimg_configure(const AcimgConfig* c) {
     if (c->splitk_cut < 0 || c->splitk_target < 1 || c->wgrad_minpix < 1 || c->tail_s < 0)
         return fail(ACIMG_EINVAL, "configure: negative / zero tuning value");
     if (c->trunk_persistent < 0 || c->trunk_persistent > 2) return fail(ACIMG_EINVAL, "configure: trunk_persistent is 0, 1 or 2");
-    if (c->trunk_nt < 0 || c->trunk_nt > 1) return fail(ACIMG_EINVAL, "configure: trunk_nt is 0 or 1");
     if (c->trunk_dma_pos < 0 || c->trunk_dma_pos > 1) return fail(ACIMG_EINVAL, "configure: trunk_dma_pos is 0 or 1");
     if (c->trunk_stagger < 0 || c->trunk_stagger > 100) return fail(ACIMG_EINVAL, "configure: trunk_stagger is a percentage");
     if (c->trunk_bk != 0 && c->trunk_bk != 32 && c->trunk_bk != 64)
@@ -1781,7 +1780,6 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
     p.flip = g_stamp_nostore;
 #endif
     if (persistent) {
-        p.a_relu = g_cfg.trunk_nt;
         p.splits = g_cfg.trunk_stagger > 0 ? g_cfg.trunk_stagger * (p.kiters * (bk == 64 ? 3400 : 2500) + 8000) / 100 : 1;
         // a workgroup per resident slot walks units blockIdx.x, blockIdx.x + P, ...: whole tiles first (with the
         // next tile's first operand stage and addresses prepared under the current tile's last K step and output

@@ -182,15 +182,12 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
             const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
             const unsigned aoff = ok ? (unsigned)(t.a_off[j] + tapoff) : OOB;
             char* dst = st + (wid + j * NW) * 1024;
-            if (p.a_relu & 1) {    // experiment (trunk_nt bit 0): activations fetched with the non-temporal policy
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, aoff, 0, 0, 2);
-                if (TERMS == 3)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + PLANE), 16, aoff, (int)p.a_lo_off, 0, 2);
-            } else {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, aoff, 0, 0, 0);
-                if (TERMS == 3)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + PLANE), 16, aoff, (int)p.a_lo_off, 0, 0);
-            }
+            // (fetching the activation tiles with the non-temporal policy, to keep the weight tiles in the XCD's L2,
+            //  was measured: 25 % slower - the column tiles of an XCD share A through that L2;
+            //  profiles/r02/trunk_shapes_r02_nt_experiment.txt)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, aoff, 0, 0, 0);
+            if (TERMS == 3)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + PLANE), 16, aoff, (int)p.a_lo_off, 0, 0);
         }
         kc = kcursor_next<BK>(kc, p.C, p.S);
     };

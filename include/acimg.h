@@ -11,7 +11,7 @@
  *     nothing is thrown across the boundary;
  *   - the CALLER owns every buffer (device pointers, 16-byte aligned), including workspace and the
  *     ticket words of the in-kernel reductions (explicit `tickets` / scratch arguments); the library
- *     allocates nothing.  Its only process-wide state is the tuning record of acimg_configure() (fourteen
+ *     allocates nothing.  Its only process-wide state is the tuning record of acimg_configure() (thirteen
  *     plain ints with compiled-in defaults, written by that call alone, never by a launch, and never
  *     read from the process environment) and the per-thread text of acimg_last_error();
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*), no host sync;
@@ -108,8 +108,6 @@ typedef struct AcimgConfig {
                                 estimated time late (0 = together) */
     int32_t trunk_dma_pos;   /* persistent kernel: a K step's operand requests 0 = in one burst after the step barrier,
                                 1 = spread under the MFMA block (B after the first sweep, A after the second) */
-    int32_t trunk_nt;        /* persistent kernel: 1 = activation tiles fetched with the non-temporal cache policy
-                                (experiment: keeps the weight tiles in the XCD's L2) */
 } AcimgConfig;
 int acimg_config_default(AcimgConfig* cfg);
 int acimg_configure(const AcimgConfig* cfg);

@@ -295,8 +295,8 @@ def test_library_reads_no_environment_and_configure_validates(lib):
     cfg = _lib.Config()
     assert lib.acimg_config_default(C.byref(cfg)) == 0
     assert (cfg.splitk_cut, cfg.splitk_target, cfg.splitk_handoff, cfg.wgrad_minpix, cfg.wgrad_halo, cfg.split3_tile_bm,
-            cfg.split3_tile_bn, cfg.tail_split, cfg.tail_s, cfg.trunk_persistent, cfg.trunk_bk, cfg.trunk_stagger, cfg.trunk_dma_pos, cfg.trunk_nt) == (320, 768, 1, 128, 1, 0, 0,
-                                                                                                  1, 0, 1, 0, 0, 0, 0)
+            cfg.split3_tile_bn, cfg.tail_split, cfg.tail_s, cfg.trunk_persistent, cfg.trunk_bk, cfg.trunk_stagger, cfg.trunk_dma_pos) == (320, 768, 1, 128, 1, 0, 0, 1,
+                                                                                                  0, 1, 0, 0, 0)
     d = ops.conv_desc(4, 12, 16, 128, 128, 3, 3)
     base = ops.conv2d_fwd_tiling(d)
     assert base[2] > 1
