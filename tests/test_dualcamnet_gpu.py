@@ -214,7 +214,8 @@ def test_configs4_fp16_operand_storage():
     print("fp16 operand storage: feature vs same-rounding oracle %.2e, frames %.2e; cost of the storage itself "
           "(oracle f16 vs f32 feature) %.2e" % (e_feat, e_gen, cost))
     # both sides round every conv operand to fp16, but a value within fp32 rounding of an fp16 tie rounds apart and
-    # the 53-layer random-init trunk amplifies that: the bar is 1e-2 on the feature, 1e-3 on the frames it conditions
-    assert e_feat < 1e-2 and e_gen < 1e-3, (e_feat, e_gen)
-    assert cost > 10 * e_feat or cost < 1e-2       # the storage format, not the kernel, is what moves the feature
+    # the 53-layer random-init trunk amplifies that (the kernel itself is exact on rounded operands:
+    # tests/test_ops_gpu.py::test_fp16_operand_storage_conv): the bar is 1e-2 on the feature, 1e-3 on the frames it
+    # conditions, and the storage format itself moves the feature by no more than that either
+    assert e_feat < 1e-2 and e_gen < 1e-3 and cost < 1e-2, (e_feat, e_gen, cost)
     assert np.isfinite(got["loss"]) and 0.0 <= got["accuracy"] <= 1.0

@@ -1012,3 +1012,43 @@ def test_trunk_kernel_variants_agree(device, case):
     for name in ("persistent", "staggered", "auto"):   # same K ranges, same MFMA order: the same bits
         assert torch.equal(outs[name][0], y0), name
     assert float((outs["bk64"][0] - y0).abs().max()) <= 4e-6 * float(y0.abs().max())
+
+
+@pytest.mark.parametrize("case", [(32, 28, 38, 256, 1024, 1, 1, 1, "SAME"), (8, 56, 75, 128, 128, 3, 3, 1, "SAME"),
+                                  (6, 56, 75, 256, 64, 1, 1, 1, "SAME")])
+def test_fp16_operand_storage_conv(device, case):
+    """`acimg_conv2d_fwd_split1p` (BASELINE configs[4]: fp16 operand storage, fp32 accumulation): exactly the
+    convolution of the fp16-ROUNDED operands — hi plane of the activations (f16(x * 2^-2)), hi plane of the weights
+    (f16(w * 2^10)) — accumulated in fp32; persistent, one-tile and 128x64-tile kernels"""
+    from acimg import ops
+
+    N, H, W, Cc, K, R, S, stride, padding = case
+    g = torch.Generator().manual_seed(77 + Cc + K)
+    x = torch.rand(N, H, W, Cc, generator=g)
+    w = torch.randn(R, S, Cc, K, generator=g) * (2.0 / (R * S * Cc)) ** 0.5
+    d = ops.conv_desc(N, H, W, Cc, K, R, S, stride, padding)
+    rows = N * H * W
+    lo_off = -(-rows * Cc * 2 // 256) * 256
+    planes = torch.zeros(lo_off * 2, dtype=torch.uint8, device=device)
+    plan = ops.Plan(device, eager=True)
+    ops.bn_relu_split(plan, x.to(device), torch.ones(Cc, device=device), torch.zeros(Cc, device=device), 1, planes,
+                      lo_off, rows, Cc)
+    wsplit = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=device)
+    ops.conv2d_split3_prepare(plan, d, w.to(device), wsplit)
+    tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=device)
+    y1 = torch.full((N, d.OH, d.OW, K), float("nan"), device=device)
+    y3 = torch.full_like(y1, float("nan"))
+    st = torch.zeros(ops.conv2d_fwd_split3_stats_rows(d), 2, K, device=device)
+    ops.conv2d_fwd_split3p(plan, d, planes, lo_off, wsplit, y1, st, tail_ws=tws, terms=1)
+    ops.conv2d_fwd_split3p(plan, d, planes, lo_off, wsplit, y3, None, tail_ws=tws, terms=3)
+    torch.cuda.synchronize()
+    xq = (x * 0.25).to(torch.float16).double() * 4.0
+    wq = (w * 1024.0).to(torch.float16).double() / 1024.0
+    conv = lambda a, b: torch.nn.functional.conv2d(a.permute(0, 3, 1, 2), b.permute(3, 2, 0, 1),  # noqa: E731
+                                                   padding=(R // 2, S // 2)).permute(0, 2, 3, 1)
+    ref1, ref3 = conv(xq, wq), conv(x.double(), w.double())
+    close(y1, ref1, tol=2e-6, what="fp16-operand conv vs conv of rounded operands %s" % (case,))
+    close(y3, ref3, tol=2e-6, what="split conv %s" % (case,))
+    cost = float((ref1 - ref3).abs().max() / ref3.abs().max())
+    assert 1e-5 < cost < 5e-3, cost                  # what 11-bit operands cost on one layer
+    close(st[:, 0].sum(0), ref1.reshape(-1, K).sum(0), tol=2e-4, what="statistics of the fp16-operand conv")
