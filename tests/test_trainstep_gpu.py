@@ -379,3 +379,39 @@ def test_configs2_two_skip_batch64(device):
     for _ in range(3):
         r3 = tr.train_step(None, eps=eps)
     assert r3["mse"] < r1["mse"]
+
+
+def test_sharded_step_accumulates_like_data_parallel(device):
+    """`Trainer.train_step_sharded` (bench.py --scaling strong): two shards of 2 images run one after the other with
+    accumulated gradients and ONE Adam update = the update a 2-rank data-parallel step would make (each shard
+    normalised with its own batch statistics, gradient = mean of the shard gradients): checked against TF-1 Adam in
+    fp64 on the mean of the gradients of two separate single-shard steps from the same state."""
+    from oracle import trainer as otr
+
+    lr = 1e-3
+    tr, orc, sess = build(device, 1, False, 2, lr=lr)
+    st = sess.store
+    shards = [otr.synthetic_batch(2, seed=200 + i) for i in range(2)]
+    w0, bn0 = st.flat["train"].clone(), st.flat["state"].clone()
+    grads = []
+    for ac, mf, vid, eps in shards:          # per-shard gradients from the same weights (BN state restored each time)
+        st.flat["train"].copy_(w0)
+        st.flat["state"].copy_(bn0)
+        st.adam_m.zero_()
+        st.adam_v.zero_()
+        tr.global_step = 0
+        tr.train_step((ac, mf, vid), eps=eps)
+        grads.append(st.grad.clone())
+    st.flat["train"].copy_(w0)
+    st.flat["state"].copy_(bn0)
+    st.adam_m.zero_()
+    st.adam_v.zero_()
+    tr.global_step = 0
+    out = tr.train_step_sharded([(s[0], s[1], s[2]) for s in shards], eps=[s[3] for s in shards])
+    gmean = (grads[0].double() + grads[1].double()) / 2
+    want, _, _ = tf_adam_fp64(w0, gmean.float(), torch.zeros_like(w0), torch.zeros_like(w0), 1, lr)
+    got = st.flat["train"].double()
+    assert float((got - want).abs().max()) <= 2e-6 * max(float(want.abs().max()), 1e-3)
+    assert tr.global_step == 1 and np.isfinite(out["loss"])
+    # the accumulated buffer is what Adam saw: sum of the shard gradients (scale 1/2 folded into the optimiser)
+    assert float((st.grad.double() - (grads[0].double() + grads[1].double())).abs().max()) <= 1e-6 * float(gmean.abs().max() * 2 + 1e-12)
