@@ -287,3 +287,48 @@ def test_reader_on_hand_built_known_answer_bundle(tmp_path):
     open(bad + ".index", "wb").write(bi)
     with pytest.raises(IOError):
         tfio.list_checkpoint(bad, verify=True)
+
+
+def test_record_readers_property_based(tmp_path):
+    """random record sets (sizes 0 ... 70 kB, GZIP or plain): the native C++ reader, the Python reader and the
+    writer's input agree byte for byte; random SequenceExamples decode to what was put in (hypothesis)"""
+    from hypothesis import given, settings
+    from hypothesis import strategies as hst
+
+    path = str(tmp_path / "p.tfrecord")
+
+    @settings(max_examples=20, deadline=None)
+    @given(hst.lists(hst.binary(min_size=0, max_size=70000), min_size=0, max_size=6), hst.booleans())
+    def roundtrip(recs, gz):
+        tfio.write_tfrecord(path, recs, compression="GZIP" if gz else None)
+        assert [bytes(r) for r in tfio.read_tfrecord_native(path)] == recs == list(tfio.read_tfrecord(path))
+
+    roundtrip()
+
+    @settings(max_examples=15, deadline=None)
+    @given(hst.integers(1, 4), hst.integers(1, 5), hst.integers(1, 6), hst.integers(1, 3), hst.integers(0, 2 ** 31 - 1))
+    def decode(steps, h, w, dch, seed):
+        rng = np.random.RandomState(seed % (2 ** 31))
+        ai = rng.rand(steps, h, w, dch).astype(np.float32)
+        sa = rng.randint(-2 ** 31, 2 ** 31 - 1, size=(steps, 7)).astype(np.int32)
+        ctx = OrderedDict([("classes", np.array([seed % 14])), ("location", np.array([seed % 61])),
+                           ("audio_image/height", np.array([h])), ("audio_image/width", np.array([w])),
+                           ("audio_image/depth", np.array([dch])), ("audio_data/mics", np.array([1])),
+                           ("audio_data/samples", np.array([7]))])
+        rec = tfio.build_sequence_example(ctx, OrderedDict([("audio/image", [a.tobytes() for a in ai]),
+                                                            ("audio/data", [s.tobytes() for s in sa])]))
+        d = tfio.decode_sequence_example_native(rec)
+        assert (d["action"], d["location"]) == (seed % 14, seed % 61)
+        np.testing.assert_array_equal(d["audio_images"], ai[:, ::-1, ::-1, :])
+        np.testing.assert_array_equal(d["audio_samples"], sa)
+        assert d["video_images"].size == 0
+
+    decode()
+
+    @settings(max_examples=50, deadline=None)
+    @given(hst.integers(0, 2 ** 64 - 1))
+    def varints(v):
+        b = tfio._put_varint(v)
+        assert tfio._varint(b + b"\x00", 0) == (v, len(b)) and 1 <= len(b) <= 10
+
+    varints()
