@@ -960,15 +960,18 @@ def test_deconv_dgrad_few_channels_direct(device):
     close(dx, x.grad, what="deconv dgrad (direct)")
 
 
-@pytest.mark.parametrize("case", [(32, 28, 38, 256, 1024, 1, 1, 1, "SAME"),     # 2128 tiles of 8 K steps: 4 whole rounds + a split tail
+@pytest.mark.parametrize("case", [(32, 28, 38, 256, 1024, 1, 1, 1, "SAME"),     # 2128 tiles of 8 K steps: 4.16 rounds
                                   (8, 56, 75, 128, 128, 3, 3, 1, "SAME"),       # 263 tiles < resident slots: every tile is split
                                   (5, 28, 38, 512, 256, 1, 1, 1, "SAME"),       # M = 5320: a row tail inside the last row tile
-                                  (32, 56, 75, 64, 256, 1, 1, 1, "SAME")])      # 2 K steps per tile
+                                  (32, 56, 75, 64, 256, 1, 1, 1, "SAME"),       # 2 K steps per tile: left whole
+                                  (32, 28, 38, 256, 256, 3, 3, 1, "SAME"),      # 532 tiles of 72 K steps: 1.04 rounds
+                                  (32, 14, 19, 2048, 512, 1, 1, 1, "SAME")])    # 268 tiles of 64 K steps
 def test_trunk_kernel_variants_agree(device, case):
-    """The trunk forward conv in its three forms — one tile per workgroup, persistent (a workgroup walks a tile list;
-    the next tile's first operand stage is requested under the current tile's last K step, output stores drain under
-    the next tile's MFMAs: counted vmcnt), persistent with 128-byte operand rows — against fp64 and against each
-    other: whole tiles bit-identical between the BK = 32 forms, tickets back at zero, statistics equal to rounding."""
+    """The trunk forward conv in its forms — one tile per workgroup, persistent (a workgroup walks a tile list; the
+    next tile's first operand stage is requested under the current tile's last K step, output stores drain under the
+    next tile's MFMAs: counted vmcnt), each with and without the tail split, persistent with 128-byte operand rows —
+    against fp64 and against each other: the BK = 32 forms give the same bits (same K ranges, same MFMA order, partials
+    added in range order whoever arrives last); tickets back at zero; statistics equal to rounding."""
     from acimg import _lib, ops
 
     N, H, W, Cc, K, R, S, stride, padding = case
@@ -988,8 +991,12 @@ def test_trunk_kernel_variants_agree(device, case):
     tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=device)
     outs = {}
     try:
-        for name, cfg in (("one-tile", dict(trunk_persistent=0)), ("persistent", dict(trunk_persistent=2)),
+        for name, cfg in (("one-tile whole", dict(trunk_persistent=0, tail_split=0)),
+                          ("persistent whole", dict(trunk_persistent=2, tail_split=0)),
+                          ("one-tile", dict(trunk_persistent=0)),
+                          ("persistent", dict(trunk_persistent=2)),
                           ("staggered", dict(trunk_persistent=2, trunk_stagger=50)),
+                          ("spread", dict(trunk_persistent=2, trunk_dma_pos=1)),
                           ("bk64", dict(trunk_persistent=2, trunk_bk=64)), ("auto", dict())):
             _lib.configure(**cfg)
             y = torch.full((N, d.OH, d.OW, K), float("nan"), device=device)
@@ -1008,10 +1015,16 @@ def test_trunk_kernel_variants_agree(device, case):
         flat = ref.reshape(-1, K)
         close(st[:, 0].sum(0), flat.sum(0), tol=2e-4, what="stats sum " + name)
         close(st[:, 1].sum(0), (flat * flat).sum(0), tol=2e-4, what="stats sumsq " + name)
-    y0 = outs["one-tile"][0]
-    for name in ("persistent", "staggered", "auto"):   # same K ranges, same MFMA order: the same bits
-        assert torch.equal(outs[name][0], y0), name
-    assert float((outs["bk64"][0] - y0).abs().max()) <= 4e-6 * float(y0.abs().max())
+    # whole tiles: the same K order in both kernels -> the same bits
+    assert torch.equal(outs["persistent whole"][0], outs["one-tile whole"][0])
+    # the same plan, different timing -> the same bits (partials are added in range order, whoever arrives last)
+    for name in ("persistent", "staggered", "spread", "auto"):
+        assert torch.equal(outs[name][0], outs["one-tile"][0]), name
+    for name in ("staggered", "spread"):
+        assert torch.equal(outs[name][1], outs["persistent"][1]), name
+    y0 = outs["one-tile whole"][0]
+    for name in outs:
+        assert float((outs[name][0] - y0).abs().max()) <= 4e-6 * float(y0.abs().max()), name
 
 
 @pytest.mark.parametrize("case", [(32, 28, 38, 256, 1024, 1, 1, 1, "SAME"), (8, 56, 75, 128, 128, 3, 3, 1, "SAME"),
