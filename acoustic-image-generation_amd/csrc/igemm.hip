@@ -1697,7 +1697,7 @@ static TailPlan pick_tail(int T, int P, int KI, int max_units) {
 static constexpr int TS_MAX_UNITS = 1024;      // partial slots (64 KiB each for a 128x128 tile)
 static constexpr size_t TS_COUNTER_BYTES = 4096;
 
-#ifdef ACIMG_STAMP
+#if defined(ACIMG_STAMP) || defined(ACIMG_ABLATE)
 static float* g_stamp_buf = nullptr;      // diagnostic build only (tools/build_stamp.sh): never in libacimg.so
 static int g_stamp_nostore = 0;           // ablation: the persistent kernel's output stores go out of range (dropped)
 extern "C" int acimg_debug_stamp_buffer(void* buf) {
@@ -1775,7 +1775,7 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
     p.ts_partial = ws ? reinterpret_cast<float*>(static_cast<char*>(ws) + TS_COUNTER_BYTES) : nullptr;
     const int n_units = tp.whole + tp.rem * tp.s;
     const dim3 grid(n_units);
-#ifdef ACIMG_STAMP
+#if defined(ACIMG_STAMP) || defined(ACIMG_ABLATE)
     p.slab = g_stamp_buf;
     p.flip = g_stamp_nostore;
 #endif

@@ -35,6 +35,7 @@
 // each part of a K step and of the epilogue and leaves them in a debug buffer (cdna_hip_programming.md §7, in-kernel
 // stamps).  The product build contains none of this.
 #ifdef ACIMG_STAMP
+#define ACIMG_ABLATE            // the ablation switches (IgemmParams::flip bits) come with the stamps, or alone
 #define ACIMG_STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(); unsigned st_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long st_begin = st_last;
 #define ACIMG_STAMP_AT(i)                                              \
     do {                                                               \
@@ -162,6 +163,9 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
     KCursorP kc{0, 0, 0, 0};
     // request K step `kc.q` of tile t into stage `slot` (B pieces before A pieces, 4 DMA instructions per wave)
     auto issue_b = [&](const Tile& t, int slot) {
+#ifdef ACIMG_ABLATE
+        if (p.flip & 4) return;                    // ablation: no weight-tile requests
+#endif
         char* st = lds + slot * STAGE;
         const unsigned kbyte = (unsigned)(kc.q * (BK * 2));
 #pragma unroll
@@ -176,6 +180,12 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
     auto issue_a = [&](const Tile& t, int slot) {      // ... and moves the cursor on
         char* st = lds + slot * STAGE;
         const int tapoff = ((kc.r * p.W + kc.s) * p.lda + kc.c0) * 2;
+#ifdef ACIMG_ABLATE
+        if (p.flip & 2) {                          // ablation: no activation-tile requests
+            kc = kcursor_next<BK>(kc, p.C, p.S);
+            return;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
             const int ih = t.a_ih0[j] + kc.r, iw = t.a_iw0[j] + kc.s;
@@ -233,7 +243,12 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             ACIMG_STAMP_AT(3);
 #endif
-            if (TERMS == 3) {
+#ifdef ACIMG_ABLATE
+            const bool lo_terms = !(p.flip & 8);   // ablation: only the hi x hi sweep
+#else
+            constexpr bool lo_terms = true;
+#endif
+            if (TERMS == 3 && lo_terms) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
                 else if (req == 2) issue_b(tb, slot ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (TERMS == 3) {
+            if (TERMS == 3 && lo_terms) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -341,8 +356,8 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
                 const int lr = tt / CH, c = tt - lr * CH;
                 const int m = m0 + (lr / WH) * WTM + h * WH + (lr % WH), n = n0 + 4 * c;
                 v[k] = tile[lr * CH + (c ^ (lr & (CH - 1)))];
-#ifdef ACIMG_STAMP
-                off[k] = (p.flip == 0 && m < e.M && n < e.Nstore) ? (unsigned)(((long)m * e.ldy + n) * 4) : OOB;
+#ifdef ACIMG_ABLATE
+                off[k] = ((p.flip & 1) == 0 && m < e.M && n < e.Nstore) ? (unsigned)(((long)m * e.ldy + n) * 4) : OOB;
 #else
                 off[k] = (m < e.M && n < e.Nstore) ? (unsigned)(((long)m * e.ldy + n) * 4) : OOB;
 #endif
