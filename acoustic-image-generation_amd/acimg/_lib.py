@@ -59,12 +59,15 @@ PROTOTYPES = {
     "acimg_conv2d_fwd_workspace": (_SZ, [_DP]),
     "acimg_conv2d_split3_weight_bytes": (_SZ, [_DP]),
     "acimg_conv2d_split3_prepare": (_I, [_DP, _P, _P, _P]),
+    "acimg_conv2d_bf16_prepare": (_I, [_DP, _P, _P, _P]),
     "acimg_conv2d_fwd_split3_stats_rows": (_I, [_DP]),
     "acimg_conv2d_fwd_split3_tiling": (_I, [_DP, C.POINTER(C.c_int)]),
     "acimg_conv2d_fwd_split3": (_I, [_DP, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "acimg_conv2d_fwd_bf16": (_I, [_DP, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "acimg_conv2d_split3_dgrad_weight_bytes": (_SZ, [_DP]),
     "acimg_conv2d_split3_prepare_dgrad": (_I, [_DP, _P, _P, _P]),
     "acimg_conv2d_dgrad_split3": (_I, [_DP, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
+    "acimg_conv2d_dgrad_bf16": (_I, [_DP, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "acimg_conv2d_split3_prepare_multi": (_I, [_I, _P, _P, _P, _P, _P]),
     "acimg_conv2d_fwd_split3p_workspace": (_SZ, [_DP]),
     "acimg_conv2d_fwd_split3p": (_I, [_DP, _P, _SZ, _P, _P, _P, _P, _SZ, _P]),
@@ -77,6 +80,7 @@ PROTOTYPES = {
     "acimg_conv2d_wgrad": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),
     "acimg_conv2d_wgrad_workspace": (_SZ, [_DP]),
     "acimg_conv2d_wgrad_split3": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),
+    "acimg_conv2d_wgrad_bf16": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),
     "acimg_deconv_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "acimg_deconv_dgrad": (_I, [_DP, _P, _I, _P, _P, _P, _I, _P, _SZ, _P, _P]),
     "acimg_deconv_wgrad": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),

@@ -324,8 +324,12 @@ def conv2d_fwd_split3_tiling(d):
     return out[0], out[1], out[2]
 
 
-def conv2d_split3_prepare(plan, d, w, wsplit):
-    plan.add("conv2d_split3_prepare", _L().acimg_conv2d_split3_prepare, C.byref(d), w, wsplit)
+def conv2d_split3_prepare(plan, d, w, wsplit, bf16=False):
+    """bf16: the forward image of the bf16-operand convs (acimg_conv2d_bf16_prepare)"""
+    if bf16:
+        plan.add("conv2d_bf16_prepare", _L().acimg_conv2d_bf16_prepare, C.byref(d), w, wsplit)
+    else:
+        plan.add("conv2d_split3_prepare", _L().acimg_conv2d_split3_prepare, C.byref(d), w, wsplit)
 
 
 def conv2d_split3_prepare_multi(plan, jobs):
@@ -334,8 +338,10 @@ def conv2d_split3_prepare_multi(plan, jobs):
              _JobsArg(jobs, "d"), _JobsArg(jobs, "w"), _JobsArg(jobs, "o"), _JobsArg(jobs, "m"))
 
 
-def conv2d_fwd_split3(plan, d, x, wsplit, y, in_scale=None, in_shift=None, in_relu=0, stats=None, bias=None):
-    plan.add("conv2d_fwd_split3", _L().acimg_conv2d_fwd_split3, C.byref(d), x, wsplit, bias, y, in_scale, in_shift,
+def conv2d_fwd_split3(plan, d, x, wsplit, y, in_scale=None, in_shift=None, in_relu=0, stats=None, bias=None, bf16=False):
+    """bf16: both operands rounded to bf16, one MFMA per product (acimg_conv2d_fwd_bf16; wsplit from the bf16 prepare)"""
+    fn = _L().acimg_conv2d_fwd_bf16 if bf16 else _L().acimg_conv2d_fwd_split3
+    plan.add("conv2d_fwd_bf16" if bf16 else "conv2d_fwd_split3", fn, C.byref(d), x, wsplit, bias, y, in_scale, in_shift,
              int(in_relu), stats)
 
 
@@ -347,8 +353,10 @@ def conv2d_split3_prepare_dgrad(plan, d, w, wsplit):
     plan.add("conv2d_split3_prepare_dgrad", _L().acimg_conv2d_split3_prepare_dgrad, C.byref(d), w, wsplit)
 
 
-def conv2d_dgrad_split3(plan, d, gy, ldgy, wsplit_t, dx, residual=None, ldres=0, mask=None, ldmask=0, lddx=0):
-    plan.add("conv2d_dgrad_split3", _L().acimg_conv2d_dgrad_split3, C.byref(d), gy, int(ldgy), wsplit_t, dx,
+def conv2d_dgrad_split3(plan, d, gy, ldgy, wsplit_t, dx, residual=None, ldres=0, mask=None, ldmask=0, lddx=0,
+                        bf16=False):
+    fn = _L().acimg_conv2d_dgrad_bf16 if bf16 else _L().acimg_conv2d_dgrad_split3
+    plan.add("conv2d_dgrad_bf16" if bf16 else "conv2d_dgrad_split3", fn, C.byref(d), gy, int(ldgy), wsplit_t, dx,
              int(lddx), residual, int(ldres), mask, int(ldmask))
 
 
@@ -394,10 +402,11 @@ def conv2d_wgrad(plan, d, x, gy, ldgy, dw, db=None):
              _WsPtr(plan.ws), _WsBytes(plan.ws))
 
 
-def conv2d_wgrad_split3(plan, d, x, gy, ldgy, dw, db=None):
+def conv2d_wgrad_split3(plan, d, x, gy, ldgy, dw, db=None, bf16=False):
     L = _L()
     plan.ws.require(L.acimg_conv2d_wgrad_workspace(C.byref(d)))
-    plan.add("conv2d_wgrad_split3", L.acimg_conv2d_wgrad_split3, C.byref(d), x, gy, int(ldgy), dw, db,
+    plan.add("conv2d_wgrad_bf16" if bf16 else "conv2d_wgrad_split3",
+             L.acimg_conv2d_wgrad_bf16 if bf16 else L.acimg_conv2d_wgrad_split3, C.byref(d), x, gy, int(ldgy), dw, db,
              _WsPtr(plan.ws), _WsBytes(plan.ws))
 
 

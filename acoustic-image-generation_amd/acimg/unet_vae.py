@@ -48,9 +48,12 @@ class UNetVAE(object):
 
     def __init__(self, input_shape=None, precision="split"):
         """precision: "split" = layers with >= 32 channels on both sides run on the split-MFMA kernels (forward
-        f16x3, gradients bf16x3: fp32-class results at 5x the fp32-MFMA rate), "f32" = exact-f32 MFMA everywhere"""
-        assert precision in ("split", "f32")
+        f16x3, gradients bf16x3: fp32-class results at 5x the fp32-MFMA rate), "f32" = exact-f32 MFMA everywhere,
+        "bf16" = BASELINE configs[1]: the same layers with both GEMM operands ROUNDED to bf16 (one MFMA per product,
+        fp32 accumulation; tensors, statistics, losses and Adam stay fp32) in forward, data and weight gradients"""
+        assert precision in ("split", "f32", "bf16")
         self.precision = precision
+        self._bf16 = precision == "bf16"
         self.scope = self.SCOPE
         self.height, self.width, self.channels = input_shape
         assert self.channels == self.CIN
@@ -58,7 +61,7 @@ class UNetVAE(object):
         self._wsplit_bufs = {}
 
     def _use_split(self, d):
-        return (self.precision == "split" and d.stride == 1 and d.C % 32 == 0 and d.K % 32 == 0 and
+        return (self.precision in ("split", "bf16") and d.stride == 1 and d.C % 32 == 0 and d.K % 32 == 0 and
                 d.N * d.OH * d.OW >= 16384)
 
     def _wsplit(self, name, nbytes, kind):
@@ -245,9 +248,9 @@ class UNetVAE(object):
             L.rows = ops.conv2d_fwd_split3_stats_rows(L.d)
             L.stats = z(L.rows, 2, kp)
             ws = self._wsplit(name, ops.conv2d_split3_weight_bytes(L.d), "fwd")
-            ops.conv2d_split3_prepare(plan, L.d, self._P(name + "/kernel"), ws)     # the kernel changes every step
+            ops.conv2d_split3_prepare(plan, L.d, self._P(name + "/kernel"), ws, bf16=self._bf16)     # the kernel changes every step
             ops.conv2d_fwd_split3(plan, L.d, x.ptr, ws, L.raw.ptr, stats=L.stats if self.training else None,
-                                  bias=self._P(name + "/bias"))
+                                  bias=self._P(name + "/bias"), bf16=self._bf16)
         else:
             ops.conv2d_fwd(plan, L.d, x.ptr, self._P(name + "/kernel"), self._P(name + "/bias"), L.raw.ptr,
                            stats=L.stats if self.training else None)
@@ -351,14 +354,17 @@ class UNetVAE(object):
             ops.bn_bwd(plan, L.raw.ptr, L.raw.ld, gy.ptr, gy.ld, L.scale, L.shift, L.save_mean, L.save_invstd,
                        self._P(L.bn + "/gamma"), L.y.pixels, up4(K), gy.ptr, gy.ld, self._G(L.bn + "/gamma"),
                        self._G(L.bn + "/beta"))
-            wg = ops.conv2d_wgrad_split3 if self._use_split(L.d) else ops.conv2d_wgrad
-            wg(plan, L.d, L.x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
+            if self._use_split(L.d):
+                ops.conv2d_wgrad_split3(plan, L.d, L.x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"),
+                                        self._G(name + "/bias"), bf16=self._bf16)
+            else:
+                ops.conv2d_wgrad(plan, L.d, L.x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
             if dx is not None and self._use_split(L.d):
                 wt = self._wsplit(name, ops.conv2d_split3_dgrad_weight_bytes(L.d), "dgrad")
                 ops.conv2d_split3_prepare_dgrad(plan, L.d, self._P(name + "/kernel"), wt)
                 ops.conv2d_dgrad_split3(plan, L.d, gy.ptr, gy.ld, wt, dx.ptr,
                                         res.ptr if res is not None else None, res.ld if res is not None else 0,
-                                        None, 0, lddx=dx.ld)
+                                        None, 0, lddx=dx.ld, bf16=self._bf16)
             elif dx is not None:
                 ops.conv2d_dgrad(plan, L.d, gy.ptr, gy.ld, self._P(name + "/kernel"), dx.ptr,
                                  res.ptr if res is not None else None, res.ld if res is not None else 0,

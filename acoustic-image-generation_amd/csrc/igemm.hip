@@ -991,7 +991,7 @@ static bool wgrad_halo_ok(const WgradParams& p) {
 
 // db (optional): fused bias gradient, db[n] = sum_m G[m][n] for n < Ngemm
 static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t st,
-                        bool split3 = false) {
+                        bool split3 = false, int terms = 3) {
     if ((p.C & 3) || (p.ldx & 3) || (p.ldg & 3) || (p.ldo & 3))
         return fail(ACIMG_EINVAL, "wgrad: C=%d ldx=%d ldg=%d ldo=%d must be multiples of 4", p.C, p.ldx, p.ldg, p.ldo);
     if (!aligned16(p.X) || !aligned16(p.G) || !aligned16(dw))
@@ -1053,7 +1053,10 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
     }
     const int rows = p.KK + (db ? 1 : 0);
     dim3 grid(cdiv(rows, bmo), cdiv(p.Ngemm, bn), p.splits);
-    if (split3 && bn == 128) hipLaunchKernelGGL((wgrad_split3_kernel<128>), grid, dim3(256), 65536, st, p);
+    if (split3 && terms == 1 && bn == 128) hipLaunchKernelGGL((wgrad_split3_kernel<128, 1>), grid, dim3(256), 65536, st, p);
+    else if (split3 && terms == 1 && bn == 64) hipLaunchKernelGGL((wgrad_split3_kernel<64, 1>), grid, dim3(256), 65536, st, p);
+    else if (split3 && terms == 1) hipLaunchKernelGGL((wgrad_split3_kernel<32, 1>), grid, dim3(256), 65536, st, p);
+    else if (split3 && bn == 128) hipLaunchKernelGGL((wgrad_split3_kernel<128>), grid, dim3(256), 65536, st, p);
     else if (split3 && bn == 64) hipLaunchKernelGGL((wgrad_split3_kernel<64>), grid, dim3(256), 65536, st, p);
     else if (split3) hipLaunchKernelGGL((wgrad_split3_kernel<32>), grid, dim3(256), 65536, st, p);
     else if (bn == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, st, p);
@@ -1519,6 +1522,15 @@ int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* ws
     return check_launch("split3_prepare");
 }
 
+int acimg_conv2d_bf16_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream) {
+    int rc = check_desc(d, "conv2d_bf16_prepare", true);
+    if (rc) return rc;
+    const int Ktot = d->R * d->S * d->C;
+    hipLaunchKernelGGL((split3_prepare_kernel<SplitBF16, false>), dim3(cdiv(Ktot, 32), cdiv(d->ldw, 32)), dim3(256), 0,
+                       (hipStream_t)stream, w, d->R * d->S, d->C, d->K, d->ldw, d->ldw, static_cast<__bf16*>(wsplit));
+    return check_launch("conv2d_bf16_prepare");
+}
+
 size_t acimg_conv2d_split3_dgrad_weight_bytes(const AcimgConvDesc* d) {
     return (size_t)2 * d->C * d->R * d->S * up4(d->K) * 2;
 }
@@ -1534,7 +1546,7 @@ int acimg_conv2d_split3_prepare_dgrad(const AcimgConvDesc* d, const float* w, vo
 }
 
 /* all of a model's trainable kernels in one launch: mode[i] = 0 forward image (acimg_conv2d_split3_prepare), 1 data-
- * gradient image (acimg_conv2d_split3_prepare_dgrad) */
+ * gradient image (acimg_conv2d_split3_prepare_dgrad), 2 forward bf16 image (acimg_conv2d_bf16_prepare) */
 int acimg_conv2d_split3_prepare_multi(int n, const AcimgConvDesc* const* descs, const float* const* w, void* const* out,
                                       const int* mode, void* stream) {
     if (n == 0) return ACIMG_OK;
@@ -1550,9 +1562,10 @@ int acimg_conv2d_split3_prepare_multi(int n, const AcimgConvDesc* const* descs, 
         if (!w[i] || !out[i]) return fail(ACIMG_EINVAL, "conv2d_split3_prepare_multi: null pointer in job %d", i);
         PrepJob& J = jobs.j[i];
         J.w = w[i]; J.out = out[i]; J.ntaps = d->R * d->S; J.C = d->C; J.K = d->K; J.ldw = d->ldw;
-        J.dgrad = mode[i] ? 1 : 0;
+        if (mode[i] < 0 || mode[i] > 2) return fail(ACIMG_EINVAL, "conv2d_split3_prepare_multi: job %d: mode is 0, 1 or 2", i);
+        J.dgrad = mode[i];
         int tiles_n;
-        if (J.dgrad) {
+        if (J.dgrad == 1) {
             if (d->K % 32 || d->K > d->ldw)
                 return fail(ACIMG_EINVAL, "conv2d_split3_prepare_multi: job %d: K must be a multiple of 32", i);
             J.Nrows = d->C;
@@ -1571,18 +1584,18 @@ int acimg_conv2d_split3_prepare_multi(int n, const AcimgConvDesc* const* descs, 
 }
 
 extern "C++" {
-template <typename TR>
+template <typename TR, int TERMS = 3>
 static int launch_split3(IgemmParams& p, hipStream_t st) {
     Split3Cfg c = pick_split3(p.M, p.Ngemm, true);
     dim3 grid(cdiv(p.M, c.bm), cdiv(p.Ngemm, c.bn), 1);
     if (c.bm == 128 && c.bn == 32)
-        hipLaunchKernelGGL((igemm_split3_kernel<128, 32, 4, 1, 256, TR>), grid, dim3(256), 2 * (2 * 128 * 64 + 2 * 32 * 64), st, p);
+        hipLaunchKernelGGL((igemm_split3_kernel<128, 32, 4, 1, 256, TR, TERMS>), grid, dim3(256), 2 * (2 * 128 * 64 + 2 * 32 * 64), st, p);
     else if (c.bm == 128 && c.bn == 128)
-        hipLaunchKernelGGL((igemm_split3_kernel<128, 128, 2, 4, 512, TR>), grid, dim3(512), 65536, st, p);
+        hipLaunchKernelGGL((igemm_split3_kernel<128, 128, 2, 4, 512, TR, TERMS>), grid, dim3(512), 65536, st, p);
     else if (c.bm == 64 && c.bn == 128)
-        hipLaunchKernelGGL((igemm_split3_kernel<64, 128, 1, 4, 256, TR>), grid, dim3(256), 2 * (2 * 64 * 64 + 2 * 128 * 64), st, p);
+        hipLaunchKernelGGL((igemm_split3_kernel<64, 128, 1, 4, 256, TR, TERMS>), grid, dim3(256), 2 * (2 * 64 * 64 + 2 * 128 * 64), st, p);
     else if (c.bm == 128 && c.bn == 64)
-        hipLaunchKernelGGL((igemm_split3_kernel<128, 64, 2, 2, 256, TR>), grid, dim3(256), 2 * (2 * 128 * 64 + 2 * 64 * 64), st, p);
+        hipLaunchKernelGGL((igemm_split3_kernel<128, 64, 2, 2, 256, TR, TERMS>), grid, dim3(256), 2 * (2 * 128 * 64 + 2 * 64 * 64), st, p);
     else
         return fail(ACIMG_EINVAL, "split3: unsupported tile %dx%d", c.bm, c.bn);
     return check_launch("igemm_split3");
@@ -1595,9 +1608,27 @@ static void epi_vec_flag(EpiParams& e) {
 }
 }  // extern "C++"
 
+static int fwd_split_onthefly(const AcimgConvDesc* d, const float* x, const void* wsplit, const float* bias, float* y,
+                              const float* in_scale, const float* in_shift, int in_relu, float* stats, void* stream,
+                              bool bf16);
+
 int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* wsplit, const float* bias,
                             float* y, const float* in_scale, const float* in_shift, int in_relu, float* stats,
                             void* stream) {
+    return fwd_split_onthefly(d, x, wsplit, bias, y, in_scale, in_shift, in_relu, stats, stream, false);
+}
+
+/* bf16 operands (activations and weights rounded to bf16, one MFMA per product, fp32 accumulation); weights from
+ * acimg_conv2d_bf16_prepare */
+int acimg_conv2d_fwd_bf16(const AcimgConvDesc* d, const float* x, const void* wsplit, const float* bias,
+                          float* y, const float* in_scale, const float* in_shift, int in_relu, float* stats,
+                          void* stream) {
+    return fwd_split_onthefly(d, x, wsplit, bias, y, in_scale, in_shift, in_relu, stats, stream, true);
+}
+
+static int fwd_split_onthefly(const AcimgConvDesc* d, const float* x, const void* wsplit, const float* bias, float* y,
+                              const float* in_scale, const float* in_shift, int in_relu, float* stats, void* stream,
+                              bool bf16) {
     int rc = check_desc(d, "conv2d_fwd_split3", true);
     if (rc) return rc;
     if (d->C % 32) return fail(ACIMG_EINVAL, "conv2d_fwd_split3: C=%d must be a multiple of 32", d->C);
@@ -1621,13 +1652,31 @@ int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* 
     e.Y = y; e.ldy = d->ldy; e.M = p.M; e.Nstore = d->K; e.act = d->act; e.bias = bias;
     e.stats = stats; e.stats_ld = d->ldw;
     epi_vec_flag(e);
+    if (bf16) return launch_split3<SplitBF16, 1>(p, (hipStream_t)stream);
     return launch_split3<SplitF16>(p, (hipStream_t)stream);
 }
 
 /* data gradient on the bf16x3 path (stride-1 convs): a forward conv of gy with the flipped/transposed kernel */
+static int dgrad_split_onthefly(const AcimgConvDesc* d, const float* gy, int ldgy, const void* wsplit_t, float* dx,
+                                int lddx, const float* residual, int ldres, const float* mask, int ldmask,
+                                void* stream, int terms);
+
 int acimg_conv2d_dgrad_split3(const AcimgConvDesc* d, const float* gy, int ldgy, const void* wsplit_t, float* dx,
                               int lddx, const float* residual, int ldres, const float* mask, int ldmask,
                               void* stream) {
+    return dgrad_split_onthefly(d, gy, ldgy, wsplit_t, dx, lddx, residual, ldres, mask, ldmask, stream, 3);
+}
+
+/* the same with gy and the kernel rounded to bf16, one MFMA per product (weights: acimg_conv2d_split3_prepare_dgrad) */
+int acimg_conv2d_dgrad_bf16(const AcimgConvDesc* d, const float* gy, int ldgy, const void* wsplit_t, float* dx,
+                            int lddx, const float* residual, int ldres, const float* mask, int ldmask,
+                            void* stream) {
+    return dgrad_split_onthefly(d, gy, ldgy, wsplit_t, dx, lddx, residual, ldres, mask, ldmask, stream, 1);
+}
+
+static int dgrad_split_onthefly(const AcimgConvDesc* d, const float* gy, int ldgy, const void* wsplit_t, float* dx,
+                                int lddx, const float* residual, int ldres, const float* mask, int ldmask,
+                                void* stream, int terms) {
     int rc = check_desc(d, "conv2d_dgrad_split3");
     if (rc) return rc;
     if (d->stride != 1 || d->K % 32 || d->K > ldgy || (ldgy & 3))
@@ -1650,6 +1699,7 @@ int acimg_conv2d_dgrad_split3(const AcimgConvDesc* d, const float* gy, int ldgy,
     e.Y = dx; e.ldy = lddx; e.M = p.M; e.Nstore = d->C; e.act = ACIMG_ACT_NONE;
     e.res = residual; e.ldres = ldres; e.mask = mask; e.ldmask = ldmask;
     epi_vec_flag(e);
+    if (terms == 1) return launch_split3<SplitBF16, 1>(p, (hipStream_t)stream);
     return launch_split3<SplitBF16>(p, (hipStream_t)stream);
 }
 
@@ -1883,8 +1933,22 @@ int acimg_tapconv_scatter(const AcimgConvDesc* d, const float* gy, int ldgy, flo
 }
 
 /* weight + bias gradient on the bf16x3 MFMA path (same contract as acimg_conv2d_wgrad) */
+static int wgrad_split_onthefly(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy, float* dw, float* db,
+                                void* ws, size_t ws_bytes, void* stream, int terms);
+
 int acimg_conv2d_wgrad_split3(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
                               float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+    return wgrad_split_onthefly(d, x, gy, ldgy, dw, db, ws, ws_bytes, stream, 3);
+}
+
+/* the same with x and gy rounded to bf16, one MFMA per product */
+int acimg_conv2d_wgrad_bf16(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
+                            float* dw, float* db, void* ws, size_t ws_bytes, void* stream) {
+    return wgrad_split_onthefly(d, x, gy, ldgy, dw, db, ws, ws_bytes, stream, 1);
+}
+
+static int wgrad_split_onthefly(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy, float* dw, float* db,
+                                void* ws, size_t ws_bytes, void* stream, int terms) {
     int rc = check_desc(d, "conv2d_wgrad_split3");
     if (rc) return rc;
     const int kp = up4(d->K);
@@ -1894,7 +1958,7 @@ int acimg_conv2d_wgrad_split3(const AcimgConvDesc* d, const float* x, const floa
     p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
     p.M = d->N * d->OH * d->OW; p.KK = d->R * d->S * d->C;
     p.G = gy; p.ldg = ldgy; p.Ngemm = kp; p.Nld = kp; p.ldo = d->ldw;
-    return launch_wgrad(p, dw, db, ws, ws_bytes, (hipStream_t)stream, true);
+    return launch_wgrad(p, dw, db, ws, ws_bytes, (hipStream_t)stream, true, terms);
 }
 
 }  // extern "C"

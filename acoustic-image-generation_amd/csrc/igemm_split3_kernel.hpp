@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void split3_prepare_kernel(const float* w, int
 struct PrepJob {
     const float* w;
     void* out;
-    int ntaps, C, K, ldw, Nrows, dgrad, tiles_k, block0;
+    int ntaps, C, K, ldw, Nrows, dgrad, tiles_k, block0;   // dgrad: 0 forward f16, 1 data-gradient bf16, 2 forward bf16
 };
 struct PrepJobs {
     PrepJob j[16];
@@ -132,14 +132,20 @@ __global__ __launch_bounds__(256) void split3_prepare_multi_kernel(const PrepJob
     const PrepJob& J = jobs.j[ji];
     const int lb = blockIdx.x - J.block0;
     const int bx = lb % J.tiles_k, by = lb / J.tiles_k;
-    if (J.dgrad)
+    if (J.dgrad == 1)
         split3_prepare_body<SplitBF16, true>(J.w, J.ntaps, J.C, J.K, J.ldw, J.Nrows, static_cast<__bf16*>(J.out), bx, by, tile);
+    else if (J.dgrad == 2)
+        split3_prepare_body<SplitBF16, false>(J.w, J.ntaps, J.C, J.K, J.ldw, J.Nrows, static_cast<__bf16*>(J.out), bx, by, tile);
     else
         split3_prepare_body<SplitF16, false>(J.w, J.ntaps, J.C, J.K, J.ldw, J.Nrows, static_cast<_Float16*>(J.out), bx, by, tile);
 }
 
-template <int BM, int BN, int WGM, int WGN, int NTHR, typename TR>
+// TERMS = 3: the split product (fp32-class results).  TERMS = 1: 16-BIT OPERAND ARITHMETIC - activations and weights are
+// rounded to TR::T (the hi halves) and multiplied once, fp32 accumulation: the arithmetic of a bf16 / fp16 mixed-
+// precision network (BASELINE configs[1], `acimg_conv2d_*_bf16`); the lo planes are neither written nor read.
+template <int BM, int BN, int WGM, int WGN, int NTHR, typename TR, int TERMS = 3>
 __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p) {
+    static_assert(TERMS == 1 || TERMS == 3, "1 = rounded operands, 3 = split product");
     typedef typename TR::V8 V8;
     constexpr int BK = 32;
     constexpr int ROWB = BK * 2;                  // bytes per LDS row (32 halves)
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
             split4<TR>(ra[j], hi, lo);
             const int off = row * ROWB + (((kq >> 1) ^ swz(row)) << 4) + ((kq & 1) << 3);
             *reinterpret_cast<uint2*>(st + off) = hi;
-            *reinterpret_cast<uint2*>(st + A_BYTES + off) = lo;
+            if (TERMS == 3) *reinterpret_cast<uint2*>(st + A_BYTES + off) = lo;
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) *reinterpret_cast<uint4*>(st + b_lds[j]) = rb[j];
@@ -291,27 +297,29 @@ __global__ __launch_bounds__(NTHR) void igemm_split3_kernel(const IgemmParams p)
             const int row = wm * WTM + i * 16 + li;
             const int off = row * ROWB + ((g ^ swz(row)) << 4);
             ah[i] = *reinterpret_cast<const V8*>(st + off);
-            al[i] = *reinterpret_cast<const V8*>(st + A_BYTES + off);
+            if (TERMS == 3) al[i] = *reinterpret_cast<const V8*>(st + A_BYTES + off);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int row = wn * WTN + j * 16 + li;
             const int off = 2 * A_BYTES + row * ROWB + ((g ^ swz(row)) << 4);
             bh[j] = *reinterpret_cast<const V8*>(st + off);
-            bl[j] = *reinterpret_cast<const V8*>(st + B_BYTES + off);
+            if (TERMS == 3) bl[j] = *reinterpret_cast<const V8*>(st + B_BYTES + off);
         }
         // rows of D = output channels (weights in the A slot), columns = pixels; small terms first.  All fragment
         // reads are issued before the first MFMA and the three terms of a product are a whole sweep apart, so no
         // MFMA waits on its predecessor's accumulator (per-accumulator order unchanged).
         __builtin_amdgcn_sched_barrier(0);
+        if (TERMS == 3) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(bl[j], ah[i], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(bl[j], ah[i], acc[i][j]);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(bh[j], al[i], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = TR::mfma(bh[j], al[i], acc[i][j]);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll

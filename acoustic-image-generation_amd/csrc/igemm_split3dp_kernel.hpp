@@ -350,17 +350,26 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
             ACIMG_STAMP_AT(10);                     // barrier
             f32x4 v[RH * CH / NTHR];
             unsigned off[RH * CH / NTHR];
+            // thread te reads 16-byte chunk c = te % CH of local rows lr0 + RSTEP k, lr0 = te / CH < RSTEP: the row of
+            // read k is a compile-time distance from the row of read 0 (32-bit offsets: the output is < 2 GiB)
+            constexpr int RSTEP = NTHR / CH;
+            static_assert(WH % RSTEP == 0 && (CH & (CH - 1)) == 0, "row-read mapping");
+            const unsigned lr0 = (unsigned)te / CH, c = (unsigned)te % CH;
+            const unsigned cx = c ^ lr0;
+            const int nn = n0 + 4 * (int)c;
+            const int mb = m0 + h * WH + (int)lr0;
+#ifdef ACIMG_ABLATE
+            const bool n_ok = nn < e.Nstore && (p.flip & 1) == 0;
+#else
+            const bool n_ok = nn < e.Nstore;
+#endif
+            const unsigned ob = ((unsigned)mb * (unsigned)e.ldy + (unsigned)nn) * 4u;
 #pragma unroll
             for (int k = 0; k < RH * CH / NTHR; ++k) {      // all row reads in flight before the first store
-                const int tt = te + k * NTHR;
-                const int lr = tt / CH, c = tt - lr * CH;
-                const int m = m0 + (lr / WH) * WTM + h * WH + (lr % WH), n = n0 + 4 * c;
-                v[k] = tile[lr * CH + (c ^ (lr & (CH - 1)))];
-#ifdef ACIMG_ABLATE
-                off[k] = ((p.flip & 1) == 0 && m < e.M && n < e.Nstore) ? (unsigned)(((long)m * e.ldy + n) * 4) : OOB;
-#else
-                off[k] = (m < e.M && n < e.Nstore) ? (unsigned)(((long)m * e.ldy + n) * 4) : OOB;
-#endif
+                const int rk = RSTEP * k;                                    // local row distance (compile time)
+                const int mk = (rk / WH) * WTM + rk % WH;                    // ... as a tile row distance
+                v[k] = tile[(lr0 + rk) * CH + (cx ^ (unsigned)(rk & (CH - 1)))];
+                off[k] = (n_ok && mb + mk < e.M) ? ob + (unsigned)(mk * e.ldy) * 4u : OOB;
             }
 #pragma unroll
             for (int k = 0; k < RH * CH / NTHR; ++k)
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
             }
         }
         // the two wave rows' partials (written before the first barrier above) -> this row block's statistics row
-        const int which = (te / BN) & 1, col = te % BN;
+        const int which = (int)(((unsigned)te / BN) & 1u), col = (int)((unsigned)te % BN);
         float sum = 0.f;
         if (e.stats) sum = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col];
         {

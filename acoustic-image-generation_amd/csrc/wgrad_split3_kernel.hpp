@@ -36,7 +36,8 @@ __device__ __forceinline__ b16x8 tr_frag(const char* tile, int row0, int colbyte
 }
 
 // BN = 128 or 64 output columns per block; 128 dW rows per block; 32 pixels per K step
-template <int BN>
+// TERMS = 1: both operands rounded to bf16 and multiplied once (`acimg_conv2d_wgrad_bf16`), lo planes unused
+template <int BN, int TERMS = 3>
 __global__ __launch_bounds__(256) void wgrad_split3_kernel(const WgradParams p) {
     constexpr int BMO = 128, BKR = 32;
     constexpr int PLANE = BKR * 256;          // bytes of one 32 x 128 bf16 plane (G planes use the same pitch)
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void wgrad_split3_kernel(const WgradParams p) 
             uint2 hi, lo;
             split4<SplitBF16>(rx[j], hi, lo);
             *reinterpret_cast<uint2*>(st + off) = hi;
-            *reinterpret_cast<uint2*>(st + PLANE + off) = lo;
+            if (TERMS == 3) *reinterpret_cast<uint2*>(st + PLANE + off) = lo;
         }
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void wgrad_split3_kernel(const WgradParams p) 
             uint2 hi, lo;
             split4<SplitBF16>(rg[j], hi, lo);
             *reinterpret_cast<uint2*>(st + 2 * PLANE + off) = hi;
-            *reinterpret_cast<uint2*>(st + 3 * PLANE + off) = lo;
+            if (TERMS == 3) *reinterpret_cast<uint2*>(st + 3 * PLANE + off) = lo;
         }
     };
 
@@ -172,17 +173,20 @@ __global__ __launch_bounds__(256) void wgrad_split3_kernel(const WgradParams p) 
         for (int j = 0; j < TM; ++j) {
             const int colbyte = (wm * 64 + j * 16) * 2;
             xh[j] = tr_frag(st, 8 * g, colbyte, lane);
-            xl[j] = tr_frag(st + PLANE, 8 * g, colbyte, lane);
+            if (TERMS == 3) xl[j] = tr_frag(st + PLANE, 8 * g, colbyte, lane);
         }
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int colbyte = (wn * WTN + i * 16) * 2;
             const b16x8 gh = tr_frag(st + 2 * PLANE, 8 * g, colbyte, lane);
-            const b16x8 gl = tr_frag(st + 3 * PLANE, 8 * g, colbyte, lane);
+            b16x8 gl;
+            if (TERMS == 3) gl = tr_frag(st + 3 * PLANE, 8 * g, colbyte, lane);
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
-                acc[i][j] = SplitBF16::mfma(gl, xh[j], acc[i][j]);
-                acc[i][j] = SplitBF16::mfma(gh, xl[j], acc[i][j]);
+                if (TERMS == 3) {
+                    acc[i][j] = SplitBF16::mfma(gl, xh[j], acc[i][j]);
+                    acc[i][j] = SplitBF16::mfma(gh, xl[j], acc[i][j]);
+                }
                 acc[i][j] = SplitBF16::mfma(gh, xh[j], acc[i][j]);
             }
         }

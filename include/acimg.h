@@ -151,6 +151,26 @@ int acimg_conv2d_dgrad_split3(const AcimgConvDesc* d, const float* gy, int ldgy,
                               int lddx, const float* residual, int ldres, const float* mask, int ldmask,
                               void* stream);
 
+/* bf16 OPERAND ARITHMETIC (BASELINE configs[1], "bf16"): the same three convolutions with both GEMM operands ROUNDED to
+ * bf16 and multiplied once per product (v_mfma_f32_16x16x32_bf16), fp32 accumulation; tensors in HBM, bias, batch
+ * statistics, losses and the optimizer stay fp32 (the mixed-precision recipe of a bf16 network: what tf's
+ * auto_mixed_precision / a bf16 cast at the conv inputs computes).  Same arguments, workspaces and epilogues as the
+ * split3 entry points they mirror; 1/3 of the MFMAs, half the LDS traffic, results carry bf16's 8 mantissa bits per
+ * operand (parity against the oracle WITH THE SAME ROUNDING: tests/test_unet_vae_gpu.py).
+ *   acimg_conv2d_bf16_prepare : forward weight image (bf16 [hi|lo][ldw][R*S*C], acimg_conv2d_split3_weight_bytes)
+ *   acimg_conv2d_fwd_bf16     : mirrors acimg_conv2d_fwd_split3
+ *   acimg_conv2d_dgrad_bf16   : mirrors acimg_conv2d_dgrad_split3 (weights from acimg_conv2d_split3_prepare_dgrad)
+ *   acimg_conv2d_wgrad_bf16   : mirrors acimg_conv2d_wgrad_split3
+ * acimg_conv2d_split3_prepare_multi: mode 2 = the bf16 forward image.
+ * Replaces: the conv2d calls of models/unet_architecture.py:159-213 under a bf16 policy. */
+int acimg_conv2d_bf16_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream);
+int acimg_conv2d_fwd_bf16(const AcimgConvDesc* d, const float* x, const void* wsplit, const float* bias,
+                          float* y, const float* in_scale, const float* in_shift, int in_relu, float* stats,
+                          void* stream);
+int acimg_conv2d_dgrad_bf16(const AcimgConvDesc* d, const float* gy, int ldgy, const void* wsplit_t, float* dx,
+                            int lddx, const float* residual, int ldres, const float* mask, int ldmask,
+                            void* stream);
+
 /* Pre-split activation format: a tensor [rows][C] is stored as TWO fp16 planes (hi at ptr, lo `lo_off`
  * bytes further), hi = f16(v/4), lo = f16(v/4 - hi): 22 mantissa bits in the same 4 bytes per element as
  * fp32.  The elementwise producers below write it (the BN affine + ReLU is already applied), and
@@ -209,6 +229,8 @@ size_t acimg_conv2d_wgrad_workspace(const AcimgConvDesc* d);
  * because the reduction runs over pixels.  Same workspace as acimg_conv2d_wgrad. */
 int acimg_conv2d_wgrad_split3(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
                               float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
+int acimg_conv2d_wgrad_bf16(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
+                            float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
 
 /* Transposed convolution, VALID (TF output = in*stride + max(kernel - stride, 0)):
  *   x : [N,H,W,C] low-res input, y : [N,OH,OW,K], w : [R][S][K][ldw>=C].

@@ -116,8 +116,43 @@ def init_params(model="UNet", seed=1240, dtype=torch.float32, bias_std=0.0, bn_j
     return p
 
 
-def forward(p, x, eps, model="UNet", training=True, relu_masks=None):
+def bf16_round(t):
+    """round-to-nearest-even to bf16, value kept in t's dtype (what `(__bf16)v` / v_cvt_pk_bf16_f32 do)"""
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+def bf16_layer(n, oh, ow, cin, cout, stride):
+    """the layers the product runs with bf16 operands under precision="bf16" (acimg/unet_vae.py `_use_split`)"""
+    return stride == 1 and cin % 32 == 0 and cout % 32 == 0 and n * oh * ow >= 16384
+
+
+class _Bf16Conv(torch.autograd.Function):
+    """BASELINE configs[1] 'bf16': a stride-1 SAME conv whose GEMM operands are rounded to bf16 in ALL THREE products,
+    fp32 (here: self.dtype) accumulation — forward conv(r(x), r(w)) + b; data gradient from (r(gy), r(w)); weight
+    gradient from (r(x), r(gy)); bias gradient = sum r(gy) (it rides in the weight-gradient GEMM as a column of ones).
+    Mirrors acimg_conv2d_fwd_bf16 / _dgrad_bf16 / _wgrad_bf16 (include/acimg.h)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xr, wr = bf16_round(x), bf16_round(w)
+        ctx.save_for_backward(xr, wr)
+        return tfsem.conv2d(xr, wr, b, 1, "SAME")
+
+    @staticmethod
+    def backward(ctx, gy):
+        xr, wr = ctx.saved_tensors
+        gr = bf16_round(gy)
+        with torch.enable_grad():
+            xl, wl = xr.detach().requires_grad_(True), wr.detach().requires_grad_(True)
+            y = tfsem.conv2d(xl, wl, None, 1, "SAME")
+            gx, gw = torch.autograd.grad(y, (xl, wl), gr)
+        return gx, gw, gr.sum((0, 1, 2))
+
+
+def forward(p, x, eps, model="UNet", training=True, relu_masks=None, bf16_operands=False):
     """x [N,H,W,cin], eps [N,Z].  Returns (out dict, new moving statistics dict).
+    bf16_operands: the conv layers `bf16_layer` selects see bf16-rounded operands in forward and both gradients
+    (the arithmetic of the product's precision="bf16"); everything else stays in x's dtype.
     relu_masks {layer name: 0/1 tensor}: the ReLU on/off pattern of the implementation under test, so that both
     sides differentiate the SAME piecewise-linear function (of the ~10^7 pre-activations of a batch a few hundred
     sit within fp32 rounding of zero; fp32 and fp64 evaluations of this very oracle differ by 1e-3..1e-2 in the
@@ -137,7 +172,11 @@ def forward(p, x, eps, model="UNet", training=True, relu_masks=None):
 
     def cbr(name, bnname, t, stride=1, padding="SAME"):
         k, b = p["%s/%s/kernel" % (sc, name)], p["%s/%s/bias" % (sc, name)]
-        t = tfsem.conv2d(t, k, b, stride, padding)
+        if bf16_operands and padding == "SAME" and bf16_layer(t.shape[0], t.shape[1], t.shape[2], k.shape[2], k.shape[3],
+                                                              stride):
+            t = _Bf16Conv.apply(t, k, b)
+        else:
+            t = tfsem.conv2d(t, k, b, stride, padding)
         bb = "%s/%s/" % (sc, bnname)
         y, mm, mv, _, _ = tfsem.batch_norm(t, p[bb + "gamma"], p[bb + "beta"], p[bb + "moving_mean"],
                                            p[bb + "moving_variance"], training, BN_MOMENTUM, BN_EPS)
@@ -190,8 +229,10 @@ def losses(p, x, fw, model="UNet"):
 class Oracle(object):
     """CPU train step: forward (batch statistics), losses, autograd, TF-1 Adam, moving-average update."""
 
-    def __init__(self, model="UNet", learning_rate=1e-4, seed=1240, dtype=torch.float32, params=None):
+    def __init__(self, model="UNet", learning_rate=1e-4, seed=1240, dtype=torch.float32, params=None,
+                 bf16_operands=False):
         self.model = model
+        self.bf16_operands = bf16_operands
         self.lr = learning_rate
         self.dtype = dtype
         self.params = OrderedDict((k, v.to(dtype).clone()) for k, v in (params or init_params(model, seed)).items())
@@ -201,7 +242,7 @@ class Oracle(object):
 
     def train_step(self, x, eps, apply=True, relu_masks=None):
         p = OrderedDict((k, v.clone().requires_grad_(trainable(k))) for k, v in self.params.items())
-        fw, stats = forward(p, x.to(self.dtype), eps.to(self.dtype), self.model, True, relu_masks)
+        fw, stats = forward(p, x.to(self.dtype), eps.to(self.dtype), self.model, True, relu_masks, self.bf16_operands)
         ls = losses(p, x.to(self.dtype), fw, self.model)
         names = [k for k in p if trainable(k)]
         grads = torch.autograd.grad(ls["loss"], [p[k] for k in names])

@@ -447,3 +447,35 @@ def test_f16_operand_mode_of_the_trunk_oracle():
     assert torch.equal(f16a, f16b)
     d = float((f16a - f32_).abs().max() / f32_.abs().max())
     assert 1e-5 < d < 0.5, d
+
+
+def test_bf16_operand_mode_of_the_unet_oracle():
+    """oracle/unet_vae.py `_Bf16Conv` (the reference statement of the product's precision="bf16", BASELINE
+    configs[1]): forward = conv of the bf16-rounded operands; data gradient from (r(gy), r(w)); weight gradient from
+    (r(x), r(gy)); bias gradient = sum r(gy) — checked against independent F.conv2d / conv_transpose2d statements;
+    the layer predicate matches acimg/unet_vae.py `_use_split`."""
+    import torch.nn.functional as F
+    from oracle import unet_vae as ouv
+
+    t = torch.tensor([1.0, 1.0 + 2.0 ** -8, 1.0 + 2.0 ** -8 + 2.0 ** -16, 3e38, 1e-30], dtype=torch.float64)
+    q = ouv.bf16_round(t)           # exact, tie -> even, above the tie; fp32's range is kept
+    assert q[0] == 1.0 and q[1] == 1.0 and q[2] == 1.0 + 2.0 ** -7 and abs(q[3] / 3e38 - 1) < 2.0 ** -8 and q[4] > 0
+    assert ouv.bf16_layer(2, 112, 149, 32, 32, 1) and not ouv.bf16_layer(2, 112, 149, 8, 32, 1)
+    assert not ouv.bf16_layer(2, 112, 149, 32, 32, 2) and not ouv.bf16_layer(2, 14, 18, 128, 128, 1)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 9, 11, 32, generator=g, dtype=torch.float64).requires_grad_(True)
+    w = (torch.randn(3, 3, 32, 32, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    b = torch.randn(32, generator=g, dtype=torch.float64).requires_grad_(True)
+    gy = torch.randn(2, 9, 11, 32, generator=g, dtype=torch.float64)
+    y = ouv._Bf16Conv.apply(x, w, b)
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), gy)
+    r = ouv.bf16_round
+    xr, wr, gr = r(x.detach()).permute(0, 3, 1, 2), r(w.detach()).permute(3, 2, 0, 1), r(gy).permute(0, 3, 1, 2)
+    assert torch.allclose(y.detach().permute(0, 3, 1, 2), F.conv2d(xr, wr, b.detach(), padding=1), rtol=0, atol=1e-12)
+    assert torch.allclose(gx.permute(0, 3, 1, 2), F.conv_transpose2d(gr, wr, padding=1), rtol=0, atol=1e-12)
+    want_gw = torch.stack([torch.stack([(F.pad(xr, (1, 1, 1, 1))[:, :, i:i + 9, j:j + 11].unsqueeze(1) *
+                                         gr.unsqueeze(2)).sum((0, 3, 4)) for j in range(3)]) for i in range(3)])
+    assert torch.allclose(gw, want_gw.permute(0, 1, 3, 2), rtol=0, atol=1e-11)     # [kh][kw][cin][cout]
+    assert torch.allclose(gb, gr.sum((0, 2, 3)), rtol=0, atol=1e-12)
+    # the rounding is in the gradients too: an un-rounded gy gives a different data gradient
+    assert not torch.allclose(gx.permute(0, 3, 1, 2), F.conv_transpose2d(gy.permute(0, 3, 1, 2), wr, padding=1), rtol=0, atol=1e-6)

@@ -118,3 +118,119 @@ def test_unet_vae_batch32_properties():
     assert last["loss"] < first["loss"], (first, last)
     st = sess.store.state_dict()
     assert all(torch.isfinite(v).all() for v in st.values())
+
+
+def _bf16(t):
+    return t.float().to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("case", [(2, 56, 75, 64, 64, 3), (4, 28, 38, 128, 96, 3), (2, 112, 149, 32, 32, 3),
+                                  (3, 40, 52, 64, 128, 1)])
+def test_bf16_operand_convs(case):
+    """BASELINE configs[1] "bf16": acimg_conv2d_fwd_bf16 / _dgrad_bf16 / _wgrad_bf16 are EXACTLY the convolutions of
+    the bf16-rounded operands accumulated in fp32 (one v_mfma_f32_16x16x32_bf16 per product): compared with fp64
+    convolutions of the same rounded operands (2e-5: fp32 accumulation order), incl. the fused bias gradient and the
+    batch-norm statistics of the forward."""
+    from acimg import ops
+
+    dev = torch.device("cuda:0")
+    N, H, W, Cc, K, R = case
+    g = torch.Generator().manual_seed(31 + Cc + K)
+    x = torch.randn(N, H, W, Cc, generator=g)
+    w = torch.randn(R, R, Cc, K, generator=g) * (2.0 / (R * R * Cc)) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1
+    gy = torch.randn(N, H, W, K, generator=g) * 1e-3
+    d = ops.conv_desc(N, H, W, Cc, K, R, R, 1, "SAME")
+    plan = ops.Plan(dev, eager=True)
+    xd, wd, bd, gyd = x.to(dev), w.to(dev), b.to(dev), gy.to(dev)
+    wimg = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=dev)
+    ops.conv2d_split3_prepare(plan, d, wd, wimg, bf16=True)
+    y = torch.full((N, H, W, K), float("nan"), device=dev)
+    rows = ops.conv2d_fwd_split3_stats_rows(d)
+    st = torch.zeros(rows, 2, K, device=dev)
+    ops.conv2d_fwd_split3(plan, d, xd, wimg, y, stats=st, bias=bd, bf16=True)
+    wt = torch.zeros(ops.conv2d_split3_dgrad_weight_bytes(d), dtype=torch.uint8, device=dev)
+    ops.conv2d_split3_prepare_dgrad(plan, d, wd, wt)
+    dx = torch.full((N, H, W, Cc), float("nan"), device=dev)
+    ops.conv2d_dgrad_split3(plan, d, gyd, K, wt, dx, bf16=True)
+    dw = torch.full((R, R, Cc, K), float("nan"), device=dev)
+    db = torch.full((K,), float("nan"), device=dev)
+    ops.conv2d_wgrad_split3(plan, d, xd, gyd, K, dw, db, bf16=True)
+    torch.cuda.synchronize()
+
+    xr = _bf16(x).permute(0, 3, 1, 2).requires_grad_(True)
+    wr = _bf16(w).permute(3, 2, 0, 1).requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, b.double(), padding=R // 2)
+    gr = _bf16(gy).permute(0, 3, 1, 2)
+    gx, gw = torch.autograd.grad(yr, (xr, wr), gr)
+    assert rel(y, yr.detach().permute(0, 2, 3, 1)) < 2e-5
+    flat = yr.detach().permute(0, 2, 3, 1).reshape(-1, K)
+    assert rel(st[:, 0].sum(0), flat.sum(0)) < 2e-4 and rel(st[:, 1].sum(0), (flat * flat).sum(0)) < 2e-4
+    assert rel(dx, gx.permute(0, 2, 3, 1)) < 2e-5
+    assert rel(dw, gw.permute(2, 3, 1, 0)) < 2e-5
+    assert rel(db, gr.sum((0, 2, 3))) < 2e-5
+    # and they are NOT the fp32-class result: the rounding is really there
+    y32 = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), b.double(),
+                                     padding=R // 2).permute(0, 2, 3, 1)
+    assert rel(y, y32) > 2e-4
+
+
+def test_unet_vae_bf16_train_step():
+    """BASELINE configs[1] (unet_architecture, bf16): one train step with precision="bf16" against the oracle computing
+    the SAME arithmetic (oracle/unet_vae.py `_Bf16Conv`: operands of the selected convs rounded to bf16 in forward,
+    data- and weight-gradient products; fp64 accumulation): outputs, losses, gradients, moving statistics.  Against
+    the un-rounded fp64 oracle the same step differs by 1e-2 in the output and by tens of percent in small gradients
+    (that is bf16, not an error): the 1e-3 bar of north_star is held by precision="split", and here against the
+    same-rounding oracle.  A pre-activation that differs by fp32 rounding between the two sides can round to the
+    neighbouring bf16 value (probability ~2e-5 per element): tolerance 1e-3 instead of 1e-4."""
+    from acimg.session import Session
+    from acimg.trainer_vae import TrainerVAE
+    from acimg import unet_vae
+    from oracle import unet_vae as ouv
+
+    dev = torch.device("cuda:0")
+    N = 2
+    model = "UNet"
+    sess = Session(dev)
+    tr = TrainerVAE(unet_vae.UNet(precision="bf16"), learning_rate=1e-3, session=sess)
+    tr._build_functions(batch_size=N)
+    params = ouv.init_params(model, seed=7, dtype=torch.float64, bias_std=0.05, bn_jitter=0.1)
+    tr.model.initialize(state={k: v.float() for k, v in params.items()})
+    x, eps = ouv.synthetic_batch(model, N, seed=11, dtype=torch.float64)
+    orc = ouv.Oracle(model, learning_rate=1e-3, dtype=torch.float64, params=params, bf16_operands=True)
+    r = tr.train_step(x.float().to(dev), eps.float().to(dev), apply=False)
+    torch.cuda.synchronize()
+    m = tr.model
+    nsplit = sum(1 for L in m.layers.values() if m._use_split(L.d))
+    assert nsplit >= 8, nsplit                       # the bf16 kernels really carry the model's large convs
+    masks = {name: (L.y.t[..., L.y.off:L.y.off + L.y.C] > 0).cpu() for name, L in m.layers.items()}
+    masks["dense"] = (m.dns1 > 0).cpu()
+    masks["conv2d"] = (m.c2d.t > 0).cpu()
+    free = orc.train_step(x, eps, apply=False)
+    shaped = {k: v.reshape(free["fw"]["masks"][k].shape) for k, v in masks.items()}
+    flips = sum(int((free["fw"]["masks"][k] != shaped[k]).sum()) for k in masks)
+    print("bf16 UNet: ReLU pattern differs from the same-rounding oracle's in %d places" % flips)
+    assert flips < 2000
+    ref = orc.train_step(x, eps, apply=False, relu_masks=shaped)
+    e_out = rel(m.output[..., :m.COUT], ref["fw"]["output"])
+    print("bf16 UNet: output rel err %.2e, mean %.2e" % (e_out, rel(m.mean, ref["fw"]["mean"])))
+    assert e_out < 1e-3
+    assert rel(m.mean, ref["fw"]["mean"]) < 1e-3 and rel(m.variance, ref["fw"]["variance"]) < 1e-3
+    for k in ("mse", "huber", "latent", "reg", "loss"):
+        assert abs(r[k] - ref["losses"][k]) <= 1e-4 * abs(ref["losses"][k]) + 1e-9, (k, r[k], ref["losses"][k])
+    grads = sess.store.grad_dict()
+    worst = ("", 0.0)
+    for name, gref in ref["grads"].items():
+        if name.endswith("/bias") and "/layer" in name:
+            continue
+        e = rel(grads[name], gref)
+        if e > worst[1]:
+            worst = (name, e)
+    print("bf16 UNet: worst gradient %s rel err %.2e" % worst)
+    assert worst[1] < 5e-3, worst
+    st = sess.store.state_dict()
+    for name, v in ref["new_stats"].items():
+        assert rel(st[name], v) < 1e-3, name
+    # it is bf16 arithmetic: the fp32-class oracle is NOT matched to 1e-3
+    free32 = ouv.Oracle(model, learning_rate=1e-3, dtype=torch.float64, params=params).train_step(x, eps, apply=False)
+    assert rel(m.output[..., :m.COUT], free32["fw"]["output"]) > 1e-3

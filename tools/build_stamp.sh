@@ -7,7 +7,7 @@ OUT=../../tools/debug
 mkdir -p $OUT
 for kind in stamp ablate; do
   DEF=$([ $kind = stamp ] && echo -DACIMG_STAMP || echo -DACIMG_ABLATE)
-  FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -Wno-pass-failed $DEF"
+  FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-function -Wno-pass-failed -fno-slp-vectorize $DEF"
   for f in igemm elementwise frontend hostutil triplet records; do
     /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $OUT/${kind}_$f.o &
   done

@@ -3,7 +3,8 @@ process in interleaved rounds (cdna_hip_programming.md rule 24), each against ma
 
     python tools/trunk_shapes.py [rounds] [variant=field:val,field:val ...]
 
-variants are AcimgConfig overrides (default: one tile per workgroup, always persistent, and the shipped per-layer choice).
+variants are AcimgConfig overrides (default: one tile per workgroup, always persistent, and the shipped per-layer choice);
+`lib:<path>` in a variant runs it on another build of the library (tools/build_ref_lib.sh), same process, same rounds.
 Also checks that every variant produces the same output (max |dy| / max |y|) and statistics as the first one."""
 import json
 import os
@@ -33,15 +34,27 @@ def main():
     variants = []
     for sp in specs:
         name, kv = sp.split("=", 1)
-        variants.append((name, {k: int(v) for k, v in (x.split(":") for x in kv.split(",") if x)}))
+        kvs = dict(x.split(":", 1) for x in kv.split(",") if x)
+        libpath = kvs.pop("lib", None)
+        variants.append((name, {k: int(v) for k, v in kvs.items()}, libpath))
     dev = torch.device("cuda:0")
-    _lib.load()
+    default_lib = _lib.load()
+    handles = {None: default_lib}
+    for _, _, path in variants:
+        if path not in handles:
+            _lib._lib, _lib.LIB_PATH = None, os.path.join(ROOT, path)
+            handles[path] = _lib.load()
+    _lib._lib = default_lib
+
+    def use(cfg, path):
+        _lib._lib = handles[path]
+        _lib.configure(**cfg)
     N = int(os.environ.get("TRUNK_BATCH", "32"))
     g = torch.Generator(device="cpu").manual_seed(1)
     rows_out = []
-    tot = {n: 0.0 for n, _ in variants}
+    tot = {n: 0.0 for n, _, _ in variants}
     tot_bound = 0.0
-    print("%-26s %2s %5s" % ("shape", "n", "tiles") + "".join(" %11s" % n for n, _ in variants) +
+    print("%-26s %2s %5s" % ("shape", "n", "tiles") + "".join(" %11s" % n for n, _, _ in variants) +
           "   bound us (mfma / hbm)   best/bound   max|dy|/max|y|")
     for (H, W, C, K, R, s, cnt) in SHAPES:
         d = ops.conv_desc(N, H, W, C, K, R, R, s, "SAME" if s == 1 else (1 if R == 3 else "SAME"))
@@ -57,9 +70,9 @@ def main():
         ops.conv2d_split3_prepare(plan, d, w, wsplit)
         nrow = ops.conv2d_fwd_split3_stats_rows(d)
         tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=dev)
-        outs, times = [], {n: [] for n, _ in variants}
-        for name, cfg in variants:
-            _lib.configure(**cfg)
+        outs, times = [], {n: [] for n, _, _ in variants}
+        for name, cfg, path in variants:
+            use(cfg, path)
             y = torch.full((N, d.OH, d.OW, K), float("nan"), device=dev)
             st = torch.zeros(nrow * 2 * K, device=dev)
             for _ in range(2):
@@ -67,8 +80,8 @@ def main():
             torch.cuda.synchronize()
             outs.append((y, st))
         for _ in range(rounds):
-            for (name, cfg), (y, st) in zip(variants, outs):
-                _lib.configure(**cfg)
+            for (name, cfg, path), (y, st) in zip(variants, outs):
+                use(cfg, path)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(5):
@@ -76,7 +89,9 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[name].append(e0.elapsed_time(e1) / 5 * 1e3)
-        _lib.configure()
+        for path in handles:
+            use({}, path)
+        _lib._lib = default_lib
         assert int(tws[:4096].view(torch.int32).abs().max()) == 0, "tickets not back at zero"
         y0, s0 = outs[0]
         err = max(float((y - y0).abs().max() / y0.abs().max()) for y, _ in outs[1:]) if len(outs) > 1 else 0.0
@@ -85,17 +100,17 @@ def main():
         fl = 2.0 * N * d.OH * d.OW * K * R * R * C
         byt = 4.0 * (N * H * W * C + K * R * R * C + N * d.OH * d.OW * K)
         b_m, b_h = fl / PEAK_X3 * 1e6, byt / HBM * 1e6
-        med = {n: sorted(times[n])[len(times[n]) // 4] for n, _ in variants}      # lower quartile of the rounds
+        med = {n: sorted(times[n])[len(times[n]) // 4] for n, _, _ in variants}      # lower quartile of the rounds
         best = min(med.values())
         tiles = -(-N * d.OH * d.OW // 128) * -(-K // 128)
         print("%-26s %2d %5d" % ("%dx%d %d->%d %dx%d/%d" % (H, W, C, K, R, R, s), cnt, tiles) +
-              "".join(" %11.1f" % med[n] for n, _ in variants) +
+              "".join(" %11.1f" % med[n] for n, _, _ in variants) +
               "   %6.1f (%5.1f / %5.1f)   %9.2f   %.1e (stats %.1e)" % (max(b_m, b_h), b_m, b_h, best / max(b_m, b_h), err, serr))
-        for n, _ in variants:
+        for n, _, _ in variants:
             tot[n] += cnt * med[n]
         tot_bound += cnt * max(b_m, b_h)
         rows_out.append(dict(shape=[H, W, C, K, R, s], count=cnt, us=med, bound_mfma=b_m, bound_hbm=b_h, err=err))
-    print("%-35s" % "trunk total (us, weighted by count)" + "".join(" %11.1f" % tot[n] for n, _ in variants) +
+    print("%-35s" % "trunk total (us, weighted by count)" + "".join(" %11.1f" % tot[n] for n, _, _ in variants) +
           "   %6.1f" % tot_bound)
     print(json.dumps({"rows": rows_out, "total": tot, "bound": tot_bound}), file=sys.stderr)
 
