@@ -1053,11 +1053,11 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
     }
     const int rows = p.KK + (db ? 1 : 0);
     dim3 grid(cdiv(rows, bmo), cdiv(p.Ngemm, bn), p.splits);
-    if (split3 && terms == 1 && bn == 128) hipLaunchKernelGGL((wgrad_split3_kernel<128, 1>), grid, dim3(256), 65536, st, p);
-    else if (split3 && terms == 1 && bn == 64) hipLaunchKernelGGL((wgrad_split3_kernel<64, 1>), grid, dim3(256), 65536, st, p);
+    if (split3 && terms == 1 && bn == 128) hipLaunchKernelGGL((wgrad_split3_kernel<128, 1, 512>), grid, dim3(512), 65536, st, p);
+    else if (split3 && terms == 1 && bn == 64) hipLaunchKernelGGL((wgrad_split3_kernel<64, 1, 512>), grid, dim3(512), 65536, st, p);
     else if (split3 && terms == 1) hipLaunchKernelGGL((wgrad_split3_kernel<32, 1>), grid, dim3(256), 65536, st, p);
-    else if (split3 && bn == 128) hipLaunchKernelGGL((wgrad_split3_kernel<128>), grid, dim3(256), 65536, st, p);
-    else if (split3 && bn == 64) hipLaunchKernelGGL((wgrad_split3_kernel<64>), grid, dim3(256), 65536, st, p);
+    else if (split3 && bn == 128) hipLaunchKernelGGL((wgrad_split3_kernel<128, 3, 512>), grid, dim3(512), 65536, st, p);
+    else if (split3 && bn == 64) hipLaunchKernelGGL((wgrad_split3_kernel<64, 3, 512>), grid, dim3(512), 65536, st, p);
     else if (split3) hipLaunchKernelGGL((wgrad_split3_kernel<32>), grid, dim3(256), 65536, st, p);
     else if (bn == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 128>), grid, dim3(256), 0, st, p);
     else if (bn == 64) hipLaunchKernelGGL((wgrad_f32_kernel<128, 64>), grid, dim3(256), 0, st, p);

@@ -37,24 +37,29 @@ __device__ __forceinline__ b16x8 tr_frag(const char* tile, int row0, int colbyte
 
 // BN = 128 or 64 output columns per block; 128 dW rows per block; 32 pixels per K step
 // TERMS = 1: both operands rounded to bf16 and multiplied once (`acimg_conv2d_wgrad_bf16`), lo planes unused
-template <int BN, int TERMS = 3>
-__global__ __launch_bounds__(256) void wgrad_split3_kernel(const WgradParams p) {
+// NTHR = 256: 4 waves of 64 dW rows x BN/2 columns; NTHR = 512: 8 waves of 64 x BN/4 (half the load / split work per
+// thread and twice the waves to hide it: the K step is paced by the register-path staging, not by the MFMAs)
+template <int BN, int TERMS = 3, int NTHR = 256>
+__global__ __launch_bounds__(NTHR) void wgrad_split3_kernel(const WgradParams p) {
     constexpr int BMO = 128, BKR = 32;
+    constexpr int WN = NTHR / 128;            // wave columns (2 wave rows of 64 dW rows each)
+    constexpr int XRS = NTHR / 32;            // X rows per pass
     constexpr int PLANE = BKR * 256;          // bytes of one 32 x 128 bf16 plane (G planes use the same pitch)
     constexpr int STAGE = 4 * PLANE;          // Xh | Xl | Gh | Gl
-    constexpr int WTN = BN / 2;
+    constexpr int WTN = BN / WN;
     constexpr int TM = 4, TN = WTN / 16;      // per wave: 64 dW rows x WTN columns
     constexpr int GQ = BN / 4;                // float4 per G row
-    constexpr int GRPP = 256 / GQ;            // G rows per pass
+    constexpr int GRPP = NTHR / GQ;           // G rows per pass
     constexpr int NG = BKR / GRPP;            // G float4 per thread
-    constexpr int NX = 4;                     // X float4 per thread (32 rows x 32 float4 / 256)
+    constexpr int NX = BKR / XRS;             // X float4 per thread (32 rows x 32 float4 / NTHR)
+    static_assert(WTN % 16 == 0 && NG >= 1 && NX >= 1, "tile / thread mapping");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN, wn = wid % WN;
     const int li = lane & 15, g = lane >> 4;
     const int kk0 = blockIdx.x * BMO, n0 = blockIdx.y * BN;
     const int m_begin = blockIdx.z * p.rows_per_split;
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(256) void wgrad_split3_kernel(const WgradParams p) 
 
     // ---- this thread's X column (4 consecutive kk) and pixel rows -----------------------------------
     const int xq = tid & 31;                  // float4 index inside the 128-wide row
-    const int xrow0 = tid >> 5;               // rows xrow0 + 8 j
+    const int xrow0 = tid >> 5;               // rows xrow0 + XRS j
     const int kk = kk0 + xq * 4;
     const bool kk_ok = kk < p.KK;
     const bool kk_ones = p.db_out != nullptr && kk == p.KK;
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(256) void wgrad_split3_kernel(const WgradParams p) 
         const int ohw = p.OH * p.OW;
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-            const int m = m_begin + xrow0 + 8 * j;
+            const int m = m_begin + xrow0 + XRS * j;
             x_img[j] = m / ohw;
             const int rem = m - x_img[j] * ohw;
             x_oh[j] = rem / p.OW;
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256) void wgrad_split3_kernel(const WgradParams p) 
     auto load_tiles = [&]() {
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-            const int m = mb_next + xrow0 + 8 * j;
+            const int m = mb_next + xrow0 + XRS * j;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < m_end) {
                 if (kk_ones) v.x = 1.f;
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void wgrad_split3_kernel(const WgradParams p) 
         char* st = lds + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
-            const int row = xrow0 + 8 * j;
+            const int row = xrow0 + XRS * j;
             const int f = (row & 3) | (((row >> 3) & 1) << 2);
             const int off = row * 256 + (((xq >> 2) ^ f) << 5) + ((xq & 3) << 3);
             uint2 hi, lo;
