@@ -772,6 +772,9 @@ static int pick_wgrad_splits(int M, int KK, int Ngemm, int bmo, int bn) {
 static void wgrad_tile(int Ngemm, int& bmo, int& bn) {
     bmo = 128;
     bn = Ngemm <= 16 ? 16 : (Ngemm <= 32 ? 32 : (Ngemm <= 64 ? 64 : 128));
+    // column counts just above a multiple of 128 (the generator's 133- and 144-column layers): 64-column tiles
+    // cover them with fewer padded columns (136 -> 192 instead of 256)
+    if (Ngemm > 64 && cdiv(Ngemm, 64) * 64 < cdiv(Ngemm, 128) * 128) bn = 64;
 }
 static size_t wgrad_ws_bytes(int M, int KK, int Ngemm, int ldo) {
     int bmo, bn;
@@ -1033,7 +1036,7 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
                            p.ldo, dw, nb1, db_slab, db);
         return check_launch("wgrad_reduce");
     }
-    if (split3) bn = p.Ngemm > 64 ? 128 : (p.Ngemm > 32 ? 64 : 32);
+    if (split3) bn = p.Ngemm > 64 ? 128 : (p.Ngemm > 32 ? 64 : 32);   // (64-column tiles for 144 columns: measured equal / slower)
     p.splits = pick_wgrad_splits(p.M, p.KK, p.Ngemm, bmo, bn);
     int rps = cdiv(p.M, p.splits);
     rps = ((rps + 31) / 32) * 32;
