@@ -776,10 +776,14 @@ static void wgrad_tile(int Ngemm, int& bmo, int& bn) {
     // cover them with fewer padded columns (136 -> 192 instead of 256)
     if (Ngemm > 64 && cdiv(Ngemm, 64) * 64 < cdiv(Ngemm, 128) * 128) bn = 64;
 }
+static int wgrad_split3_bn(int Ngemm) {      // column tile of the split-MFMA weight-gradient kernel
+    return Ngemm > 64 ? 128 : (Ngemm > 32 ? 64 : 32);   // (64-column tiles for 144 columns: measured equal / slower)
+}
 static size_t wgrad_ws_bytes(int M, int KK, int Ngemm, int ldo) {
+    // one sizing query serves acimg_conv2d_wgrad and acimg_conv2d_wgrad_split3 / _bf16: the larger of their slab counts
     int bmo, bn;
     wgrad_tile(Ngemm, bmo, bn);
-    const int s = pick_wgrad_splits(M, KK, Ngemm, bmo, bn);
+    const int s = std::max(pick_wgrad_splits(M, KK, Ngemm, bmo, bn), pick_wgrad_splits(M, KK, Ngemm, bmo, wgrad_split3_bn(Ngemm)));
     return s > 1 ? (size_t)(s + 1) * ((size_t)KK + 1) * ldo * sizeof(float) : 0;
 }
 
@@ -1036,7 +1040,7 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
                            p.ldo, dw, nb1, db_slab, db);
         return check_launch("wgrad_reduce");
     }
-    if (split3) bn = p.Ngemm > 64 ? 128 : (p.Ngemm > 32 ? 64 : 32);   // (64-column tiles for 144 columns: measured equal / slower)
+    if (split3) bn = wgrad_split3_bn(p.Ngemm);
     p.splits = pick_wgrad_splits(p.M, p.KK, p.Ngemm, bmo, bn);
     int rps = cdiv(p.M, p.splits);
     rps = ((rps + 31) / 32) * 32;

@@ -261,7 +261,8 @@ def test_split3_generator_convs(device, case):
 
 
 @pytest.mark.parametrize("case", [(2, 36, 48, 128, 128, 3, 3, 3, "SAME"), (3, 12, 16, 136, 128, 3, 3, 1, "SAME"),
-                                  (2, 36, 48, 12, 128, 3, 3, 1, "SAME"), (5, 9, 7, 64, 64, 3, 3, 1, "SAME")])
+                                  (2, 36, 48, 12, 128, 3, 3, 1, "SAME"), (5, 9, 7, 64, 64, 3, 3, 1, "SAME"),
+                                  (4, 14, 19, 2048, 144, 1, 1, 1, "SAME")])      # 144 columns: workspace sized for either tile rule
 def test_wgrad_split3_geometries(device, case):
     """strided (pool_2), padded-channel, tiny-C and ragged-M weight gradients on the bf16x3 kernel; gy read
     as a channel slice of a wider buffer"""
@@ -394,6 +395,7 @@ DGRAD_CASES = [
     (3, 1, 1, 152, 2304, 1, 1, 1, "VALID"),
     (2, 36, 48, 16, 32, 3, 3, 3, "SAME"),
     (2, 18, 24, 256, 128, 3, 3, 1, "SAME"),
+    (8, 12, 16, 128, 133, 3, 3, 1, "SAME"),     # 133 columns: 64-column weight-gradient tiles (3 x 64 instead of 2 x 128)
     # general stride (the strided-conv "pool" layers of the RGB / spectrogram U-Nets)
     (2, 17, 23, 8, 8, 3, 3, 2, "SAME"),
     (2, 12, 15, 32, 32, 2, 3, 2, "VALID"),
