@@ -160,16 +160,37 @@ def current_stream_handle(device=None):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+_SIDE = {}        # device -> (side stream, its workspace): shared by the plans of a device
+
+
+def side_lane(device):
+    """The SIDE LANE of a device: a second HIP stream with its own workspace.  Plans put the weight gradient of a layer
+    there (`Plan.add(..., side=True)` between `Plan.fork()` and `Plan.join()`), so that it runs beside the data
+    gradient of the same layer on the main stream: the two read the same gradient, write disjoint buffers and each
+    leaves part of the chip idle (slab tails, split-K hand-offs, 48-tile layers)."""
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = (torch.cuda.Stream(device=device), Workspace(device))
+    return _SIDE[key]
+
+
 class Plan(object):
-    """Ordered list of C-ABI calls.  eager=True runs each call as it is added."""
+    """Ordered list of C-ABI calls.  eager=True runs each call as it is added (everything on the current stream)."""
 
     def __init__(self, device=None, eager=False, ws=None):
         self.device = device
         self.eager = eager
         self.ws = ws if ws is not None else Workspace(device)
         self.calls = []      # (name, fn, raw args); args None => host hook
+        self.side = set()    # indices of `calls` launched on the side lane's stream
         self._resolved = None
         self._ws_version = -1
+        self._cuda = device is not None and torch.device(device).type == "cuda"
+
+    @property
+    def side_ws(self):
+        """workspace of the calls added with side=True (the main workspace when the plan is eager / not on a GPU)"""
+        return self.ws if (self.eager or not self._cuda) else side_lane(self.device)[1]
 
     def add_hook(self, pyfn):
         """a host callback run in order between kernel launches (e.g. fire a gradient all-reduce)"""
@@ -179,58 +200,102 @@ class Plan(object):
             self.calls.append(("hook", pyfn, None))
             self._resolved = None
 
-    def add(self, name, fn, *args):
+    def add(self, name, fn, *args, side=False):
         if self.eager:
             self.ws.allocate()
             rc = fn(*[_resolve(a) for a in args], current_stream_handle(self.device))
             _lib.check(rc, name)
         else:
+            if side and self._cuda:
+                self.side.add(len(self.calls))
             self.calls.append((name, fn, args))
             self._resolved = None
 
+    def fork(self):
+        """the side lane waits for everything issued on the main stream so far"""
+        if self.eager or not self._cuda:
+            return
+        ev, dev = torch.cuda.Event(), self.device
+
+        def _fork():
+            ev.record(torch.cuda.current_stream(dev))
+            side_lane(dev)[0].wait_event(ev)
+        self.add_hook(_fork)
+
+    def make_join(self):
+        """a callable that makes the main stream wait for everything issued on the side lane so far (for hooks that
+        decide at run time whether they consume side-lane results)"""
+        if self.eager or not self._cuda:
+            return lambda: None
+        ev, dev = torch.cuda.Event(), self.device
+
+        def _join():
+            ev.record(side_lane(dev)[0])
+            torch.cuda.current_stream(dev).wait_event(ev)
+        return _join
+
+    def join(self):
+        """the main stream waits for everything issued on the side lane so far"""
+        if self.eager or not self._cuda:
+            return
+        self.add_hook(self.make_join())
+
     def extend(self, other):
+        base = len(self.calls)
         self.calls.extend(other.calls)
+        self.side.update(base + i for i in other.side)
         self._resolved = None
+
+    def _versions(self):
+        return (self.ws.version, self.side_ws.version)
 
     def finalize(self):
         self.ws.allocate()
-        self._ws_version = self.ws.version
+        self.side_ws.allocate()
+        self._ws_version = self._versions()
         self._resolved = [(name, fn, None if args is None else tuple(_resolve(a) for a in args))
                           for name, fn, args in self.calls]
         return self
 
+    def _side_handle(self):
+        return side_lane(self.device)[0].cuda_stream if self.side else None
+
     def run(self, stream=None):
-        if self._resolved is None or self._ws_version != self.ws.version:
+        if self._resolved is None or self._ws_version != self._versions():
             self.finalize()
         st = stream if stream is not None else current_stream_handle(self.device)
-        for name, fn, args in self._resolved:
+        side_st, side = self._side_handle(), self.side
+        for i, (name, fn, args) in enumerate(self._resolved):
             if args is None:
                 fn()
                 continue
-            rc = fn(*args, st)
+            rc = fn(*args, side_st if i in side else st)
             if rc:
                 _lib.check(rc, name)
 
     def run_probed(self, indices, out, stream=None):
         """run(), bracketing the calls whose index is in `indices` with events on the launch stream;
         appends (index, start_event, end_event) to `out` (bench.py's live per-kernel timing)."""
-        if self._resolved is None or self._ws_version != self.ws.version:
+        if self._resolved is None or self._ws_version != self._versions():
             self.finalize()
         st = stream if stream is not None else current_stream_handle(self.device)
         ts = torch.cuda.current_stream(self.device)
+        side_st, side = self._side_handle(), self.side
         for i, (name, fn, args) in enumerate(self._resolved):
             if args is None:
                 fn()
                 continue
+            on_side = i in side
             if i in indices:
+                lane = side_lane(self.device)[0] if on_side else ts
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
-                e0.record(ts)
-                rc = fn(*args, st)
-                e1.record(ts)
+                e0.record(lane)
+                rc = fn(*args, side_st if on_side else st)
+                e1.record(lane)
                 out.append((i, e0, e1))
             else:
-                rc = fn(*args, st)
+                rc = fn(*args, side_st if on_side else st)
             if rc:
                 _lib.check(rc, name)
 
@@ -395,19 +460,22 @@ def conv2d_dgrad(plan, d, gy, ldgy, w, dx, residual=None, ldres=0, mask=None, ld
              int(ldres), mask, int(ldmask), _WsPtr(plan.ws), _WsBytes(plan.ws), _Tickets(plan.ws))
 
 
-def conv2d_wgrad(plan, d, x, gy, ldgy, dw, db=None):
+def conv2d_wgrad(plan, d, x, gy, ldgy, dw, db=None, side=False):
+    """side: launch on the plan's side lane (Plan.fork / Plan.join around it and the work it runs beside)"""
     L = _L()
-    plan.ws.require(L.acimg_conv2d_wgrad_workspace(C.byref(d)))
-    plan.add("conv2d_wgrad", L.acimg_conv2d_wgrad, C.byref(d), x, gy, int(ldgy), dw, db,
-             _WsPtr(plan.ws), _WsBytes(plan.ws))
+    ws = plan.side_ws if side else plan.ws
+    ws.require(L.acimg_conv2d_wgrad_workspace(C.byref(d)))
+    plan.add("conv2d_wgrad", L.acimg_conv2d_wgrad, C.byref(d), x, gy, int(ldgy), dw, db, _WsPtr(ws), _WsBytes(ws),
+             side=side)
 
 
-def conv2d_wgrad_split3(plan, d, x, gy, ldgy, dw, db=None, bf16=False):
+def conv2d_wgrad_split3(plan, d, x, gy, ldgy, dw, db=None, bf16=False, side=False):
     L = _L()
-    plan.ws.require(L.acimg_conv2d_wgrad_workspace(C.byref(d)))
+    ws = plan.side_ws if side else plan.ws
+    ws.require(L.acimg_conv2d_wgrad_workspace(C.byref(d)))
     plan.add("conv2d_wgrad_bf16" if bf16 else "conv2d_wgrad_split3",
              L.acimg_conv2d_wgrad_bf16 if bf16 else L.acimg_conv2d_wgrad_split3, C.byref(d), x, gy, int(ldgy), dw, db,
-             _WsPtr(plan.ws), _WsBytes(plan.ws))
+             _WsPtr(ws), _WsBytes(ws), side=side)
 
 
 def deconv_fwd(plan, d, x, w, bias, y):
@@ -424,11 +492,12 @@ def deconv_dgrad(plan, d, gy, ldgy, w, dx, mask=None, ldmask=0):
              int(ldmask), _WsPtr(plan.ws), _WsBytes(plan.ws), _Tickets(plan.ws))
 
 
-def deconv_wgrad(plan, d, x, gy, ldgy, dw, db=None):
+def deconv_wgrad(plan, d, x, gy, ldgy, dw, db=None, side=False):
     L = _L()
-    plan.ws.require(L.acimg_deconv_workspace(C.byref(d)))
-    plan.add("deconv_wgrad", L.acimg_deconv_wgrad, C.byref(d), x, gy, int(ldgy), dw, db,
-             _WsPtr(plan.ws), _WsBytes(plan.ws))
+    ws = plan.side_ws if side else plan.ws
+    ws.require(L.acimg_deconv_workspace(C.byref(d)))
+    plan.add("deconv_wgrad", L.acimg_deconv_wgrad, C.byref(d), x, gy, int(ldgy), dw, db, _WsPtr(ws), _WsBytes(ws),
+             side=side)
 
 
 def bn_finalize(plan, stats, rows, Cn, ldstats, count, gamma, beta, moving_mean, moving_var, scale,

@@ -118,7 +118,8 @@ class Trainer(object):
 
         def on_ready(name, p=p):
             if name in ready:
-                p.add_hook(lambda i=ready[name]: self._bucket_ready(i))
+                # the bucket's weight gradients run on the plan's side lane: joined before an exchange reads them
+                p.add_hook(lambda i=ready[name], join=p.make_join(): self._bucket_ready(i, join))
 
         modelac.record_backward(p, g.g_logit, modelimages.g_output, FLAGS.latent_loss / N if not ae else 0.0,
                                 on_ready=on_ready)
@@ -154,8 +155,10 @@ class Trainer(object):
         ma._register = _reuse
         return self._build_graph(N, mi, ma)
 
-    def _bucket_ready(self, i):
+    def _bucket_ready(self, i, join=None):
         if self.comm is not None and not self.hold_exchange:
+            if join is not None:
+                join()
             self.comm.bucket_ready(i)
 
     def enable_data_parallel(self, group=None):

@@ -13,6 +13,7 @@ concatenated [mean|std] weight; every backward kernel emits the PRE-activation g
 layer below (ReLU mask applied in the data-gradient epilogue from the saved activation), so no
 standalone ReLU / ReLU-grad / concat / slice pass touches HBM.
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -56,6 +57,8 @@ class UNetAc(object):
         assert precision in ("split", "f32")
         self.precision = precision
         self.split_min_rows = 16384      # below this the f32 kernel (64x64 tiles + split-K) fills the chip better
+        # backward: weight gradients on the plan's side lane (a second HIP stream), beside the data gradients
+        self.side_lane = os.environ.get("ACIMG_NO_SIDE_LANE") is None
         self._wsplit_bufs = {}
         self.scope = 'UNetAcRes'
         self.num_frames = num_frames
@@ -299,7 +302,8 @@ class UNetAc(object):
         g_feat: where to leave the gradient w.r.t. resnetfeature [N,12,16,12];
         kl_weight: FLAGS.latent_loss / N (trainer/mfcctrainer.py:56-59);
         on_ready(name): called at record time right after the kernels that finish layer `name`'s
-        weight gradient (lets the trainer place its gradient all-reduce hooks)."""
+        weight gradient were ADDED (lets the trainer place its gradient all-reduce hooks); weight gradients may still
+        be in flight on the side lane there: a consumer calls plan.join() first.  The plan ends joined."""
         on_ready = on_ready or (lambda name: None)
         N = self.N
         z = self.session.zeros
@@ -313,7 +317,14 @@ class UNetAc(object):
             """weight/bias gradient of conv `name`, and its data gradient into dx (if given)"""
             d, x, y = self._descs[name]
             wg = ops.conv2d_wgrad_split3 if (self.precision == "split" and d.K % 64 == 0) else ops.conv2d_wgrad
-            wg(plan, d, x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
+            # the weight gradients run on the side lane (a second stream, in layer order) beside the chain of data
+            # gradients on the main stream: a weight gradient only needs its layer's gy (fork = the side lane waits
+            # for it), every gradient buffer is written once, before the fork that publishes it, and nothing on the
+            # main stream waits for a weight gradient until a consumer of the parameter gradients joins
+            beside = dx is not None and self.side_lane
+            if beside:
+                plan.fork()
+            wg(plan, d, x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"), side=beside)
             if dx is not None and self._use_split(d):
                 wt = self._wsplit(name, ops.conv2d_split3_dgrad_weight_bytes(d), "dgrad")
                 self._prepare_job(plan, d, name, wt, 1)
@@ -344,8 +355,10 @@ class UNetAc(object):
             g_skip = None
         back("layer6/conv_1", g_c61, g_l6in)           # no mask: deconv output has no activation
         g_conv5, g_c51, g_conv4, g_c41 = gbuf(self.conv5), gbuf(self.c51), gbuf(self.conv4), gbuf(self.c41)
+        if self.side_lane:
+            plan.fork()
         ops.deconv_wgrad(plan, self.d_up, self.conv5.ptr, g_up.ptr, g_up.ld, self._G("upsample_1/kernel"),
-                         self._G("upsample_1/bias"))
+                         self._G("upsample_1/bias"), side=self.side_lane)
         ops.deconv_dgrad(plan, self.d_up, g_up.ptr, g_up.ld, self._P("upsample_1/kernel"), g_conv5.ptr,
                          self.conv5.ptr, self.conv5.ld)
         back("layer5/conv_2", g_conv5, g_c51, mask=self.c51)
@@ -371,8 +384,10 @@ class UNetAc(object):
         else:
             ops.latent_bwd(plan, self.heads_out, self.eps, self.sigma, g_z, 152, kl_weight, g_heads, N, Z)
         g_cat145 = z(N, h, w, 148)
+        if self.side_lane:
+            plan.fork()
         ops.conv2d_wgrad(plan, self.d_heads, self.cat145, g_heads, self.hn, self._G("heads/kernel"),
-                         self._G("heads/bias"))
+                         self._G("heads/bias"), side=self.side_lane)
         ops.conv2d_dgrad(plan, self.d_heads, g_heads, self.hn, self._P("heads/kernel"), g_cat145)
         on_ready("heads")
         # through the two min-max normalisations
@@ -388,6 +403,7 @@ class UNetAc(object):
         back("layer1/pool_2", g_pool1, g_conv1, mask=self.conv1, res=g_skip)
         back("layer1/conv_2", g_conv1, g_c11, mask=self.c11)
         back("layer1/conv_1", g_c11, None)
+        plan.join()           # every parameter gradient of the generator is complete from here on
         self._grad_bufs = dict(g_conv7=g_conv7, g_l6in=g_l6in, g_conv5=g_conv5, g_net=g_net, g_z=g_z,
                                g_heads=g_heads, g_cat145=g_cat145, g_conv2_0=g_conv2_0, g_conv1=g_conv1,
                                g_c11=g_c11)

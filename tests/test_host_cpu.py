@@ -315,3 +315,34 @@ def test_library_reads_no_environment_and_configure_validates(lib):
     bad.split3_tile_bm, bad.split3_tile_bn = 96, 96
     assert lib.acimg_configure(C.byref(bad)) == -1 and "tile" in _lib.last_error()
     assert lib.acimg_configure(None) == -1
+
+
+def test_plan_side_lane_bookkeeping():
+    """ops.Plan: calls added with side=True are remembered by index (and re-based by extend); fork / join are host
+    hooks; without a GPU (or in eager mode) everything stays on the one stream and the one workspace"""
+    from acimg import ops
+
+    a = ops.Plan("cpu")
+    a.add("x", lambda *args: 0, 1)
+    a.fork()
+    a.add("y", lambda *args: 0, 2, side=True)
+    a.join()
+    assert a.side == set() and len(a.calls) == 2 and a.side_ws is a.ws          # no GPU: one lane
+
+    class FakeCudaPlan(ops.Plan):
+        def __init__(self):
+            ops.Plan.__init__(self, "cpu")
+            self._cuda = True
+
+        @property
+        def side_ws(self):
+            return self.ws
+    b = FakeCudaPlan()
+    b.add("x", lambda *args: 0, 1)
+    b.add("w", lambda *args: 0, 2, side=True)
+    b.add("d", lambda *args: 0, 3)
+    c = FakeCudaPlan()
+    c.add("head", lambda *args: 0, 0)
+    c.extend(b)
+    c.add("w2", lambda *args: 0, 4, side=True)
+    assert b.side == {1} and c.side == {2, 4} and [n for n, _, _ in c.calls] == ["head", "x", "w", "d", "w2"]

@@ -415,3 +415,38 @@ def test_sharded_step_accumulates_like_data_parallel(device):
     assert tr.global_step == 1 and np.isfinite(out["loss"])
     # the accumulated buffer is what Adam saw: sum of the shard gradients (scale 1/2 folded into the optimiser)
     assert float((st.grad.double() - (grads[0].double() + grads[1].double())).abs().max()) <= 1e-6 * float(gmean.abs().max() * 2 + 1e-12)
+
+
+def test_side_lane_is_only_a_schedule(device, monkeypatch):
+    """The generator's weight gradients run on the plan's SIDE LANE (a second HIP stream, forked per layer from the
+    main stream's chain of data gradients, joined before anything reads a parameter gradient): the same kernels on
+    the same operands, so gradients, losses and the updated weights are BIT-IDENTICAL to the single-stream plan;
+    replaying the two-stream plan is bit-identical to itself (no race between the lanes)."""
+    from oracle import trainer as otr
+
+    ac, mf, vid, eps = otr.synthetic_batch(2, seed=77)
+    res = {}
+    for lane in (True, False):
+        if not lane:
+            monkeypatch.setenv("ACIMG_NO_SIDE_LANE", "1")       # host-side switch read when the model is constructed
+        tr, orc, sess = build(device, 1, False, 2)
+        assert tr.modelac.side_lane == lane
+        g = tr.graphs[2]
+        assert bool(g.plan_train.side) == lane
+        if lane:
+            assert len(g.plan_train.side) >= 14          # every layer with a data gradient beside it
+        out = tr.train_step((ac, mf, vid), eps=eps)
+        torch.cuda.synchronize()
+        res[lane] = (out, sess.store.grad.clone(), sess.store.flat["train"].clone())
+        if lane:
+            sess.store.load_state(orc.state_dict(), strict=True)
+            sess.store.adam_m.zero_()
+            sess.store.adam_v.zero_()
+            tr.global_step = 0
+            out2 = tr.train_step((ac, mf, vid), eps=eps)
+            torch.cuda.synchronize()
+            assert torch.equal(sess.store.grad, res[True][1]) and torch.equal(sess.store.flat["train"], res[True][2])
+            assert out2["loss"] == out["loss"]
+    assert torch.equal(res[True][1], res[False][1])
+    assert torch.equal(res[True][2], res[False][2])
+    assert res[True][0]["loss"] == res[False][0]["loss"]

@@ -1,5 +1,8 @@
 """Per-call report of the recorded train step, measured in place: every C-ABI call of the plan is bracketed with
 events (Plan.run_probed) over a few steps.  Run on the GPU box.  usage: python tools/op_report.py [batch] [first_call] [trainer_mask|unet_rgb|unet_sound]"""
+import os
+
+os.environ.setdefault("ACIMG_NO_SIDE_LANE", "1")   # per-op attribution: one stream (overlapped ops would be charged each other's time)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "acoustic-image-generation_amd"))
