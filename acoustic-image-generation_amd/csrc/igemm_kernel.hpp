@@ -85,6 +85,16 @@ __device__ __forceinline__ void epi_store4(const EpiParams& e, long opix, int cn
     }
 }
 
+// sum over the 16 lanes of a DPP row (= the 16 pixel rows of an MFMA accumulator fragment), result in every lane:
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror - four v_add_f32 with a DPP operand, no LDS
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
 // ---- shared epilogue: lane holds channels n4..n4+3 of pixel m for each (tm, tn) -------------------
 template <int BM, int BN, int WGM, int WGN, int NTHR, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[TM][TN], float* smem, int m0,
@@ -153,11 +163,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
                     s1 += v;
                     s2 += v * v;
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1 += __shfl_xor(s1, o, 64);
-                    s2 += __shfl_xor(s2, o, 64);
-                }
+                s1 = row16_sum(s1);      // the 16 pixel lanes of a fragment are one DPP row: four v_add_f32 with a DPP
+                s2 = row16_sum(s2);      // operand each (the __shfl_xor butterfly this replaces went through the LDS crossbar)
                 if (li == 0) {
                     const int col = wn * WTN + j * 16 + 4 * g + rg;
                     red[(wm * 2 + 0) * BN + col] = s1;

@@ -44,16 +44,6 @@ __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N == 0, "add the immediate");
 }
 
-// sum over the 16 lanes of a DPP row (= the 16 pixel rows of an MFMA accumulator fragment), result in every lane:
-// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror - four v_add_f32 with a DPP operand, no LDS
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
-    return v;
-}
-
 // linear workgroup id -> (row tile, column tile), see IgemmParams::ras_*
 __device__ __forceinline__ void raster_tile(const IgemmParams& p, int L, int& mt, int& nt) {
     const int T = p.ras_tiles_m * p.ras_tiles_n;

@@ -64,7 +64,7 @@ def main():
                 elif op == "dgrad":
                     ops.conv2d_dgrad_split3(plan, d, gy, K, out[2], out[0])
                 else:
-                    ops.conv2d_fwd_split3(plan, d, x, out[2], out[0])
+                    ops.conv2d_fwd_split3(plan, d, x, out[2], out[0], stats=out[1])
 
             for name, cfg, path in variants:
                 use(cfg, path)
@@ -77,7 +77,8 @@ def main():
                 else:
                     wi = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=dev)
                     ops.conv2d_split3_prepare(plan, d, w, wi)
-                    out = (torch.zeros(N, H, W, K, device=dev), None, wi)
+                    out = (torch.zeros(N, H, W, K, device=dev),
+                           torch.zeros(ops.conv2d_fwd_split3_stats_rows(d), 2, K, device=dev), wi)
                 run(out)
                 run(out)
                 torch.cuda.synchronize()
