@@ -192,12 +192,12 @@ class Plan(object):
         """workspace of the calls added with side=True (the main workspace when the plan is eager / not on a GPU)"""
         return self.ws if (self.eager or not self._cuda) else side_lane(self.device)[1]
 
-    def add_hook(self, pyfn):
+    def add_hook(self, pyfn, name="hook"):
         """a host callback run in order between kernel launches (e.g. fire a gradient all-reduce)"""
         if self.eager:
             pyfn()
         else:
-            self.calls.append(("hook", pyfn, None))
+            self.calls.append((name, pyfn, None))
             self._resolved = None
 
     def add(self, name, fn, *args, side=False):
@@ -220,7 +220,7 @@ class Plan(object):
         def _fork():
             ev.record(torch.cuda.current_stream(dev))
             side_lane(dev)[0].wait_event(ev)
-        self.add_hook(_fork)
+        self.add_hook(_fork, "fork")
 
     def make_join(self):
         """a callable that makes the main stream wait for everything issued on the side lane so far (for hooks that
@@ -238,7 +238,17 @@ class Plan(object):
         """the main stream waits for everything issued on the side lane so far"""
         if self.eager or not self._cuda:
             return
-        self.add_hook(self.make_join())
+        self.add_hook(self.make_join(), "join")
+
+    def shared_calls(self):
+        """indices of the calls (either lane) recorded between a fork and the next join: they may share the chip"""
+        out, open_ = set(), False
+        for i, (name, fn, args) in enumerate(self.calls):
+            if args is None:
+                open_ = True if name == "fork" else (False if name == "join" else open_)
+            elif open_ or i in self.side:
+                out.add(i)
+        return out
 
     def extend(self, other):
         base = len(self.calls)
@@ -429,13 +439,14 @@ def conv2d_fwd_split3p_workspace(d):
     return int(_L().acimg_conv2d_fwd_split3p_workspace(C.byref(d)))
 
 
-def conv2d_fwd_split3p(plan, d, x_planes, x_lo_off, wsplit, y, stats=None, tail_ws=None, terms=3):
-    """tail_ws: a uint8 buffer DEDICATED to split3p calls (tickets in its first 4 KiB must start, and stay, zero);
-    terms = 1: fp16 operand storage (acimg_conv2d_fwd_split1p: hi planes only)"""
+def conv2d_fwd_split3p(plan, d, x_planes, x_lo_off, wsplit, y, stats=None, tail_ws=None, terms=3, side=False):
+    """tail_ws: a uint8 buffer DEDICATED to split3p calls ON ONE LANE (tickets in its first 4 KiB must start, and stay,
+    zero; a call on the side lane brings its own); terms = 1: fp16 operand storage (acimg_conv2d_fwd_split1p: hi
+    planes only)"""
     nbytes = 0 if tail_ws is None else (tail_ws.numel() * tail_ws.element_size() if hasattr(tail_ws, "numel") else 0)
     fn = _L().acimg_conv2d_fwd_split3p if terms == 3 else _L().acimg_conv2d_fwd_split1p
     plan.add("conv2d_fwd_split3p" if terms == 3 else "conv2d_fwd_split1p", fn, C.byref(d), x_planes, int(x_lo_off),
-             wsplit, y, stats, tail_ws, int(nbytes))
+             wsplit, y, stats, tail_ws, int(nbytes), side=side)
 
 
 def bn_relu_split(plan, x, scale, shift, relu, out, lo_off, rows, Cn):
@@ -501,10 +512,10 @@ def deconv_wgrad(plan, d, x, gy, ldgy, dw, db=None, side=False):
 
 
 def bn_finalize(plan, stats, rows, Cn, ldstats, count, gamma, beta, moving_mean, moving_var, scale,
-                shift, decay=0.997, eps=1e-5, training=True, save_mean=None, save_invstd=None):
+                shift, decay=0.997, eps=1e-5, training=True, save_mean=None, save_invstd=None, side=False):
     plan.add("bn_finalize", _L().acimg_bn_finalize, stats, int(rows), int(Cn), int(ldstats),
              float(count), gamma, beta, moving_mean, moving_var, float(decay), float(eps),
-             int(bool(training)), scale, shift, save_mean, save_invstd)
+             int(bool(training)), scale, shift, save_mean, save_invstd, side=side)
 
 
 def bn_add_relu(plan, a, sa, ta, b, sb, tb, out, N, OH, OW, Cn, BH, BW, bstride):

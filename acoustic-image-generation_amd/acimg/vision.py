@@ -44,6 +44,8 @@ class ResNet50Model(object):
         self.precision = precision
         self._split = precision in ("f16x3", "f16")
         self._terms = 1 if precision == "f16" else 3
+        # the four projection shortcuts run on the plan's side lane (a second HIP stream) beside conv1 .. conv3
+        self.side_lane = os.environ.get("ACIMG_NO_SIDE_LANE") is None
         self.num_classes = num_classes
         self.height = input_shape[0]
         self.width = input_shape[1]
@@ -266,15 +268,21 @@ class ResNet50Model(object):
         """byte offset of the lo plane of a [rows, c] split-format tensor"""
         return -(-rows * c * 2 // 256) * 256
 
-    def _conv_bn_planes(self, plan, scope, xplanes, hw, cin, kh, kw, cout, stride, padding, out, training):
-        """like _conv_bn, for an input in split format (pre-normalised fp16 hi/lo planes)"""
+    def _conv_bn_planes(self, plan, scope, xplanes, hw, cin, kh, kw, cout, stride, padding, out, training, side=False):
+        """like _conv_bn, for an input in split format (pre-normalised fp16 hi/lo planes).  side: conv + finalize on the
+        plan's side lane (the projection shortcut beside conv1..conv3 of its unit), with a statistics buffer and a
+        tail workspace (tickets) of their own"""
         st = self.session.store
         P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
         d = ops.conv_desc(self.N, hw[0], hw[1], cin, cout, kh, kw, stride, padding, ldx=cin, ldy=up4(cout),
                           ldw=up4(cout))
         rows = ops.conv2d_fwd_split3_stats_rows(d)
-        self._stats_need = max(self._stats_need, rows * 2 * up4(cout))
-        stats = ops.LazyPtr(lambda: self.stats)
+        if side:
+            self._stats_side_need = max(getattr(self, "_stats_side_need", 0), rows * 2 * up4(cout))
+            stats = ops.LazyPtr(lambda: self.stats_side)
+        else:
+            self._stats_need = max(self._stats_need, rows * 2 * up4(cout))
+            stats = ops.LazyPtr(lambda: self.stats)
         if scope not in self._sp3:
             off = self._sp3_bytes
             self._sp3[scope] = off
@@ -282,13 +290,14 @@ class ResNet50Model(object):
             ops.conv2d_split3_prepare(self.plan_prepare, d, P(scope + "/weights"),
                                       ops.LazyPtr(lambda off=off: self.wsplit[off:]))
         off = self._sp3[scope]
-        if getattr(self, "_tail_ws", None) is None:
+        ws_attr = "_tail_ws_side" if side else "_tail_ws"
+        if getattr(self, ws_attr, None) is None:
             # partial sums + tile tickets of the trunk kernel's tail split; used by nothing else, zero at start
-            self._tail_ws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8,
-                                        device=self.session.device)
+            setattr(self, ws_attr, torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8,
+                                               device=self.session.device))
         ops.conv2d_fwd_split3p(plan, d, xplanes, self._lo_off(self.N * hw[0] * hw[1], cin),
                                ops.LazyPtr(lambda off=off: self.wsplit[off:]), out, stats if training else None,
-                               tail_ws=self._tail_ws, terms=self._terms)
+                               tail_ws=getattr(self, ws_attr), terms=self._terms, side=side)
         if not hasattr(self, "_aff_cache"):
             self._aff_cache = {}
         if scope not in self._aff_cache:
@@ -297,7 +306,7 @@ class ResNet50Model(object):
         b = scope + "/BatchNorm/"
         ops.bn_finalize(plan, stats if training else None, rows if training else 0, cout, up4(cout),
                         self.N * d.OH * d.OW if training else 0, P(b + "gamma"), P(b + "beta"),
-                        P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, BN_DECAY, BN_EPS, training)
+                        P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, BN_DECAY, BN_EPS, training, side=side)
         return d.OH, d.OW, sc, sh
 
     def _record_forward_split(self, plan, training):
@@ -319,6 +328,13 @@ class ResNet50Model(object):
         units = list(self._units())
         for i, (scope, din, d, db, s) in enumerate(units):
             last = i == len(units) - 1
+            beside = din != d and self.side_lane
+            if beside:
+                # the projection shortcut reads the same planes as conv1 and meets the main branch only in the unit's
+                # last pass: it runs on the plan's side lane beside conv1 .. conv3 (their tails leave slots)
+                plan.fork()
+                _, _, ssc, tsc = self._conv_bn_planes(plan, scope + "/shortcut", cur, (h, w), din, 1, 1, d, s, "SAME",
+                                                      self.arena_sc, training, side=True)
             oh1, ow1, s1, t1 = self._conv_bn_planes(plan, scope + "/conv1", cur, (h, w), din, 1, 1, db, 1, "SAME",
                                                     self.arena_r1, training)
             ops.bn_relu_split(plan, self.arena_r1, s1, t1, 1, self.planes_1, self._lo_off(N * h * w, db), N * h * w, db)
@@ -332,8 +348,11 @@ class ResNet50Model(object):
             out_lo = 0 if last else self._lo_off(N * oh3 * ow3, d)
             out32 = self.xfinal if last else None
             if din != d:
-                _, _, ssc, tsc = self._conv_bn_planes(plan, scope + "/shortcut", cur, (h, w), din, 1, 1, d, s, "SAME",
-                                                      self.arena_sc, training)
+                if beside:
+                    plan.join()
+                else:
+                    _, _, ssc, tsc = self._conv_bn_planes(plan, scope + "/shortcut", cur, (h, w), din, 1, 1, d, s,
+                                                          "SAME", self.arena_sc, training)
                 ops.bn_add_relu_split(plan, self.arena_r3, s3, t3, self.arena_sc, ssc, tsc, None, 0, out_planes, out_lo,
                                       out32, N, oh3, ow3, d, oh3, ow3, 1)
             else:
@@ -347,6 +366,9 @@ class ResNet50Model(object):
         ops.bn_relu(plan, self.raw_cm, scm, tcm, self.output, N * fh * fw, 12, 12, 12)
         if self.stats is None or self.stats.numel() < self._stats_need:
             self.stats = self.session.zeros(self._stats_need)
+        need = getattr(self, "_stats_side_need", 0)
+        if need and (getattr(self, "stats_side", None) is None or self.stats_side.numel() < need):
+            self.stats_side = self.session.zeros(need)
 
     def _stem_bn(self, plan, training):
         """conv1 (7x7/2 after 3+3 explicit zero padding) + BN statistics as a row-run conv (include/acimg.h,

@@ -385,6 +385,7 @@ def main():
         cand.setdefault(key, []).append((i, 2.0 * d.N * d.OH * d.OW * d.K * d.R * d.S * (3 if d.R == 7 else d.C)))
     tile = max(cand, key=lambda k: sum(f for _, f in cand[k]))
     probe_idx = set(i for i, _ in cand[tile])
+    shared = g.plan_train.shared_calls()
     flops = dict(cand[tile])
     alg_bytes = {}
     for i in probe_idx:
@@ -449,6 +450,11 @@ def main():
                 "traffic_source": prof["file"] if prof_ok else None,
                 "traffic_commit": prof["commit"] if prof_ok else None,
                 "launches_per_step": len(probe_idx),
+                # launches recorded between a fork and a join of the plan's side lane (the projection shortcuts and the
+                # conv1 .. conv3 they run beside): their event durations include the other lane's work
+                "launches_sharing_chip": len(probe_idx & shared),
+                "achieved_exclusive": (sum(flops[i] for i, _, _ in events if i not in shared) /
+                                       max(sum(e0.elapsed_time(e1) for i, e0, e1 in events if i not in shared), 1e-9) / 1e9),
                 "avg_launch_ms": ms / len(events), "avg_launch_gflop": fl / len(events) / 1e9,
                 "share_of_step_time": (ms / args.steps) / (dt / args.steps * 1e3)}
 

@@ -346,3 +346,13 @@ def test_plan_side_lane_bookkeeping():
     c.extend(b)
     c.add("w2", lambda *args: 0, 4, side=True)
     assert b.side == {1} and c.side == {2, 4} and [n for n, _, _ in c.calls] == ["head", "x", "w", "d", "w2"]
+    # calls between a fork and the next join (either lane) may share the chip: bench.py excludes them from
+    # `roofline.achieved_exclusive`
+    e = FakeCudaPlan()
+    e.add("a", lambda *args: 0, 1)
+    e.add_hook(lambda: None, "fork")
+    e.add("w", lambda *args: 0, 1, side=True)
+    e.add("d", lambda *args: 0, 1)
+    e.add_hook(lambda: None, "join")
+    e.add("z", lambda *args: 0, 1)
+    assert e.shared_calls() == {2, 3}
