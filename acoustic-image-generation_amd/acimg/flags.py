@@ -17,6 +17,9 @@ _DEFS = [
     ("moddrop", int, 0), ("l2", int, 0), ("project", int, 0), ("jointmvae", int, 0),
     ("onlyaudiovideo", int, 0), ("mfcc", int, 0), ("mfccmap", int, 0), ("num_skip_conn", int, 1),
     ("ae", int, 0), ("MSE", int, 1), ("huber_loss", int, 1),
+    # not a reference flag: 1 = Trainer.train() runs the two-lane pipeline (frozen trunk of the next batch beside the
+    # optimisation step of the current one; same numbers, the log line of an iteration one call later), 0 = one stream
+    ("pipeline", int, 1),
 ]
 
 

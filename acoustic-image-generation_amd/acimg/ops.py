@@ -160,18 +160,22 @@ def current_stream_handle(device=None):
     return torch.cuda.current_stream(device).cuda_stream
 
 
-_SIDE = {}        # device -> (side stream, its workspace): shared by the plans of a device
+_SIDE = {}        # (device, main stream) -> side stream;  device -> workspace of the side-lane calls
 
 
 def side_lane(device):
-    """The SIDE LANE of a device: a second HIP stream with its own workspace.  Plans put the weight gradient of a layer
-    there (`Plan.add(..., side=True)` between `Plan.fork()` and `Plan.join()`), so that it runs beside the data
-    gradient of the same layer on the main stream: the two read the same gradient, write disjoint buffers and each
-    leaves part of the chip idle (slab tails, split-K hand-offs, 48-tile layers)."""
-    key = str(device)
-    if key not in _SIDE:
-        _SIDE[key] = (torch.cuda.Stream(device=device), Workspace(device))
-    return _SIDE[key]
+    """The SIDE LANE of the current stream of a device: a second HIP stream (one per main stream, so that two plans
+    running on two streams do not couple through it) and the device's side workspace.  Plans put the weight gradient
+    of a layer there (`Plan.add(..., side=True)` between `Plan.fork()` and `Plan.join()`), so that it runs beside the
+    data gradient of the same layer on the main stream: the two read the same gradient, write disjoint buffers and
+    each leaves part of the chip idle (slab tails, split-K hand-offs, 48-tile layers)."""
+    dkey = str(device)
+    if dkey not in _SIDE:
+        _SIDE[dkey] = Workspace(device)
+    skey = (dkey, torch.cuda.current_stream(device).cuda_stream)
+    if skey not in _SIDE:
+        _SIDE[skey] = torch.cuda.Stream(device=device)
+    return _SIDE[skey], _SIDE[dkey]
 
 
 class Plan(object):
@@ -250,6 +254,13 @@ class Plan(object):
                 out.add(i)
         return out
 
+    def slice(self, lo, hi):
+        """calls [lo, hi) as a plan of their own (same workspace, same lanes)"""
+        p = Plan(self.device, ws=self.ws)
+        p.calls = self.calls[lo:hi]
+        p.side = set(i - lo for i in self.side if lo <= i < hi)
+        return p
+
     def extend(self, other):
         base = len(self.calls)
         self.calls.extend(other.calls)
@@ -283,9 +294,10 @@ class Plan(object):
             if rc:
                 _lib.check(rc, name)
 
-    def run_probed(self, indices, out, stream=None):
-        """run(), bracketing the calls whose index is in `indices` with events on the launch stream;
-        appends (index, start_event, end_event) to `out` (bench.py's live per-kernel timing)."""
+    def run_probed(self, indices, out, stream=None, offset=0):
+        """run(), bracketing the calls whose index (+ offset: position of this slice in the plan the indices refer to)
+        is in `indices` with events on the launch stream; appends (index, start_event, end_event) to `out` (bench.py's
+        live per-kernel timing)."""
         if self._resolved is None or self._ws_version != self._versions():
             self.finalize()
         st = stream if stream is not None else current_stream_handle(self.device)
@@ -296,14 +308,14 @@ class Plan(object):
                 fn()
                 continue
             on_side = i in side
-            if i in indices:
+            if i + offset in indices:
                 lane = side_lane(self.device)[0] if on_side else ts
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(lane)
                 rc = fn(*args, side_st if on_side else st)
                 e1.record(lane)
-                out.append((i, e0, e1))
+                out.append((i + offset, e0, e1))
             else:
                 rc = fn(*args, side_st if on_side else st)
             if rc:

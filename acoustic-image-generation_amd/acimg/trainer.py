@@ -55,6 +55,7 @@ class Trainer(object):
         self.log = print
         self.hold_exchange = False     # True while micro-batch gradients are being accumulated (train_step_sharded)
         self._acc = None
+        self._pipe = None              # state of the two-lane pipeline (train_step_pipelined)
 
     # ------------------------------------------------------------------------------------------------
     # graph construction
@@ -102,6 +103,7 @@ class Trainer(object):
         # ---- training step ----
         p = sess.new_plan()
         head(p)
+        head_calls = len(p.calls)
         p.extend(modelimages.plan_train)
         p.extend(modelac.plan_fwd)
         ops.recon_loss(p, modelac.output, g.acoustic, g.g_logit, g.sums, count, w_mse, w_hub)
@@ -126,6 +128,9 @@ class Trainer(object):
         modelimages.record_backward(p)
         p.add_hook(lambda: self._bucket_ready(0))
         g.plan_train = p
+        # the calls [head_calls, head_calls + frozen_calls) are the FROZEN trunk (train_step_pipelined's lane A)
+        g.head_calls = head_calls
+        g.frozen_calls = getattr(modelimages, "frozen_calls", None)
         # ---- evaluation step (is_training = 0: moving statistics; MSE only, :411-442) ----
         e = sess.new_plan()
         head(e)
@@ -174,6 +179,7 @@ class Trainer(object):
     def sync_moving_statistics(self):
         """collective: every rank ends up with the mean over ranks of the trunk's BN moving statistics
         (per-replica while training; one set for checkpoints and evaluation: SURVEY §8(e))"""
+        self.flush_pipeline()
         store = self.session.store
         rng = [(v.offset, v.numel) for n, v in store.vars.items() if v.group == "state" and "/moving_" in n]
         dp.average_moving_statistics(store.flat["state"], rng, getattr(self, "group", None))
@@ -206,6 +212,7 @@ class Trainer(object):
         tensors already resident in the graph's input buffers.  Returns {mse, huber, latent, reg, loss}
         (python floats; sync=False returns the device tensor instead and does not block)."""
         g = self.primary if batch is None else self._graph_for(int(batch[1].reshape(-1, 12).shape[0]))
+        self.flush_pipeline()
         if batch is not None:
             self._feed(g, batch, eps)
         else:
@@ -229,6 +236,115 @@ class Trainer(object):
         if not sync:
             return g.losses
         return self._scalars(g)
+
+    # ---- two-lane software pipeline -------------------------------------------------------------------------
+    def _pipeline(self, g):
+        """Lane A = the frozen trunk (no trainable variable is read: trainer/mfcctrainer.py:64 keeps it out of
+        var_list) up to `xfinal`; lane B = everything that reads or writes a trained variable: conv_map, the generator,
+        the losses, the backward pass, the gradient exchange, Adam.  Two HIP streams; per call lane A runs batch t + 1
+        while lane B runs batch t.  The arithmetic of every batch is the sequential step's, bit for bit: lane A's
+        inputs (images, frozen weights, its own moving statistics in order) do not depend on lane B, and lane B of batch
+        t + 1 starts behind lane B of batch t (same stream) and behind lane A of batch t + 1 (event).  The only buffer
+        the lanes share is `xfinal` (written by lane A's LAST call, read by conv_map forward and weight gradient): that
+        call waits for lane B of the previous batch."""
+        if self._pipe is not None and self._pipe["g"] is g:
+            return self._pipe
+        if g.frozen_calls is None or not self.modelimages._split:
+            raise RuntimeError("train_step_pipelined: needs the split-MFMA trunk (precision f16x3 / f16): its frozen part "
+                               "uses no shared workspace")
+        if self._pipe is not None:
+            self.flush_pipeline()
+        dev = self.session.device
+        full = g.plan_train
+        lo, cut = g.head_calls, g.head_calls + g.frozen_calls
+        assert full.calls[cut - 1][0] == "bn_add_relu_split", full.calls[cut - 1][0]     # the call that writes xfinal
+        # lane A is the caller's stream (where the one-stream step would run), lane B one more stream: with the two
+        # side lanes that is 4 HIP streams = the runtime's default number of hardware queues (streams beyond it share
+        # a queue and serialise)
+        cur = torch.cuda.current_stream(dev)
+        pipe = dict(g=g, a1=full.slice(lo, cut - 1), a2=full.slice(cut - 1, cut), a_off=lo,
+                    head=full.slice(0, lo), b=full.slice(cut, len(full.calls)), b_off=cut,
+                    sa=cur, sb=torch.cuda.Stream(device=dev),
+                    ev_a=torch.cuda.Event(), ev_b=torch.cuda.Event(), pending=False, b_ran=False)
+        pipe["sb"].wait_stream(cur)
+        self._pipe = pipe
+        return pipe
+
+    def _lane_b(self, pipe, probe=None):
+        """batch t's trained part on lane B (inputs already in the graph's buffers), Adam included"""
+        g = pipe["g"]
+        with torch.cuda.stream(pipe["sb"]):
+            pipe["sb"].wait_event(pipe["ev_a"])          # lane A has written xfinal for this batch
+            pipe["head"].run()
+            if probe is None:
+                pipe["b"].run()
+            else:
+                pipe["b"].run_probed(probe[0], probe[1], offset=pipe["b_off"])
+            store = self.session.store
+            scale = 1.0
+            if self.comm is not None and self.comm.enabled:
+                self.comm.wait()
+                scale = self.comm.grad_scale
+            self.global_step += 1
+            lr_t = ops.adam_lr_t(self.learning_rate, self.global_step)
+            rc = _lib.load().acimg_adam_step(store.flat["train"].data_ptr(), store.grad.data_ptr(),
+                                             store.adam_m.data_ptr(), store.adam_v.data_ptr(),
+                                             store.train_numel(), lr_t, 0.9, 0.999, 1e-8, scale,
+                                             ops.current_stream_handle(self.session.device))
+            _lib.check(rc, "adam_step")
+            pipe["ev_b"].record(pipe["sb"])
+        pipe["pending"], pipe["b_ran"] = False, True
+
+    def train_step_pipelined(self, batch=None, eps=None, probe=None):
+        """One call = one batch in, one optimisation step out, in steady state: the frozen trunk of THIS batch runs on
+        lane A while conv_map + generator + backward + Adam of the PREVIOUS batch run on lane B.  Returns the device
+        tensor of the previous batch's losses (None on the first call); `flush_pipeline()` finishes the last batch.
+        batch None: reuse the images / targets resident in the graph's buffers (bench.py)."""
+        g = self.primary if batch is None else self._graph_for(int(batch[1].reshape(-1, 12).shape[0]))
+        pipe = self._pipeline(g)
+        out = None
+        if pipe["pending"]:
+            self._lane_b(pipe, probe)
+            out = g.losses
+        with torch.cuda.stream(pipe["sa"]):              # lane A: this batch's frozen trunk
+            if batch is not None:
+                g.video.copy_(batch[2].reshape(g.N, 224, 298, 3), non_blocking=True)
+            if probe is None:
+                pipe["a1"].run()
+            else:
+                pipe["a1"].run_probed(probe[0], probe[1], offset=pipe["a_off"])
+            if pipe["b_ran"]:
+                pipe["sa"].wait_event(pipe["ev_b"])      # the previous batch no longer reads xfinal
+            pipe["a2"].run()
+            pipe["ev_a"].record(pipe["sa"])
+        with torch.cuda.stream(pipe["sb"]):              # lane B, behind the previous batch: this batch's targets
+            if batch is not None:
+                g.acoustic.copy_(batch[0].reshape(g.N, 36, 48, 12), non_blocking=True)
+                g.mfcc.copy_(batch[1].reshape(g.N, 12), non_blocking=True)
+            self._noise(g, eps)
+        pipe["pending"] = True
+        return out
+
+    def _lane_b_scalars(self, losses):
+        """python floats of a loss tensor produced on lane B (read behind that lane, not behind the trunk in flight)"""
+        with torch.cuda.stream(self._pipe["sb"]):
+            v = losses[:5].tolist()
+        return OrderedDict(mse=v[0], huber=v[1], latent=v[2], reg=v[3], loss=v[4])
+
+    def flush_pipeline(self):
+        """finish the batch whose trunk has run, and make the current stream wait for both lanes; returns its losses
+        (device tensor) or None"""
+        pipe, out = self._pipe, None
+        if pipe is None:
+            return None
+        if pipe["pending"]:
+            self._lane_b(pipe)
+            out = pipe["g"].losses
+        cur = torch.cuda.current_stream(self.session.device)
+        if cur != pipe["sa"]:
+            cur.wait_stream(pipe["sa"])
+        cur.wait_stream(pipe["sb"])
+        return out
 
     def train_step_sharded(self, shards, eps=None, probe=None):
         """Strong-scaling step: `shards` = this rank's micro-batches (each of the primary graph's size: the BN group),
@@ -280,6 +396,7 @@ class Trainer(object):
     def eval_step(self, batch=None, eps=None):
         """forward in inference mode (BN moving statistics); returns mse + the four per-3-channel MSEs"""
         g = self.primary if batch is None else self._graph_for(int(batch[1].reshape(-1, 12).shape[0]))
+        self.flush_pipeline()
         if batch is not None:
             self._feed(g, batch, eps)
         else:
@@ -335,6 +452,7 @@ class Trainer(object):
         reference's own `_restore_model` / `init_model` (:214-247) can read it.  Data-parallel: every rank calls this
         (the BN moving statistics are averaged over ranks first, a collective); only rank 0 writes."""
         from . import tfio
+        self.flush_pipeline()
         if self.comm is not None and self.comm.enabled:
             self.sync_moving_statistics()
         if not dp.is_writer(getattr(self, "group", None)):
@@ -382,13 +500,28 @@ class Trainer(object):
         best_epoch, best_loss = -1, 10000
         for epoch in range(start_epoch, start_epoch + self.num_epochs):
             step = 0
+            pipelined = bool(getattr(self.modelimages, "_split", False)) and FLAGS.pipeline
+
+            def report(i, r):
+                if i % self.display_freq == 0:
+                    self.log('{}: {} - Iteration: [{:3}]\t Training_mse_Loss: {:6f}\t Training_Loss: {:6f}'.format(
+                        datetime.now(), FLAGS.exp_name, i, r["mse"], r["loss"]))
+
             for next_batch in train_data.data:
                 acoustic, mfcc, images, _, _ = self._retrieve_batch(next_batch)
-                r = self.train_step((acoustic, mfcc, images))
-                if step % self.display_freq == 0:
-                    self.log('{}: {} - Iteration: [{:3}]\t Training_mse_Loss: {:6f}\t Training_Loss: {:6f}'.format(
-                        datetime.now(), FLAGS.exp_name, step, r["mse"], r["loss"]))
+                if pipelined:
+                    # the frozen trunk of this batch beside the optimisation step of the previous one: the line of
+                    # iteration i is written one call later (same numbers, same order)
+                    out = self.train_step_pipelined((acoustic, mfcc, images))
+                    if out is not None and (step - 1) % self.display_freq == 0:
+                        report(step - 1, self._lane_b_scalars(out))
+                else:
+                    report(step, self.train_step((acoustic, mfcc, images)))
                 step += 1
+            if pipelined:
+                out = self.flush_pipeline()
+                if out is not None and (step - 1) % self.display_freq == 0:
+                    report(step - 1, self._lane_b_scalars(out))
             total_loss = self._evaluate(session, 'validation', valid_data)
             self.log('{}: {} - Epoch: {}\t Validation_mse_Loss: {:6f}'.format(datetime.now(), FLAGS.exp_name, epoch,
                                                                               total_loss))

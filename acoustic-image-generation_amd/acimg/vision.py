@@ -362,6 +362,10 @@ class ResNet50Model(object):
             if not last:
                 cur, nxt = nxt, cur
         fh, fw = self.feat_hw
+        if training:
+            # everything recorded so far is the FROZEN trunk (no trainable variable is read): the trainer may run it
+            # for the next batch beside the trained part of the current one; the last call writes `xfinal`
+            self.frozen_calls = len(plan.calls)
         scm, tcm = self._conv_map_tap(plan, training)
         ops.bn_relu(plan, self.raw_cm, scm, tcm, self.output, N * fh * fw, 12, 12, 12)
         if self.stats is None or self.stats.numel() < self._stats_need:
@@ -412,8 +416,11 @@ class ResNet50Model(object):
         ops.conv2d_split3_prepare(plan, d1, self.cm_wt, self.cm_wsplit)
         ops.conv2d_fwd_split3(plan, d1, self.xfinal, self.cm_wsplit, self.cm_z)
         rows = ops.tapconv_stats_rows(d)
-        self._stats_need = max(self._stats_need, rows * 2 * 12)
-        stats = ops.LazyPtr(lambda: self.stats)
+        # a statistics buffer of its own: conv_map is the first layer of the TRAINED part of the step, which the
+        # two-lane pipeline (acimg/trainer.py) runs beside the frozen trunk of the next batch
+        if getattr(self, "stats_cm", None) is None or self.stats_cm.numel() < rows * 2 * 12:
+            self.stats_cm = self.session.zeros(rows * 2 * 12)
+        stats = self.stats_cm
         ops.tapconv_gather(plan, d, self.cm_z, 144, self.raw_cm, stats if training else None)
         if not hasattr(self, "_aff_cache"):
             self._aff_cache = {}

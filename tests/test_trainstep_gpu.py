@@ -450,3 +450,49 @@ def test_side_lane_is_only_a_schedule(device, monkeypatch):
     assert torch.equal(res[True][1], res[False][1])
     assert torch.equal(res[True][2], res[False][2])
     assert res[True][0]["loss"] == res[False][0]["loss"]
+
+
+def test_pipelined_steps_equal_sequential_steps(device):
+    """`Trainer.train_step_pipelined` (bench.py's default): the frozen trunk of batch t + 1 runs on one HIP stream while
+    conv_map + generator + backward + Adam of batch t run on another.  The trunk reads no trained variable, so the
+    arithmetic of every batch is the one-stream step's: after 4 different batches the weights, the Adam moments, the
+    batch-norm moving statistics and every step's losses are BIT-IDENTICAL to 4 calls of `train_step`; a sequential
+    call after pipelined ones flushes the pipeline first."""
+    from oracle import trainer as otr
+
+    batches = [otr.synthetic_batch(2, seed=300 + i) for i in range(4)]
+    tr, orc, sess = build(device, 1, False, 2)
+    seq_losses = []
+    for ac, mf, vid, eps in batches:
+        r = tr.train_step((ac, mf, vid), eps=eps)
+        seq_losses.append([r[k] for k in ("mse", "huber", "latent", "reg", "loss")])
+    torch.cuda.synchronize()
+    st = sess.store
+    want = (st.flat["train"].clone(), st.flat["state"].clone(), st.adam_m.clone(), st.adam_v.clone())
+
+    tr2, orc2, sess2 = build(device, 1, False, 2)
+    got_losses = []
+    for ac, mf, vid, eps in batches:
+        out = tr2.train_step_pipelined((ac, mf, vid), eps=eps)
+        if out is not None:
+            torch.cuda.synchronize()
+            got_losses.append(out[:5].tolist())
+    assert len(got_losses) == 3 and tr2.global_step == 3         # one batch is in flight
+    out = tr2.flush_pipeline()
+    torch.cuda.synchronize()
+    got_losses.append(out[:5].tolist())
+    assert tr2.global_step == 4 and tr2.flush_pipeline() is None
+    st2 = sess2.store
+    assert torch.equal(st2.flat["train"], want[0]), float((st2.flat["train"] - want[0]).abs().max())
+    assert torch.equal(st2.flat["state"], want[1])
+    assert torch.equal(st2.adam_m, want[2]) and torch.equal(st2.adam_v, want[3])
+    assert got_losses == seq_losses, (got_losses, seq_losses)
+    # mixing the two entry points: a pending batch is finished before a one-stream step runs
+    ac, mf, vid, eps = batches[0]
+    tr2.train_step_pipelined((ac, mf, vid), eps=eps)
+    r5 = tr2.train_step((batches[1][0], batches[1][1], batches[1][2]), eps=batches[1][3])
+    r5s_a = tr.train_step((ac, mf, vid), eps=eps)
+    r5s_b = tr.train_step((batches[1][0], batches[1][1], batches[1][2]), eps=batches[1][3])
+    torch.cuda.synchronize()
+    assert tr2.global_step == 6 and r5["loss"] == r5s_b["loss"]
+    assert torch.equal(sess2.store.flat["train"], sess.store.flat["train"])
