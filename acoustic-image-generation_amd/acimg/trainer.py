@@ -252,8 +252,7 @@ class Trainer(object):
         if g.frozen_calls is None or not self.modelimages._split:
             raise RuntimeError("train_step_pipelined: needs the split-MFMA trunk (precision f16x3 / f16): its frozen part "
                                "uses no shared workspace")
-        if self._pipe is not None:
-            self.flush_pipeline()
+        assert self._pipe is None or not self._pipe["pending"]
         dev = self.session.device
         full = g.plan_train
         lo, cut = g.head_calls, g.head_calls + g.frozen_calls
@@ -301,8 +300,11 @@ class Trainer(object):
         tensor of the previous batch's losses (None on the first call); `flush_pipeline()` finishes the last batch.
         batch None: reuse the images / targets resident in the graph's buffers (bench.py)."""
         g = self.primary if batch is None else self._graph_for(int(batch[1].reshape(-1, 12).shape[0]))
-        pipe = self._pipeline(g)
         out = None
+        if self._pipe is not None and self._pipe["g"] is not g:
+            out = self.flush_pipeline()      # another batch size (the last, partial batch): finish the one in flight
+            self._pipe = None
+        pipe = self._pipeline(g)
         if pipe["pending"]:
             self._lane_b(pipe, probe)
             out = g.losses
