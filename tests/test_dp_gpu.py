@@ -45,6 +45,16 @@ ac, mf, vid, eps = batches[rank]
 for _ in range(2):
     out = tr.train_step((ac, mf, vid), eps=eps)
 w = sess.store.flat["train"].clone()
+# the two-lane pipelined entry (trunk of the next batch beside the optimisation step of this one; the bucket hooks and
+# the exchange run on lane B): the same two steps, bit for bit
+tr_p, sess_p = make()
+comm_p = tr_p.enable_data_parallel()
+for _ in range(2):
+    tr_p.train_step_pipelined((ac, mf, vid), eps=eps)
+tr_p.flush_pipeline()
+torch.cuda.synchronize()
+assert tr_p.global_step == 2 and torch.equal(sess_p.store.flat["train"], w), \
+    float((sess_p.store.flat["train"] - w).abs().max())
 # identical on both ranks
 gathered = [torch.empty_like(w) for _ in range(world)]
 dist.all_gather(gathered, w)
