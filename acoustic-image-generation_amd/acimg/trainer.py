@@ -263,7 +263,7 @@ class Trainer(object):
         cur = torch.cuda.current_stream(dev)
         pipe = dict(g=g, a1=full.slice(lo, cut - 1), a2=full.slice(cut - 1, cut), a_off=lo,
                     head=full.slice(0, lo), b=full.slice(cut, len(full.calls)), b_off=cut,
-                    sa=cur, sb=torch.cuda.Stream(device=dev),
+                    sa=cur, sb=torch.cuda.Stream(device=dev),     # (a high-priority lane B: measured 0.5 % slower)
                     ev_a=torch.cuda.Event(), ev_b=torch.cuda.Event(), pending=False, b_ran=False)
         pipe["sb"].wait_stream(cur)
         self._pipe = pipe
