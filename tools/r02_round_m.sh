@@ -20,6 +20,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r02m_prof -o run --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > $R/gpurun_out/r02m_prof_bench.json 2>/dev/null
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r02m_prof1 -o run --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-pipeline --no-cpu-baseline --no-secondary > $R/gpurun_out/r02m_prof1_bench.json 2>/dev/null
 echo prof done
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_traffic/fetch -o run --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-pipeline --no-cpu-baseline --no-secondary > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_traffic/write -o run --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-pipeline --no-cpu-baseline --no-secondary > /dev/null 2>&1
+ACIMG_NO_SIDE_LANE=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_traffic/fetch -o run --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-pipeline --no-cpu-baseline --no-secondary > /dev/null 2>&1
+ACIMG_NO_SIDE_LANE=1 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_traffic/write -o run --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-pipeline --no-cpu-baseline --no-secondary > /dev/null 2>&1
 echo done
