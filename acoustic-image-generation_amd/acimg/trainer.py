@@ -131,6 +131,8 @@ class Trainer(object):
         # the calls [head_calls, head_calls + frozen_calls) are the FROZEN trunk (train_step_pipelined's lane A)
         g.head_calls = head_calls
         g.frozen_calls = getattr(modelimages, "frozen_calls", None)
+        g.stage_calls = getattr(modelimages, "stage_calls", None) if getattr(modelimages, "stages", 1) == 2 else None
+        g.stage_read_calls = getattr(modelimages, "stage_read_calls", None)
         # ---- evaluation step (is_training = 0: moving statistics; MSE only, :411-442) ----
         e = sess.new_plan()
         head(e)
@@ -149,7 +151,8 @@ class Trainer(object):
         if N in self.graphs:
             return self.graphs[N]
         # a different batch size (last partial batch): same variables, new buffers + plans
-        mi = type(self.modelimages)(input_shape=[224, 298, 3], num_classes=None, precision=self.modelimages.precision)
+        mi = type(self.modelimages)(input_shape=[224, 298, 3], num_classes=None, precision=self.modelimages.precision,
+                                    stages=getattr(self.modelimages, "stages", 1))
         ma = type(self.modelac)(input_shape=[36, 48, 12], embedding=self.modelac.embedding,
                                 num_skip=self.modelac.num_skip, precision=self.modelac.precision)
         mi._register = lambda store: None
@@ -237,43 +240,66 @@ class Trainer(object):
             return g.losses
         return self._scalars(g)
 
-    # ---- two-lane software pipeline -------------------------------------------------------------------------
+    # ---- software pipeline over HIP streams ------------------------------------------------------------------
     def _pipeline(self, g):
-        """Lane A = the frozen trunk (no trainable variable is read: trainer/mfcctrainer.py:64 keeps it out of
-        var_list) up to `xfinal`; lane B = everything that reads or writes a trained variable: conv_map, the generator,
-        the losses, the backward pass, the gradient exchange, Adam.  Two HIP streams; per call lane A runs batch t + 1
-        while lane B runs batch t.  The arithmetic of every batch is the sequential step's, bit for bit: lane A's
-        inputs (images, frozen weights, its own moving statistics in order) do not depend on lane B, and lane B of batch
-        t + 1 starts behind lane B of batch t (same stream) and behind lane A of batch t + 1 (event).  The only buffer
-        the lanes share is `xfinal` (written by lane A's LAST call, read by conv_map forward and weight gradient): that
-        call waits for lane B of the previous batch."""
+        """Stages: the FROZEN trunk (no trainable variable is read: trainer/mfcctrainer.py:64 keeps it out of var_list),
+        as one stage or — `ResNet50Model(stages=2)`, the default — as two (blocks 1-2 | blocks 3-4, each with its own
+        arena / statistics / tail workspace, a dedicated boundary tensor between them); then the TRAINED part: conv_map,
+        the generator, the losses, the backward pass, the gradient exchange, Adam.  One HIP stream per stage (the first
+        is the caller's); per call the stages run consecutive batches: trunk stage 1 of batch n, stage 2 of batch n - 1,
+        the trained part of batch n - 2.  The arithmetic of every batch is the one-stream step's, bit for bit: a trunk
+        stage's inputs (images or the boundary tensor, frozen weights, its own moving statistics, in batch order) do not
+        depend on later stages, and every stage processes the batches in order on its own stream.  Buffers that cross a
+        stage boundary are written by the producing stage's LAST call, which waits until the consuming stage of the
+        previous batch has read them (boundary tensor: after stage 2's first unit; `xfinal`: after the whole trained
+        part, whose last kernel — conv_map's weight gradient — reads it)."""
         if self._pipe is not None and self._pipe["g"] is g:
             return self._pipe
-        if g.frozen_calls is None or not self.modelimages._split:
+        mi = self.modelimages
+        if g.frozen_calls is None or not mi._split:
             raise RuntimeError("train_step_pipelined: needs the split-MFMA trunk (precision f16x3 / f16): its frozen part "
                                "uses no shared workspace")
-        assert self._pipe is None or not self._pipe["pending"]
+        assert self._pipe is None or not self._pipe["inflight"]
         dev = self.session.device
         full = g.plan_train
         lo, cut = g.head_calls, g.head_calls + g.frozen_calls
         assert full.calls[cut - 1][0] == "bn_add_relu_split", full.calls[cut - 1][0]     # the call that writes xfinal
-        # lane A is the caller's stream (where the one-stream step would run), lane B one more stream: with the two
-        # side lanes that is 4 HIP streams = the runtime's default number of hardware queues (streams beyond it share
-        # a queue and serialise)
         cur = torch.cuda.current_stream(dev)
-        pipe = dict(g=g, a1=full.slice(lo, cut - 1), a2=full.slice(cut - 1, cut), a_off=lo,
-                    head=full.slice(0, lo), b=full.slice(cut, len(full.calls)), b_off=cut,
-                    sa=cur, sb=torch.cuda.Stream(device=dev),     # (a high-priority lane B: measured 0.5 % slower)
-                    ev_a=torch.cuda.Event(), ev_b=torch.cuda.Event(), pending=False, b_ran=False)
+        stages = []
+        if g.stage_calls is not None:
+            sc, src = g.head_calls + g.stage_calls, g.head_calls + g.stage_read_calls
+            assert full.calls[sc - 1][0] == "bn_add_relu_split"                          # ... the boundary tensor
+            stages.append(dict(parts=[(full.slice(lo, sc - 1), lo, None, None), (full.slice(sc - 1, sc), sc - 1, "x", None)],
+                               stream=cur))
+            stages.append(dict(parts=[(full.slice(sc, src), sc, None, "x"), (full.slice(src, cut - 1), src, None, None),
+                                      (full.slice(cut - 1, cut), cut - 1, "b", None)],
+                               stream=torch.cuda.Stream(device=dev)))
+        else:
+            stages.append(dict(parts=[(full.slice(lo, cut - 1), lo, None, None), (full.slice(cut - 1, cut), cut - 1, "b", None)],
+                               stream=cur))
+        for st in stages:
+            st["done"] = torch.cuda.Event()
+        # 1 + len(stages) streams, + the trained part's side lane: at most 4 = the runtime's hardware queues (a fifth
+        # stream shares a queue with another one and serialises with it)
+        pipe = dict(g=g, stages=stages, head=full.slice(0, lo), b=full.slice(cut, len(full.calls)), b_off=cut,
+                    sb=torch.cuda.Stream(device=dev), ev={"x": torch.cuda.Event(), "b": torch.cuda.Event()},
+                    recorded=set(), inflight=[])
         pipe["sb"].wait_stream(cur)
+        for st in stages[1:]:
+            st["stream"].wait_stream(cur)
         self._pipe = pipe
         return pipe
 
-    def _lane_b(self, pipe, probe=None):
-        """batch t's trained part on lane B (inputs already in the graph's buffers), Adam included"""
+    def _run_trained_part(self, pipe, item, probe=None):
+        """the trained part of the oldest batch on its stream (targets copied in behind the previous batch), Adam included"""
         g = pipe["g"]
         with torch.cuda.stream(pipe["sb"]):
-            pipe["sb"].wait_event(pipe["ev_a"])          # lane A has written xfinal for this batch
+            if item["targets"] is not None:
+                ac, mf = item["targets"]
+                g.acoustic.copy_(ac.reshape(g.N, 36, 48, 12), non_blocking=True)
+                g.mfcc.copy_(mf.reshape(g.N, 12), non_blocking=True)
+            self._noise(g, item["eps"])
+            pipe["sb"].wait_event(pipe["stages"][-1]["done"])      # the trunk has written xfinal for this batch
             pipe["head"].run()
             if probe is None:
                 pipe["b"].run()
@@ -291,41 +317,63 @@ class Trainer(object):
                                              store.train_numel(), lr_t, 0.9, 0.999, 1e-8, scale,
                                              ops.current_stream_handle(self.session.device))
             _lib.check(rc, "adam_step")
-            pipe["ev_b"].record(pipe["sb"])
-        pipe["pending"], pipe["b_ran"] = False, True
+            pipe["ev"]["b"].record(pipe["sb"])
+        pipe["recorded"].add("b")
+
+    def _run_trunk_stage(self, pipe, k, item, probe=None):
+        g, st = pipe["g"], pipe["stages"][k]
+        with torch.cuda.stream(st["stream"]):
+            if k == 0:
+                if item["video"] is not None:
+                    g.video.copy_(item["video"].reshape(g.N, 224, 298, 3), non_blocking=True)
+            else:
+                st["stream"].wait_event(pipe["stages"][k - 1]["done"])
+            for plan, off, wait, record in st["parts"]:
+                if wait is not None and wait in pipe["recorded"]:
+                    st["stream"].wait_event(pipe["ev"][wait])      # the consumer of the previous batch has read it
+                if probe is None:
+                    plan.run()
+                else:
+                    plan.run_probed(probe[0], probe[1], offset=off)
+                if record is not None:
+                    pipe["ev"][record].record(st["stream"])
+                    pipe["recorded"].add(record)
+            st["done"].record(st["stream"])
+
+    def _advance(self, pipe, new_item, probe=None):
+        """one tick: every batch in flight moves one stage on (oldest first, so that an event waited on in this tick was
+        recorded for the batch before); returns the loss tensor if a batch finished"""
+        out, n = None, len(pipe["stages"])
+        flight = pipe["inflight"]
+        if flight and flight[0]["stage"] == n:
+            self._run_trained_part(pipe, flight.pop(0), probe)
+            out = pipe["g"].losses
+        for item in flight:                      # oldest first = deepest stage first
+            self._run_trunk_stage(pipe, item["stage"], item, probe)
+            item["stage"] += 1
+        if new_item is not None:
+            new_item["stage"] = 0
+            self._run_trunk_stage(pipe, 0, new_item, probe)
+            new_item["stage"] = 1
+            flight.append(new_item)
+        return out
 
     def train_step_pipelined(self, batch=None, eps=None, probe=None):
-        """One call = one batch in, one optimisation step out, in steady state: the frozen trunk of THIS batch runs on
-        lane A while conv_map + generator + backward + Adam of the PREVIOUS batch run on lane B.  Returns the device
-        tensor of the previous batch's losses (None on the first call); `flush_pipeline()` finishes the last batch.
-        batch None: reuse the images / targets resident in the graph's buffers (bench.py)."""
+        """One call = one batch in, one optimisation step out, in steady state: the frozen trunk of THIS batch starts on
+        the caller's stream while the later stages of the previous batches run on theirs (`_pipeline`).  Returns the
+        device tensor of the losses of the batch that finished in this call (None while the pipeline fills);
+        `flush_pipeline()` finishes the batches in flight.  batch None: reuse the images / targets resident in the
+        graph's buffers (bench.py)."""
         g = self.primary if batch is None else self._graph_for(int(batch[1].reshape(-1, 12).shape[0]))
         out = None
         if self._pipe is not None and self._pipe["g"] is not g:
-            out = self.flush_pipeline()      # another batch size (the last, partial batch): finish the one in flight
+            out = self.flush_pipeline()      # another batch size (the last, partial batch): finish the ones in flight
             self._pipe = None
         pipe = self._pipeline(g)
-        if pipe["pending"]:
-            self._lane_b(pipe, probe)
-            out = g.losses
-        with torch.cuda.stream(pipe["sa"]):              # lane A: this batch's frozen trunk
-            if batch is not None:
-                g.video.copy_(batch[2].reshape(g.N, 224, 298, 3), non_blocking=True)
-            if probe is None:
-                pipe["a1"].run()
-            else:
-                pipe["a1"].run_probed(probe[0], probe[1], offset=pipe["a_off"])
-            if pipe["b_ran"]:
-                pipe["sa"].wait_event(pipe["ev_b"])      # the previous batch no longer reads xfinal
-            pipe["a2"].run()
-            pipe["ev_a"].record(pipe["sa"])
-        with torch.cuda.stream(pipe["sb"]):              # lane B, behind the previous batch: this batch's targets
-            if batch is not None:
-                g.acoustic.copy_(batch[0].reshape(g.N, 36, 48, 12), non_blocking=True)
-                g.mfcc.copy_(batch[1].reshape(g.N, 12), non_blocking=True)
-            self._noise(g, eps)
-        pipe["pending"] = True
-        return out
+        item = dict(video=None if batch is None else batch[2], targets=None if batch is None else (batch[0], batch[1]),
+                    eps=eps)
+        res = self._advance(pipe, item, probe)
+        return res if res is not None else out
 
     def _lane_b_scalars(self, losses):
         """python floats of a loss tensor produced on lane B (read behind that lane, not behind the trunk in flight)"""
@@ -334,17 +382,18 @@ class Trainer(object):
         return OrderedDict(mse=v[0], huber=v[1], latent=v[2], reg=v[3], loss=v[4])
 
     def flush_pipeline(self):
-        """finish the batch whose trunk has run, and make the current stream wait for both lanes; returns its losses
-        (device tensor) or None"""
+        """finish the batches in flight (oldest first) and make the current stream wait for every lane; returns the
+        losses of the last one (device tensor) or None"""
         pipe, out = self._pipe, None
         if pipe is None:
             return None
-        if pipe["pending"]:
-            self._lane_b(pipe)
-            out = pipe["g"].losses
+        while pipe["inflight"]:
+            res = self._advance(pipe, None)
+            out = res if res is not None else out
         cur = torch.cuda.current_stream(self.session.device)
-        if cur != pipe["sa"]:
-            cur.wait_stream(pipe["sa"])
+        for st in pipe["stages"]:
+            if st["stream"] != cur:
+                cur.wait_stream(st["stream"])
         cur.wait_stream(pipe["sb"])
         return out
 

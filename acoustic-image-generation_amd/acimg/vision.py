@@ -32,7 +32,7 @@ BN_EPS = 1e-5
 
 class ResNet50Model(object):
 
-    def __init__(self, input_shape=None, num_classes=None, precision="f16x3"):
+    def __init__(self, input_shape=None, num_classes=None, precision="f16x3", stages=None):
         """precision: arithmetic of the frozen trunk convs — "f16x3" (split-fp16 MFMA, fp32-class
         results, default), "f32" (exact-f32 MFMA) or "f16" (fp16 OPERAND STORAGE: the same data path, but the 52 trunk
         convs fetch and multiply only the hi fp16 plane of activations and weights — one MFMA per product, fp32
@@ -44,8 +44,20 @@ class ResNet50Model(object):
         self.precision = precision
         self._split = precision in ("f16x3", "f16")
         self._terms = 1 if precision == "f16" else 3
-        # the four projection shortcuts run on the plan's side lane (a second HIP stream) beside conv1 .. conv3
-        self.side_lane = os.environ.get("ACIMG_NO_SIDE_LANE") is None
+        # stages = 2: the frozen trunk is recorded as TWO pipeline stages (blocks 1-2 | blocks 3-4) with an activation
+        # arena, a statistics buffer and a tail workspace each and a dedicated boundary tensor, so that the trainer can
+        # run stage 1 of batch t + 2 beside stage 2 of batch t + 1 (Trainer.train_step_pipelined): two trunk kernels of
+        # different depth fill each other's partial last rounds.  stages = 1: one arena; the four projection shortcuts
+        # then run on the plan's side lane beside conv1 .. conv3 (with two stages the stage streams take that role and
+        # the 4 hardware queues are spent on the pipeline's lanes).
+        if stages is None:
+            stages = int(os.environ.get("ACIMG_TRUNK_STAGES", "2")) if precision in ("f16x3", "f16") else 1
+        assert stages in (1, 2)
+        if precision not in ("f16x3", "f16"):
+            stages = 1
+        self.stages = stages
+        self.STAGE_CUT = 7          # units of blocks 1 + 2
+        self.side_lane = os.environ.get("ACIMG_NO_SIDE_LANE") is None and stages == 1
         self.num_classes = num_classes
         self.height = input_shape[0]
         self.width = input_shape[1]
@@ -173,6 +185,24 @@ class ResNet50Model(object):
             u8 = lambda n: torch.zeros(int(n), dtype=torch.uint8, device=sess.device)  # noqa: E731
             self.planes_a, self.planes_b = u8(4 * mx_io + 512), u8(4 * mx_io + 512)
             self.planes_1, self.planes_2 = u8(4 * mx_r1 + 512), u8(4 * mx_r2 + 512)
+            if self.stages == 2:
+                # stage 2's own arenas (sized for its units) and the tensor that crosses the stage boundary
+                hh, ww = ph, pw
+                io2 = r12 = r22 = r32 = xb = 0
+                for k, (scope, din, d, db, s_) in enumerate(self._units()):
+                    oh, _ = ops.same_out_pad(hh, 1, s_)
+                    ow, _ = ops.same_out_pad(ww, 1, s_)
+                    if k == self.STAGE_CUT - 1:
+                        xb = N * oh * ow * d
+                    if k >= self.STAGE_CUT:
+                        r12, r22 = max(r12, N * hh * ww * db), max(r22, N * oh * ow * db)
+                        r32, io2 = max(r32, N * oh * ow * d), max(io2, N * oh * ow * d)
+                    hh, ww = oh, ow
+                self.planes_x = u8(4 * xb + 512)
+                self.planes_a2, self.planes_b2 = u8(4 * io2 + 512), u8(4 * io2 + 512)
+                self.planes_12, self.planes_22 = u8(4 * r12 + 512), u8(4 * r22 + 512)
+                self.arena_r12, self.arena_r22 = z(r12), z(r22)
+                self.arena_r32, self.arena_sc2 = z(r32), z(r32)
         self.xfinal = z(N, h, w, 2048)          # block4 output, kept for the conv_map weight gradient
         self.affine = z(2 * (nch + 64 + 16))    # scale/shift of every BN layer
         self._aff_off = 0
@@ -268,18 +298,22 @@ class ResNet50Model(object):
         """byte offset of the lo plane of a [rows, c] split-format tensor"""
         return -(-rows * c * 2 // 256) * 256
 
-    def _conv_bn_planes(self, plan, scope, xplanes, hw, cin, kh, kw, cout, stride, padding, out, training, side=False):
+    def _conv_bn_planes(self, plan, scope, xplanes, hw, cin, kh, kw, cout, stride, padding, out, training, side=False,
+                        tag=""):
         """like _conv_bn, for an input in split format (pre-normalised fp16 hi/lo planes).  side: conv + finalize on the
-        plan's side lane (the projection shortcut beside conv1..conv3 of its unit), with a statistics buffer and a
-        tail workspace (tickets) of their own"""
+        plan's side lane (the projection shortcut beside conv1..conv3 of its unit); tag "2": second pipeline stage.
+        Every (stage, lane) pair has a statistics buffer and a tail workspace (tickets) of its own: they may run at the
+        same time"""
         st = self.session.store
         P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
         d = ops.conv_desc(self.N, hw[0], hw[1], cin, cout, kh, kw, stride, padding, ldx=cin, ldy=up4(cout),
                           ldw=up4(cout))
         rows = ops.conv2d_fwd_split3_stats_rows(d)
-        if side:
-            self._stats_side_need = max(getattr(self, "_stats_side_need", 0), rows * 2 * up4(cout))
-            stats = ops.LazyPtr(lambda: self.stats_side)
+        lane = ("_side" if side else "") + tag
+        if lane:
+            self._lane_stats_need = getattr(self, "_lane_stats_need", {})
+            self._lane_stats_need[lane] = max(self._lane_stats_need.get(lane, 0), rows * 2 * up4(cout))
+            stats = ops.LazyPtr(lambda lane=lane: self.lane_stats[lane])
         else:
             self._stats_need = max(self._stats_need, rows * 2 * up4(cout))
             stats = ops.LazyPtr(lambda: self.stats)
@@ -290,7 +324,7 @@ class ResNet50Model(object):
             ops.conv2d_split3_prepare(self.plan_prepare, d, P(scope + "/weights"),
                                       ops.LazyPtr(lambda off=off: self.wsplit[off:]))
         off = self._sp3[scope]
-        ws_attr = "_tail_ws_side" if side else "_tail_ws"
+        ws_attr = "_tail_ws" + lane
         if getattr(self, ws_attr, None) is None:
             # partial sums + tile tickets of the trunk kernel's tail split; used by nothing else, zero at start
             setattr(self, ws_attr, torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8,
@@ -326,25 +360,39 @@ class ResNet50Model(object):
                                   pt, pl)
         h, w = ph, pw
         units = list(self._units())
+        two = self.stages == 2
         for i, (scope, din, d, db, s) in enumerate(units):
             last = i == len(units) - 1
+            st2 = two and i >= self.STAGE_CUT
+            tag = "2" if st2 else ""
+            r1, r2, r3, asc = ((self.arena_r12, self.arena_r22, self.arena_r32, self.arena_sc2) if st2 else
+                               (self.arena_r1, self.arena_r2, self.arena_r3, self.arena_sc))
+            p1, p2 = (self.planes_12, self.planes_22) if st2 else (self.planes_1, self.planes_2)
+            if two and i == self.STAGE_CUT:
+                # stage 2 starts here: it reads the boundary tensor and ping-pongs inside its own arena
+                if training:
+                    self.stage_calls = len(plan.calls)
+                cur, nxt = self.planes_x, self.planes_a2
             beside = din != d and self.side_lane
             if beside:
                 # the projection shortcut reads the same planes as conv1 and meets the main branch only in the unit's
                 # last pass: it runs on the plan's side lane beside conv1 .. conv3 (their tails leave slots)
                 plan.fork()
                 _, _, ssc, tsc = self._conv_bn_planes(plan, scope + "/shortcut", cur, (h, w), din, 1, 1, d, s, "SAME",
-                                                      self.arena_sc, training, side=True)
+                                                      asc, training, side=True, tag=tag)
             oh1, ow1, s1, t1 = self._conv_bn_planes(plan, scope + "/conv1", cur, (h, w), din, 1, 1, db, 1, "SAME",
-                                                    self.arena_r1, training)
-            ops.bn_relu_split(plan, self.arena_r1, s1, t1, 1, self.planes_1, self._lo_off(N * h * w, db), N * h * w, db)
-            oh2, ow2, s2, t2 = self._conv_bn_planes(plan, scope + "/conv2", self.planes_1, (h, w), db, 3, 3, db, s,
-                                                    "SAME" if s == 1 else 1, self.arena_r2, training)
-            ops.bn_relu_split(plan, self.arena_r2, s2, t2, 1, self.planes_2, self._lo_off(N * oh2 * ow2, db),
-                              N * oh2 * ow2, db)
-            oh3, ow3, s3, t3 = self._conv_bn_planes(plan, scope + "/conv3", self.planes_2, (oh2, ow2), db, 1, 1, d, 1,
-                                                    "SAME", self.arena_r3, training)
-            out_planes = None if last else nxt
+                                                    r1, training, tag=tag)
+            ops.bn_relu_split(plan, r1, s1, t1, 1, p1, self._lo_off(N * h * w, db), N * h * w, db)
+            oh2, ow2, s2, t2 = self._conv_bn_planes(plan, scope + "/conv2", p1, (h, w), db, 3, 3, db, s,
+                                                    "SAME" if s == 1 else 1, r2, training, tag=tag)
+            ops.bn_relu_split(plan, r2, s2, t2, 1, p2, self._lo_off(N * oh2 * ow2, db), N * oh2 * ow2, db)
+            oh3, ow3, s3, t3 = self._conv_bn_planes(plan, scope + "/conv3", p2, (oh2, ow2), db, 1, 1, d, 1,
+                                                    "SAME", r3, training, tag=tag)
+            if two and i == self.STAGE_CUT - 1:
+                nxt_out = self.planes_x          # the last unit of stage 1 writes the boundary tensor
+            else:
+                nxt_out = nxt
+            out_planes = None if last else nxt_out
             out_lo = 0 if last else self._lo_off(N * oh3 * ow3, d)
             out32 = self.xfinal if last else None
             if din != d:
@@ -352,15 +400,20 @@ class ResNet50Model(object):
                     plan.join()
                 else:
                     _, _, ssc, tsc = self._conv_bn_planes(plan, scope + "/shortcut", cur, (h, w), din, 1, 1, d, s,
-                                                          "SAME", self.arena_sc, training)
-                ops.bn_add_relu_split(plan, self.arena_r3, s3, t3, self.arena_sc, ssc, tsc, None, 0, out_planes, out_lo,
+                                                          "SAME", asc, training, tag=tag)
+                ops.bn_add_relu_split(plan, r3, s3, t3, asc, ssc, tsc, None, 0, out_planes, out_lo,
                                       out32, N, oh3, ow3, d, oh3, ow3, 1)
             else:
-                ops.bn_add_relu_split(plan, self.arena_r3, s3, t3, None, None, None, cur, self._lo_off(N * h * w, din),
+                ops.bn_add_relu_split(plan, r3, s3, t3, None, None, None, cur, self._lo_off(N * h * w, din),
                                       out_planes, out_lo, out32, N, oh3, ow3, d, h, w, s)
             h, w = oh3, ow3
+            if two and i == self.STAGE_CUT and training:
+                self.stage_read_calls = len(plan.calls)      # stage 2 no longer reads the boundary tensor from here on
             if not last:
-                cur, nxt = nxt, cur
+                if two and i == self.STAGE_CUT:
+                    cur, nxt = self.planes_a2, self.planes_b2
+                else:
+                    cur, nxt = nxt, cur
         fh, fw = self.feat_hw
         if training:
             # everything recorded so far is the FROZEN trunk (no trainable variable is read): the trainer may run it
@@ -370,9 +423,10 @@ class ResNet50Model(object):
         ops.bn_relu(plan, self.raw_cm, scm, tcm, self.output, N * fh * fw, 12, 12, 12)
         if self.stats is None or self.stats.numel() < self._stats_need:
             self.stats = self.session.zeros(self._stats_need)
-        need = getattr(self, "_stats_side_need", 0)
-        if need and (getattr(self, "stats_side", None) is None or self.stats_side.numel() < need):
-            self.stats_side = self.session.zeros(need)
+        self.lane_stats = getattr(self, "lane_stats", {})
+        for lane, need in getattr(self, "_lane_stats_need", {}).items():
+            if lane not in self.lane_stats or self.lane_stats[lane].numel() < need:
+                self.lane_stats[lane] = self.session.zeros(need)
 
     def _stem_bn(self, plan, training):
         """conv1 (7x7/2 after 3+3 explicit zero padding) + BN statistics as a row-run conv (include/acimg.h,

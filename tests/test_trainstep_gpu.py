@@ -453,11 +453,11 @@ def test_side_lane_is_only_a_schedule(device, monkeypatch):
 
 
 def test_pipelined_steps_equal_sequential_steps(device):
-    """`Trainer.train_step_pipelined` (bench.py's default): the frozen trunk of batch t + 1 runs on one HIP stream while
-    conv_map + generator + backward + Adam of batch t run on another.  The trunk reads no trained variable, so the
-    arithmetic of every batch is the one-stream step's: after 4 different batches the weights, the Adam moments, the
-    batch-norm moving statistics and every step's losses are BIT-IDENTICAL to 4 calls of `train_step`; a sequential
-    call after pipelined ones flushes the pipeline first."""
+    """`Trainer.train_step_pipelined` (bench.py's default): trunk stage 1 (blocks 1-2) of batch n, trunk stage 2 (blocks
+    3-4) of batch n - 1 and conv_map + generator + backward + Adam of batch n - 2 run on three HIP streams.  The trunk
+    reads no trained variable, so the arithmetic of every batch is the one-stream step's: after 4 different batches
+    the weights, the Adam moments, the batch-norm moving statistics and every step's losses are BIT-IDENTICAL to 4
+    calls of `train_step`; a sequential call after pipelined ones flushes the pipeline first."""
     from oracle import trainer as otr
 
     batches = [otr.synthetic_batch(2, seed=300 + i) for i in range(4)]
@@ -477,10 +477,13 @@ def test_pipelined_steps_equal_sequential_steps(device):
         if out is not None:
             torch.cuda.synchronize()
             got_losses.append(out[:5].tolist())
-    assert len(got_losses) == 3 and tr2.global_step == 3         # one batch is in flight
-    out = tr2.flush_pipeline()
-    torch.cuda.synchronize()
-    got_losses.append(out[:5].tolist())
+    depth = len(tr2._pipe["stages"])                             # trunk stages = batches in flight
+    assert depth == tr2.modelimages.stages == 2
+    assert len(got_losses) == 4 - depth and tr2.global_step == 4 - depth
+    while tr2._pipe["inflight"]:
+        out = tr2._advance(tr2._pipe, None)
+        torch.cuda.synchronize()
+        got_losses.append(out[:5].tolist())
     assert tr2.global_step == 4 and tr2.flush_pipeline() is None
     st2 = sess2.store
     assert torch.equal(st2.flat["train"], want[0]), float((st2.flat["train"] - want[0]).abs().max())
