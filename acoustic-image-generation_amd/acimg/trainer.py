@@ -283,7 +283,7 @@ class Trainer(object):
         # stream shares a queue with another one and serialises with it)
         pipe = dict(g=g, stages=stages, head=full.slice(0, lo), b=full.slice(cut, len(full.calls)), b_off=cut,
                     sb=torch.cuda.Stream(device=dev), ev={"x": torch.cuda.Event(), "b": torch.cuda.Event()},
-                    recorded=set(), inflight=[])
+                    recorded=set(), inflight=[], finished=[])
         pipe["sb"].wait_stream(cur)
         for st in stages[1:]:
             st["stream"].wait_stream(cur)
@@ -317,6 +317,9 @@ class Trainer(object):
                                              store.train_numel(), lr_t, 0.9, 0.999, 1e-8, scale,
                                              ops.current_stream_handle(self.session.device))
             _lib.check(rc, "adam_step")
+            if item.get("tag") is not None:
+                # a private copy of this batch's losses (the graph's buffer is rewritten by the next batch)
+                pipe["finished"].append((item["tag"], g.losses[:5].clone()))
             pipe["ev"]["b"].record(pipe["sb"])
         pipe["recorded"].add("b")
 
@@ -358,20 +361,31 @@ class Trainer(object):
             flight.append(new_item)
         return out
 
-    def train_step_pipelined(self, batch=None, eps=None, probe=None):
+    def pop_finished(self):
+        """[(tag, {mse, huber, latent, reg, loss})] of the batches submitted with a tag that finished since the last call,
+        oldest first (reads behind the trained part's stream, not behind the trunks in flight)"""
+        pipe = self._pipe
+        if pipe is None or not pipe["finished"]:
+            return []
+        done, pipe["finished"] = pipe["finished"], []
+        return [(tag, self._lane_b_scalars(t)) for tag, t in done]
+
+    def train_step_pipelined(self, batch=None, eps=None, probe=None, tag=None):
         """One call = one batch in, one optimisation step out, in steady state: the frozen trunk of THIS batch starts on
         the caller's stream while the later stages of the previous batches run on theirs (`_pipeline`).  Returns the
         device tensor of the losses of the batch that finished in this call (None while the pipeline fills);
         `flush_pipeline()` finishes the batches in flight.  batch None: reuse the images / targets resident in the
-        graph's buffers (bench.py)."""
+        graph's buffers (bench.py).  tag: keep this batch's losses for `pop_finished()` (the training log)."""
         g = self.primary if batch is None else self._graph_for(int(batch[1].reshape(-1, 12).shape[0]))
         out = None
+        carried = []
         if self._pipe is not None and self._pipe["g"] is not g:
             out = self.flush_pipeline()      # another batch size (the last, partial batch): finish the ones in flight
-            self._pipe = None
+            carried, self._pipe = self._pipe["finished"], None
         pipe = self._pipeline(g)
+        pipe["finished"] = carried + pipe["finished"]
         item = dict(video=None if batch is None else batch[2], targets=None if batch is None else (batch[0], batch[1]),
-                    eps=eps)
+                    eps=eps, tag=tag)
         res = self._advance(pipe, item, probe)
         return res if res is not None else out
 
@@ -561,18 +575,19 @@ class Trainer(object):
             for next_batch in train_data.data:
                 acoustic, mfcc, images, _, _ = self._retrieve_batch(next_batch)
                 if pipelined:
-                    # the frozen trunk of this batch beside the optimisation step of the previous one: the line of
-                    # iteration i is written one call later (same numbers, same order)
-                    out = self.train_step_pipelined((acoustic, mfcc, images))
-                    if out is not None and (step - 1) % self.display_freq == 0:
-                        report(step - 1, self._lane_b_scalars(out))
+                    # this batch's trunk starts beside the later stages of the batches before it: the line of iteration
+                    # i is written when that batch finishes, a few calls later (same numbers, same order)
+                    self.train_step_pipelined((acoustic, mfcc, images),
+                                              tag=step if step % self.display_freq == 0 else None)
+                    for i, r in self.pop_finished():
+                        report(i, r)
                 else:
                     report(step, self.train_step((acoustic, mfcc, images)))
                 step += 1
             if pipelined:
-                out = self.flush_pipeline()
-                if out is not None and (step - 1) % self.display_freq == 0:
-                    report(step - 1, self._lane_b_scalars(out))
+                self.flush_pipeline()
+                for i, r in self.pop_finished():
+                    report(i, r)
             total_loss = self._evaluate(session, 'validation', valid_data)
             self.log('{}: {} - Epoch: {}\t Validation_mse_Loss: {:6f}'.format(datetime.now(), FLAGS.exp_name, epoch,
                                                                               total_loss))
