@@ -243,7 +243,7 @@ class Trainer(object):
     # ---- software pipeline over HIP streams ------------------------------------------------------------------
     def _pipeline(self, g):
         """Stages: the FROZEN trunk (no trainable variable is read: trainer/mfcctrainer.py:64 keeps it out of var_list),
-        as one stage or — `ResNet50Model(stages=2)`, the default — as two (blocks 1-2 | blocks 3-4, each with its own
+        as one stage or — `ResNet50Model(stages=2)`, the default — as two (units 1-8 | units 9-16, each with its own
         arena / statistics / tail workspace, a dedicated boundary tensor between them); then the TRAINED part: conv_map,
         the generator, the losses, the backward pass, the gradient exchange, Adam.  One HIP stream per stage (the first
         is the caller's); per call the stages run consecutive batches: trunk stage 1 of batch n, stage 2 of batch n - 1,

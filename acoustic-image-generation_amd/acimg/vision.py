@@ -44,7 +44,7 @@ class ResNet50Model(object):
         self.precision = precision
         self._split = precision in ("f16x3", "f16")
         self._terms = 1 if precision == "f16" else 3
-        # stages = 2: the frozen trunk is recorded as TWO pipeline stages (blocks 1-2 | blocks 3-4) with an activation
+        # stages = 2: the frozen trunk is recorded as TWO pipeline stages (units 1-8 | units 9-16) with an activation
         # arena, a statistics buffer and a tail workspace each and a dedicated boundary tensor, so that the trainer can
         # run stage 1 of batch t + 2 beside stage 2 of batch t + 1 (Trainer.train_step_pipelined): two trunk kernels of
         # different depth fill each other's partial last rounds.  stages = 1: one arena; the four projection shortcuts
@@ -56,7 +56,9 @@ class ResNet50Model(object):
         if precision not in ("f16x3", "f16"):
             stages = 1
         self.stages = stages
-        self.STAGE_CUT = 7          # units of blocks 1 + 2
+        # units in stage 1: 8 = blocks 1 + 2 + the first unit of block 3 (measured: 5: 7.53, 6: 7.30, 7: 7.18, 8: 7.06,
+        # 9: 7.19 ms/step; the two trunk stages and the trained part should take about the same time)
+        self.STAGE_CUT = int(os.environ.get("ACIMG_STAGE_CUT", "8"))
         self.side_lane = os.environ.get("ACIMG_NO_SIDE_LANE") is None and stages == 1
         self.num_classes = num_classes
         self.height = input_shape[0]

@@ -453,8 +453,8 @@ def test_side_lane_is_only_a_schedule(device, monkeypatch):
 
 
 def test_pipelined_steps_equal_sequential_steps(device):
-    """`Trainer.train_step_pipelined` (bench.py's default): trunk stage 1 (blocks 1-2) of batch n, trunk stage 2 (blocks
-    3-4) of batch n - 1 and conv_map + generator + backward + Adam of batch n - 2 run on three HIP streams.  The trunk
+    """`Trainer.train_step_pipelined` (bench.py's default): trunk stage 1 (units 1-8) of batch n, trunk stage 2 (units
+    9-16) of batch n - 1 and conv_map + generator + backward + Adam of batch n - 2 run on three HIP streams.  The trunk
     reads no trained variable, so the arithmetic of every batch is the one-stream step's: after 4 different batches
     the weights, the Adam moments, the batch-norm moving statistics and every step's losses are BIT-IDENTICAL to 4
     calls of `train_step`; a sequential call after pipelined ones flushes the pipeline first."""
