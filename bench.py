@@ -342,6 +342,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_dp = os.environ.get("ACIMG_DP_FORCE") == "1" and "RANK" in os.environ   # one-rank RCCL rehearsal
+    if (world > 1 or force_dp) and not args.no_pipeline:
+        # streams of a data-parallel pipelined step: trunk stage 1, trunk stage 2, trained part, RCCL's = 4 = the runtime's
+        # hardware queues; the trained part's side lane (neutral inside the pipeline: 7.28 ms with or without it) would
+        # be a fifth one sharing a queue with another
+        os.environ["ACIMG_NO_SIDE_LANE"] = "1"
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
