@@ -178,6 +178,45 @@ def side_lane(device):
     return _SIDE[skey], _SIDE[dkey]
 
 
+def _runs_beside(a, b, work):
+    """True if a small kernel on stream b completes while stream a is still busy with `work` (two streams that share a
+    hardware queue serialise: the runtime maps streams onto a few queues in an order the program cannot see)"""
+    ea, eb = torch.cuda.Event(), torch.cuda.Event()
+    flag = torch.zeros(8, device=work.device)
+    torch.cuda.synchronize(work.device)
+    with torch.cuda.stream(a):
+        for _ in range(6):
+            work = torch.mm(work, work).clamp_(-1.0, 1.0)
+        ea.record(a)
+    with torch.cuda.stream(b):
+        flag.add_(1.0)
+        eb.record(b)
+    while not eb.query() and not ea.query():
+        pass
+    beside = eb.query() and not ea.query()
+    torch.cuda.synchronize(work.device)
+    return beside
+
+
+def concurrent_streams(device, base, want, pool=8):
+    """up to `want` new streams that really run beside `base` and beside each other (measured, a few ms each); fewer if
+    the runtime has fewer free hardware queues — the caller then shares lanes, which costs time, never correctness"""
+    work = torch.rand(2048, 2048, device=device) * 0.01
+    chosen, cands = [base], [torch.cuda.Stream(device=device) for _ in range(pool)]
+    for c in cands:
+        if len(chosen) > want:
+            break
+        if all(_runs_beside(x, c, work) and _runs_beside(c, x, work) for x in chosen):
+            chosen.append(c)
+    return chosen[1:]
+
+
+def set_side_lane(device, main_stream, side_stream):
+    """use `side_stream` as the side lane of plans run on `main_stream` (side_stream = main_stream: no second lane)"""
+    side_lane(device)      # creates the device's side workspace
+    _SIDE[(str(device), main_stream.cuda_stream)] = side_stream
+
+
 class Plan(object):
     """Ordered list of C-ABI calls.  eager=True runs each call as it is added (everything on the current stream)."""
 

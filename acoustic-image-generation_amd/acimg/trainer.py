@@ -265,6 +265,14 @@ class Trainer(object):
         lo, cut = g.head_calls, g.head_calls + g.frozen_calls
         assert full.calls[cut - 1][0] == "bn_add_relu_split", full.calls[cut - 1][0]     # the call that writes xfinal
         cur = torch.cuda.current_stream(dev)
+        # one stream per stage beyond the first, one for the trained part and one for its side lane — only streams that
+        # were MEASURED to run beside the caller's and beside each other (ops.concurrent_streams): the runtime maps
+        # streams onto a few hardware queues (4 by default; RCCL takes some) and two streams on one queue serialise
+        want = (2 if g.stage_calls is not None else 1) + 1
+        lanes = ops.concurrent_streams(dev, cur, want)
+        side_b = lanes.pop() if len(lanes) == want else None
+        while len(lanes) < want - 1:
+            lanes.append(lanes[-1] if lanes else cur)      # too few queues: stages share a lane (slower, still correct)
         stages = []
         if g.stage_calls is not None:
             sc, src = g.head_calls + g.stage_calls, g.head_calls + g.stage_read_calls
@@ -273,20 +281,21 @@ class Trainer(object):
                                stream=cur))
             stages.append(dict(parts=[(full.slice(sc, src), sc, None, "x"), (full.slice(src, cut - 1), src, None, None),
                                       (full.slice(cut - 1, cut), cut - 1, "b", None)],
-                               stream=torch.cuda.Stream(device=dev)))
+                               stream=lanes[0]))
         else:
             stages.append(dict(parts=[(full.slice(lo, cut - 1), lo, None, None), (full.slice(cut - 1, cut), cut - 1, "b", None)],
                                stream=cur))
         for st in stages:
             st["done"] = torch.cuda.Event()
-        # 1 + len(stages) streams, + the trained part's side lane: at most 4 = the runtime's hardware queues (a fifth
-        # stream shares a queue with another one and serialises with it)
         pipe = dict(g=g, stages=stages, head=full.slice(0, lo), b=full.slice(cut, len(full.calls)), b_off=cut,
-                    sb=torch.cuda.Stream(device=dev), ev={"x": torch.cuda.Event(), "b": torch.cuda.Event()},
-                    recorded=set(), inflight=[], finished=[])
-        pipe["sb"].wait_stream(cur)
+                    sb=lanes[-1], ev={"x": torch.cuda.Event(), "b": torch.cuda.Event()},
+                    recorded=set(), inflight=[], finished=[], lanes=len(set(x.cuda_stream for x in lanes + [cur])))
+        ops.set_side_lane(dev, pipe["sb"], side_b if side_b is not None else pipe["sb"])
+        if pipe["sb"] != cur:
+            pipe["sb"].wait_stream(cur)
         for st in stages[1:]:
-            st["stream"].wait_stream(cur)
+            if st["stream"] != cur:
+                st["stream"].wait_stream(cur)
         self._pipe = pipe
         return pipe
 
@@ -301,14 +310,22 @@ class Trainer(object):
             self._noise(g, item["eps"])
             pipe["sb"].wait_event(pipe["stages"][-1]["done"])      # the trunk has written xfinal for this batch
             pipe["head"].run()
-            if probe is None:
-                pipe["b"].run()
-            else:
-                pipe["b"].run_probed(probe[0], probe[1], offset=pipe["b_off"])
+            # data parallel: ONE exchange of the whole flat gradient, issued from THIS stream after the backward pass (no
+            # buckets, no separate exchange stream): the trained part has a whole tick of slack behind the trunk stages,
+            # so nothing needs to overlap inside it; every collective call costs host time, and every stream beyond the
+            # runtime's 4 hardware queues shares a queue with one of the lanes (RCCL's own stream is the fourth)
+            held, self.hold_exchange = self.hold_exchange, True
+            try:
+                if probe is None:
+                    pipe["b"].run()
+                else:
+                    pipe["b"].run_probed(probe[0], probe[1], offset=pipe["b_off"])
+            finally:
+                self.hold_exchange = held
             store = self.session.store
             scale = 1.0
             if self.comm is not None and self.comm.enabled:
-                self.comm.wait()
+                self.comm.allreduce_all()
                 scale = self.comm.grad_scale
             self.global_step += 1
             lr_t = ops.adam_lr_t(self.learning_rate, self.global_step)

@@ -521,8 +521,9 @@ def main():
                        "per_gpu_batch": images_per_step // world, "global_batch": images_per_step,
                        "bn_group": B, "shards_per_gpu_per_step": len(shards) if strong else 1,
                        "parallelism": "dp%d" % world, "launches_per_step": len(g.plan_train) + 2,
-                       "lanes": ("2 (HIP streams): frozen trunk of batch t+1 beside conv_map + generator + backward + "
-                                 "Adam of batch t; every batch's arithmetic is the one-stream step's") if pipelined else "1"},
+                       "lanes": ("%d HIP streams measured to run side by side: trunk units 1-8 of batch n | trunk units 9-16 "
+                                 "of batch n-1 | conv_map + generator + backward + exchange + Adam of batch n-2; every batch's "
+                                 "arithmetic is the one-stream step's" % tr._pipe["lanes"]) if pipelined else "1"},
             "final_loss": last["loss"], "final_mse": last["mse"],
             "roofline": roof,
         }
