@@ -9,16 +9,23 @@ Workload (BASELINE.json metric "train-step images/sec"): the `Train
 reference — modified ResNet-50 image encoder (224x298x3, BN in batch-statistics mode) + UNetAcRes
 generator (1 skip) -> 36x48x12, MSE + Huber + 1e-6*KL + slim L2, backward through the generator and
 conv_map, TF-1 Adam — per-GPU batch 32, synthetic seeded inputs ALREADY RESIDENT in HBM, random-init
-weights.  N > 1: one process per GPU, weak scaling by default (32 images per GPU: the series ends on configs[3]'s
-8 x 32 = 256), bucketed RCCL all-reduce of the 43 MB gradient overlapped with backward.  `--scaling strong
+weights.  A "step" is one call of `Trainer.train_step_pipelined`: in steady state it runs ONE batch's worth of every
+part of the step — trunk units 1-8 of batch n, trunk units 9-16 of batch n - 1, conv_map + generator + losses +
+backward + (exchange) + Adam of batch n - 2 — on three HIP streams: K timed calls = K complete steps,
+nothing skipped, every batch's arithmetic bit-identical to the one-stream step (`--no-pipeline`).  N > 1: one process
+per GPU, weak scaling by default (32 images per GPU: the series ends on configs[3]'s 8 x 32 = 256), one RCCL all-reduce
+of the 43 MB gradient per step, issued from the trained part's stream (a whole pipeline tick of slack behind the trunk
+stages); `--no-pipeline`: bucketed, overlapped with backward.  `--scaling strong
 --global-batch 256`: the SAME 256 images per step at every N, as shards of 32 (the batch-norm group) run one after
 the other on each rank with accumulated gradients — the arithmetic of a step does not depend on N.
 
 One JSON line on rank 0.  `roofline` is for the dominant kernel (the 128x128-tile implicit-GEMM
 forward conv that runs the ResNet trunk (LDS-DMA staged, XCD-aware tile order): split-fp16 "f16x3" MFMA by default, exact-f32 MFMA with
 --precision f32): ALGORITHMIC FLOPs (2*M*N*K per conv) of its launches divided by their
-HIP-event-measured duration inside the timed region, against the dense MFMA peak of the dtype the
-matrix cores run in.  The f16x3 kernel issues 3 MFMA FLOPs per algorithmic FLOP (`hw_flop_factor`).  `cpu_baseline` times the CPU oracle
+HIP-event-measured duration, against the dense MFMA peak of the dtype the matrix cores run in.  One stream: the events
+of the timed region.  Pipelined: an event pair on a lane also brackets the wait behind the other lanes' kernels, so the
+kernel is timed in three one-stream steps right after the timed region (rocprofv3 of the same command shows the same
+begin-to-end time per launch in both); the timed region's event figure is reported beside it (`timed_region_event_*`).  The f16x3 kernel issues 3 MFMA FLOPs per algorithmic FLOP (`hw_flop_factor`).  `cpu_baseline` times the CPU oracle
 (PyTorch restatement of the reference's TF-1 graph; TF-1 itself is unavailable offline) on a bounded
 sample on this box's host cores.
 """
