@@ -269,7 +269,10 @@ class Trainer(object):
         # were MEASURED to run beside the caller's and beside each other (ops.concurrent_streams): the runtime maps
         # streams onto a few hardware queues (4 by default; RCCL takes some) and two streams on one queue serialise
         want = (2 if g.stage_calls is not None else 1) + 1
-        lanes = ops.concurrent_streams(dev, cur, want)
+        key = (cur.cuda_stream, want)
+        if getattr(self, "_lane_cache", None) is None or self._lane_cache[0] != key:
+            self._lane_cache = (key, ops.concurrent_streams(dev, cur, want))     # measured once per trainer
+        lanes = list(self._lane_cache[1])
         side_b = lanes.pop() if len(lanes) == want else None
         while len(lanes) < want - 1:
             lanes.append(lanes[-1] if lanes else cur)      # too few queues: stages share a lane (slower, still correct)

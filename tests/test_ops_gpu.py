@@ -1067,3 +1067,23 @@ def test_fp16_operand_storage_conv(device, case):
     cost = float((ref1 - ref3).abs().max() / ref3.abs().max())
     assert 1e-5 < cost < 5e-3, cost                  # what 11-bit operands cost on one layer
     close(st[:, 0].sum(0), ref1.reshape(-1, K).sum(0), tol=2e-4, what="statistics of the fp16-operand conv")
+
+
+def test_pipeline_lanes_are_measured(device):
+    """`ops.concurrent_streams`: the streams handed to the pipeline really run beside the caller's stream and beside
+    each other (a small kernel on one completes while the other is busy) — the runtime maps streams onto a few hardware
+    queues in an order the program cannot see, and two streams on one queue serialise"""
+    from acimg import ops
+
+    cur = torch.cuda.current_stream(device)
+    lanes = ops.concurrent_streams(device, cur, 3)
+    assert 1 <= len(lanes) <= 3
+    assert len(set(s.cuda_stream for s in lanes + [cur])) == len(lanes) + 1
+    work = torch.rand(2048, 2048, device=device) * 0.01
+    for s in lanes:
+        assert ops._runs_beside(cur, s, work) and ops._runs_beside(s, cur, work)
+    # a stream never runs beside itself
+    assert not ops._runs_beside(cur, cur, work)
+    ops.set_side_lane(device, lanes[0], lanes[0])          # "no second lane" is a valid side lane
+    with torch.cuda.stream(lanes[0]):
+        assert ops.side_lane(device)[0] == lanes[0]
