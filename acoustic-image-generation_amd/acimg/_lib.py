@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libacimg.so")
+LIB_PATH = os.environ.get("ACIMG_LIB") or os.path.join(_HERE, "lib", "libacimg.so")     # ACIMG_LIB: another build (A/B tools)
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 
