@@ -327,18 +327,14 @@ class ResNet50Model(object):
                                       ops.LazyPtr(lambda off=off: self.wsplit[off:]))
         off = self._sp3[scope]
         ws_attr = "_tail_ws" + lane
-        if self.stages == 2:
-            # recorded for the staged pipeline: the partial last round of a trunk conv is filled by the other stages'
-            # kernels, so the tail split's hand-off (partial sums, tickets, the last arriver's reads) is pure overhead
-            # there: 7.21 -> 7.13 ms/step without it.  No workspace = no tail split (include/acimg.h); the one-stream
-            # entry runs the same plan, so both stay bit-identical.
-            tail_ws = None
-        else:
-            if getattr(self, ws_attr, None) is None:
-                # partial sums + tile tickets of the trunk kernel's tail split; used by nothing else, zero at start
-                setattr(self, ws_attr, torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8,
-                                                   device=self.session.device))
-            tail_ws = getattr(self, ws_attr)
+        if getattr(self, ws_attr, None) is None:
+            # partial sums + tile tickets of the trunk kernel's tail split; used by nothing else, zero at start
+            setattr(self, ws_attr, torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8,
+                                               device=self.session.device))
+        # (recording the staged trunk WITHOUT the tail split — the other stages fill the partial last rounds anyway —
+        #  was measured: 7.21 -> 7.13 ms/step pipelined, but 8.96 -> 9.22 ms on one stream and 249 -> 223 TFLOP/s for
+        #  the kernel with the chip to itself; the plan is shared by both entry points, so the split stays)
+        tail_ws = getattr(self, ws_attr)
         ops.conv2d_fwd_split3p(plan, d, xplanes, self._lo_off(self.N * hw[0] * hw[1], cin),
                                ops.LazyPtr(lambda off=off: self.wsplit[off:]), out, stats if training else None,
                                tail_ws=tail_ws, terms=self._terms, side=side)
