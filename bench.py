@@ -24,8 +24,9 @@ forward conv that runs the ResNet trunk (LDS-DMA staged, XCD-aware tile order): 
 --precision f32): ALGORITHMIC FLOPs (2*M*N*K per conv) of its launches divided by their
 HIP-event-measured duration, against the dense MFMA peak of the dtype the matrix cores run in.  One stream: the events
 of the timed region.  Pipelined: an event pair on a lane also brackets the wait behind the other lanes' kernels, so the
-kernel is timed in three one-stream steps right after the timed region (rocprofv3 of the same command shows the same
-begin-to-end time per launch in both); the timed region's event figure is reported beside it (`timed_region_event_*`).  The f16x3 kernel issues 3 MFMA FLOPs per algorithmic FLOP (`hw_flop_factor`).  `cpu_baseline` times the CPU oracle
+kernel is timed in three one-stream steps right after the timed region (rocprofv3 --kernel-trace serialises kernels
+across streams, so its per-kernel average is the kernel alone on the chip too, and agrees); the timed region's event
+figure is reported beside it (`timed_region_event_*`).  The f16x3 kernel issues 3 MFMA FLOPs per algorithmic FLOP (`hw_flop_factor`).  `cpu_baseline` times the CPU oracle
 (PyTorch restatement of the reference's TF-1 graph; TF-1 itself is unavailable offline) on a bounded
 sample on this box's host cores.
 """
@@ -494,11 +495,11 @@ def main():
                 "share_of_step_time": (ms / args.steps) / (dt / args.steps * 1e3)}
 
     if roof is not None and seq_events:
-        # Two lanes: an event pair on lane A also brackets the time the launch waits behind the other lane's kernels, so
-        # it over-states the kernel's own duration (rocprofv3 --kernel-trace of this very command shows the kernel's
-        # begin-to-end time unchanged: profiles/r02/bench_b32_kernel_stats_r02m.csv vs ..._onelane.csv).  The kernel is
-        # therefore timed with the chip to itself, in one-stream steps right after the timed region; the event figure of
-        # the timed region is kept beside it.
+        # Pipelined: an event pair on a lane also brackets the time the launch waits behind the other lanes' kernels, so
+        # it over-states the kernel's own duration.  The kernel is therefore timed with the chip to itself, in one-stream
+        # steps right after the timed region — which is also what rocprofv3 --kernel-trace of this command reports (it
+        # serialises kernels across streams: profiles/r02/bench_b32_kernel_stats_r02p.csv); the event figure of the timed
+        # region is kept beside it.
         ms1 = sum(e0.elapsed_time(e1) for _, e0, e1 in seq_events)
         fl1 = sum(flops[i] for i, _, _ in seq_events)
         roof["timed_region_event_ms"] = roof["avg_launch_ms"]
