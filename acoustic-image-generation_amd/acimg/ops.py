@@ -443,6 +443,11 @@ def conv2d_fwd_split3_stats_rows(d):
     return _L().acimg_conv2d_fwd_split3_stats_rows(C.byref(d))
 
 
+def conv2d_fwd_split3p_stats_rows(d):
+    """statistics rows of conv2d_fwd_split3p(terms=3) for this shape under the CURRENT configuration"""
+    return _L().acimg_conv2d_fwd_split3p_stats_rows(C.byref(d))
+
+
 def conv2d_fwd_split3_tiling(d):
     """(BM, BN, persistent) of the pre-split forward conv launch for `d`"""
     out = (C.c_int * 3)()

@@ -310,7 +310,7 @@ class ResNet50Model(object):
         P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
         d = ops.conv_desc(self.N, hw[0], hw[1], cin, cout, kh, kw, stride, padding, ldx=cin, ldy=up4(cout),
                           ldw=up4(cout))
-        rows = ops.conv2d_fwd_split3_stats_rows(d)
+        rows = ops.conv2d_fwd_split3p_stats_rows(d) if self._terms == 3 else ops.conv2d_fwd_split3_stats_rows(d)
         lane = ("_side" if side else "") + tag
         if lane:
             self._lane_stats_need = getattr(self, "_lane_stats_need", {})

@@ -15,6 +15,7 @@
 #include "wgrad_split3_kernel.hpp"
 #include "igemm_split3d_kernel.hpp"
 #include "igemm_split3dp_kernel.hpp"
+#include "igemm_split3r_kernel.hpp"
 #include <cstdlib>
 #include <algorithm>
 
@@ -638,7 +639,7 @@ static TileCfg pick_cfg(int M, int Ngemm) {
 
 // Tuning record (acimg_configure): plain ints, defaults compiled in, written only by acimg_configure and never by a
 // launch; the launch heuristics below read it instead of the process environment.
-static AcimgConfig g_cfg = {320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0};
+static AcimgConfig g_cfg = {320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0};
 
 static int pick_splits(int M, int Ngemm, TileCfg c, int kiters) {
     // measured on the generator's 12x16 layers (192-288 tiles of 64x64, 36+ K steps: tools/splitk_sweep.sh):
@@ -1188,7 +1189,7 @@ int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
 
 int acimg_config_default(AcimgConfig* c) {
     if (!c) return fail(ACIMG_EINVAL, "config_default: null");
-    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0};
+    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0};
     return ACIMG_OK;
 }
 
@@ -1201,6 +1202,9 @@ int acimg_configure(const AcimgConfig* c) {
     if (c->trunk_stagger < 0 || c->trunk_stagger > 100) return fail(ACIMG_EINVAL, "configure: trunk_stagger is a percentage");
     if (c->trunk_bk != 0 && c->trunk_bk != 32 && c->trunk_bk != 64)
         return fail(ACIMG_EINVAL, "configure: trunk_bk must be 0 (per layer), 32 or 64");
+    if (c->trunk_ring < 0 || c->trunk_ring > 2) return fail(ACIMG_EINVAL, "configure: trunk_ring is 0, 1 or 2");
+    if (c->trunk_ring_bm != 0 && c->trunk_ring_bm != 128 && c->trunk_ring_bm != 256)
+        return fail(ACIMG_EINVAL, "configure: trunk_ring_bm must be 0 (per shape), 128 or 256");
     if (c->split3_tile_bm || c->split3_tile_bn) {
         const int bm = c->split3_tile_bm, bn = c->split3_tile_bn;
         if (!((bm == 128 && bn == 128) || (bm == 64 && bn == 128) || (bm == 128 && bn == 64)))
@@ -1506,6 +1510,25 @@ static bool split3p_persistent(const Split3Cfg& c, long tiles) {
     return g_cfg.trunk_persistent == 2 || (g_cfg.trunk_persistent == 1 && tiles >= 512);
 }
 
+// Ring kernel (igemm_split3r_kernel.hpp) for a pre-split trunk conv, and with how many tile rows: 0 = not on it.
+// 256-row tiles halve the operand and fragment bytes per MFMA but leave half as many tiles: taken where at least two
+// rounds of them exist on the 256 CUs (tools/trunk_shapes.py, profiles/r03/).
+static int ring_rows(const AcimgConvDesc* d, int terms) {
+    if (!g_cfg.trunk_ring || terms != 3) return 0;
+    const int M = d->N * d->OH * d->OW;
+    const Split3Cfg c = pick_split3(M, d->K);
+    if (c.bm != 128 || c.bn != 128) return 0;
+    if (g_cfg.trunk_ring_bm) return g_cfg.trunk_ring_bm;
+    const long t256 = (long)cdiv(M, 256) * cdiv(d->K, 128);
+    return t256 >= 500 ? 256 : 128;
+}
+
+int acimg_conv2d_fwd_split3p_stats_rows(const AcimgConvDesc* d) {
+    const int M = d->N * d->OH * d->OW;
+    const int rr = ring_rows(d, 3);
+    return cdiv(M, rr ? rr : pick_split3(M, d->K).bm);
+}
+
 int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out) {
     if (!d || !out) return fail(ACIMG_EINVAL, "conv2d_fwd_split3_tiling: null argument");
     const int M = d->N * d->OH * d->OW;
@@ -1713,7 +1736,7 @@ static int dgrad_split_onthefly(const AcimgConvDesc* d, const float* gy, int ldg
 // ---- tail split of the trunk kernel: which tiles to cut, and into how many K ranges ------------------------
 struct TailPlan { int whole, s, rem; };
 static int resident_slots(int which, const void* fn, int threads, size_t lds) {
-    static int cache[5] = {0, 0, 0, 0, 0};
+    static int cache[7] = {0, 0, 0, 0, 0, 0, 0};
     if (!cache[which]) {
         int dev = 0, ncu = 0, per = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -1721,7 +1744,7 @@ static int resident_slots(int which, const void* fn, int threads, size_t lds) {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, threads, lds) != hipSuccess || ncu <= 0 || per <= 0) {
             (void)hipGetLastError();
             ncu = 256;                    // MI355X; no device (CPU-side sizing queries): same answer
-            per = which == 4 ? 1 : (which == 0 || which == 3) ? 2 : 3;
+            per = which >= 4 ? 1 : (which == 0 || which == 3) ? 2 : 3;
         }
         cache[which] = ncu * per;
     }
@@ -1751,7 +1774,7 @@ static TailPlan pick_tail(int T, int P, int KI, int max_units) {
     }
     return best;
 }
-static constexpr int TS_MAX_UNITS = 1024;      // partial slots (64 KiB each for a 128x128 tile)
+static constexpr int TS_MAX_UNITS = 1024;      // partial slots (64 KiB each for a 128x128 tile; a 256x128 tile takes two)
 static constexpr size_t TS_COUNTER_BYTES = 4096;
 
 #if defined(ACIMG_STAMP) || defined(ACIMG_ABLATE)
@@ -1814,6 +1837,31 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
                    : which == 1 ? (const void*)igemm_split3d_kernel<64, 128, 1, 4, 256, 2, 2>
                                 : (const void*)igemm_split3d_kernel<128, 64, 2, 2, 256, 2, 2>;
     if ((long)p.M * d->ldy * 4 >= (1L << 31)) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: output >= 2 GiB");
+    if (const int rr = ring_rows(d, terms)) {
+        // one workgroup per CU walks units blockIdx.x, blockIdx.x + P, ... (whole tiles, then K ranges of the tail tiles)
+        p.ras_tiles_m = cdiv(p.M, rr);
+        p.ras_gm = std::max(1, 32 / p.ras_gn);       // 32 resident tiles per XCD
+        const int Tr = p.ras_tiles_m * p.ras_tiles_n;
+        const size_t lds_r = (size_t)3 * 2 * (rr + 128) * 64 + 4 * 2 * 128 * 4;
+        const void* fr = rr == 256 ? (const void*)igemm_split3r_kernel<4> : (const void*)igemm_split3r_kernel<2>;
+        static bool attr[2] = {false, false};        // > 64 KiB of dynamic LDS needs the opt-in once per process
+        if (!attr[rr == 256]) {
+            (void)hipFuncSetAttribute(fr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+            attr[rr == 256] = true;
+        }
+        const int Pr = resident_slots(rr == 256 ? 5 : 6, fr, 512, lds_r);
+        TailPlan tr{Tr, 1, 0};
+        if (ws && ws_bytes >= acimg_conv2d_fwd_split3p_workspace(d))
+            tr = pick_tail(Tr, Pr, p.kiters, TS_MAX_UNITS * 128 / rr);
+        p.ts_whole = tr.whole; p.ts_s = tr.s;
+        p.ts_counters = static_cast<int*>(ws);
+        p.ts_partial = ws ? reinterpret_cast<float*>(static_cast<char*>(ws) + TS_COUNTER_BYTES) : nullptr;
+        const int units = tr.whole + tr.rem * tr.s;
+        const int nwg = std::min(units, Pr);
+        if (rr == 256) hipLaunchKernelGGL((igemm_split3r_kernel<4>), dim3(nwg), dim3(512), lds_r, st, p, units, nwg);
+        else hipLaunchKernelGGL((igemm_split3r_kernel<2>), dim3(nwg), dim3(512), lds_r, st, p, units, nwg);
+        return check_launch("conv2d_fwd_split3p (ring)");
+    }
     const bool persistent = split3p_persistent(c, T);
     // K-step depth of the persistent kernel: 32 = the one-tile kernel's image (2 workgroups / CU); 64 = full 128-byte
     // operand lines per DMA request, 1 workgroup / CU (measured slower on every trunk shape: experiments only)

@@ -1,0 +1,461 @@
+// RING form of the trunk kernel (round 3): the same f16x3 product on pre-split activations as igemm_split3d /
+// igemm_split3dp_kernel (same LDS rows, same per-accumulator term order, hence the same bits per output element), but
+// the K loop is a software pipeline INSIDE every wave instead of barrier-separated phases.
+//
+// Why (profiles/r02/ablate_probe_r02.txt): in the two-stage kernels every wave of a CU reads its 12 fragments right
+// behind the step barrier (768 LDS cycles for 16 waves), then multiplies (1536 MFMA cycles per SIMD), then queues the
+// next stage's LDS-DMA requests at the CU's one texture addresser (64 KiB at 64 B/clk = 1024 cycles, every wave
+// blocked on its own requests): the three phases ADD (a K step of two co-resident workgroups takes ~3000 cycles, the
+// ablation's parts sum to the whole).  Here
+//   * one workgroup per CU, 8 waves, 256 VGPRs: wave tile 64x64 (TM = 4: workgroup tile 256x128) or 32x64 (TM = 2:
+//     128x128 for the layers with few row tiles): 48 KiB of operands and 128 KiB of fragment reads per 1536 MFMA cycles
+//     instead of 64 and 192;
+//   * the fragments of step g + 1 are read WHILE the 48 MFMAs of step g run: the hi planes (live through all three
+//     sweeps) into a second register set, bl' under the second and third sweep and al' under the third in place - one
+//     or two ds_read_b128 per group of four MFMAs;
+//   * a ring of THREE LDS slots: step g multiplies D(g) from registers, reads D(g+1) from its slot, and requests D(g+3)
+//     into the slot D(g) left - one request between groups of MFMAs, never a burst; a request has between one and two
+//     whole steps to land (counted vmcnt at the end of a step: everything but the youngest stage);
+//   * ONE barrier per step (everyone's pieces of D(g+1) landed; everyone's reads of D(g) done);
+//   * the operand stream does not stop at tile boundaries: the loader cursor walks (unit, K step) pairs ahead of the
+//     multiplier, so the first steps of the next tile are in LDS (and its first fragments in registers) when a tile's
+//     last MFMA issues;
+//   * the output tile leaves through WAVE-PRIVATE staging (16 rows x 256 B per wave in the slot D(g) left; the
+//     request that would have refilled it is deferred by one step): no workgroup barrier in the epilogue, 256-byte row
+//     segments, stores left in flight under the next tile's MFMAs;
+//   * units = whole tiles, then the K ranges of the tail tiles (same hand-off protocol as the other trunk kernels:
+//     sc1 partial slabs + ticket, last arriver adds in range order), all in one stream.
+// LDS: 3 slots x [A hi | A lo | B hi | B lo] (48 / 32 KiB each), then [4][2][128] floats of statistics scratch.
+#pragma once
+#include "igemm_split3dp_kernel.hpp"
+
+namespace acimg {
+
+template <int RA>
+struct TileAddrR {
+    int a_off[RA], a_ih0[RA], a_iw0[RA];   // this lane's row of each of the wave's A pieces
+    unsigned b_goff;                       // this lane's row of the wave's B piece, byte offset at k = 0 (or OOB)
+};
+
+template <int TM>
+__global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams p, const int n_units,
+                                                               const int stride_units) {
+    constexpr int BK = 32, BN = 128, NTHR = 512, NW = 8, WGM = 4, WGN = 2, TN = 4;
+    constexpr int WTM = TM * 16, WTN = TN * 16, BM = WGM * WTM;
+    constexpr int ROWB = BK * 2;
+    constexpr int A_PLANE = BM * ROWB, B_PLANE = BN * ROWB;
+    constexpr int SLOT = 2 * A_PLANE + 2 * B_PLANE;
+    constexpr int RA = BM / 16 / NW;                 // A pieces (16 rows x 64 B of one plane) per wave and plane: 2 / 1
+    constexpr int RPS = 2 * (RA + 1);                // LDS-DMA requests per stage and wave: 6 / 4
+    constexpr int NG = 3 * TM;                       // groups of TN MFMAs per step: 12 / 6
+    static_assert((TM + TN) % TM == 0 && TN % TM == 0 && WGM * WGN == NW && (BM / 16) % NW == 0 && BN / 16 == NW,
+                  "tile / wave mapping");
+    static_assert(NW * 4096 <= SLOT, "wave-private output staging lives in one ring slot");
+    typedef TileAddrR<RA> Tile;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+    float* const red = smem + 3 * SLOT / 4;          // [WGM][2][BN] statistics partials; red[0] doubles as the tail flag
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+    const int li = lane & 15, g4 = lane >> 4;
+    const int prow = lane >> 2, pch = lane & 3;      // this lane's row / physical chunk inside a DMA piece
+    const int kc_sw = pch ^ swz(prow);               // logical k chunk it fetches (pieces start at multiples of 16 rows)
+    const int Ktot = p.ntaps * p.C;
+    const int ohw = p.OH * p.OW;
+    const unsigned b_lo_off = (unsigned)((long)p.Nld * Ktot * 2);
+    const EpiParams& e = p.e;
+
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
+
+    // fragment read offsets inside a slot (row * 64 + swizzled chunk): fragment i of A is 1024 i bytes further
+    const int fa_off = (wm * WTM + li) * ROWB + ((g4 ^ swz(li)) << 4);
+    const int fb_off = 2 * A_PLANE + (wn * WTN + li) * ROWB + ((g4 ^ swz(li)) << 4);
+
+    // ---- units: [0, ts_whole) whole tiles, then ts_s K ranges per tail tile -------------------------------------
+    auto unit_range = [&](int u, int& vt, int& kb, int& ke, int& chunk) __attribute__((always_inline)) {
+        if (p.ts_s > 1 && u >= p.ts_whole) {
+            const int uu = u - p.ts_whole;
+            const int t = uu / p.ts_s;
+            chunk = uu - t * p.ts_s;
+            vt = p.ts_whole + t;
+            const int base = p.kiters / p.ts_s, extra = p.kiters - base * p.ts_s;
+            kb = chunk * base + min(chunk, extra);
+            ke = kb + base + (chunk < extra ? 1 : 0);
+        } else {
+            vt = u;
+            chunk = -1;
+            kb = 0;
+            ke = p.kiters;
+        }
+    };
+
+    // ---- loader: walks (unit, K step) ahead of the multiplier ----------------------------------------------------
+    Tile lt;
+    KCursorP lkc{0, 0, 0, 0};
+    int l_unit = blockIdx.x, l_k = 0, l_ke = 0, l_slot = 0, n_issued = 0;
+    unsigned st_aoff[RA] = {}, st_boff = 0;          // the stage being requested: per-lane source offsets
+    int st_base = 0;                                 // ... and its slot's LDS byte offset
+
+    auto setup = [&](int vt) __attribute__((always_inline)) {
+        int mt_, nt_;
+        raster_tile(p, vt, mt_, nt_);
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int row = (wid + j * NW) * 16 + prow;
+            const int m = mt_ * BM + row;
+            if (m < p.M) {
+                const int img = m / ohw;
+                const int r2 = m - img * ohw;
+                const int oh = r2 / p.OW;
+                const int ow = r2 - oh * p.OW;
+                lt.a_ih0[j] = oh * p.stride - p.pad_t;
+                lt.a_iw0[j] = ow * p.stride - p.pad_l;
+                lt.a_off[j] = ((img * p.H + lt.a_ih0[j]) * p.W + lt.a_iw0[j]) * p.lda * 2 + kc_sw * 16;
+            } else {
+                lt.a_ih0[j] = -(1 << 28);
+                lt.a_iw0[j] = -(1 << 28);
+                lt.a_off[j] = 0;
+            }
+        }
+        const int n = nt_ * BN + wid * 16 + prow;
+        lt.b_goff = n < p.Nld ? (unsigned)(((long)n * Ktot + kc_sw * 8) * 2) : OOB;
+    };
+    // stages the loader can still issue, capped at 2 (a unit has at least 2 steps)
+    auto loader_avail = [&]() __attribute__((always_inline)) -> int {
+        const int left = l_ke - l_k;
+        if (left >= 2) return 2;
+        return left + (l_unit + stride_units < n_units ? 2 : 0) >= 2 ? 2 : left;
+    };
+    auto begin_stage = [&]() __attribute__((always_inline)) {
+        if (l_k == l_ke) {                           // next unit of this workgroup's list
+            if (l_ke != 0) l_unit += stride_units;
+            int vt, chunk;
+            unit_range(l_unit, vt, l_k, l_ke, chunk);
+            setup(vt);
+            lkc = kcursor_at<BK>(l_k, p.C, p.S);
+        }
+        const int tapoff = ((lkc.r * p.W + lkc.s) * p.lda + lkc.c0) * 2;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int ih = lt.a_ih0[j] + lkc.r, iw = lt.a_iw0[j] + lkc.s;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            st_aoff[j] = ok ? (unsigned)(lt.a_off[j] + tapoff) : OOB;
+        }
+        st_boff = lt.b_goff == OOB ? OOB : lt.b_goff + (unsigned)(lkc.q * (BK * 2));
+        st_base = l_slot * SLOT;
+        lkc = kcursor_next<BK>(lkc, p.C, p.S);
+        ++l_k;
+        l_slot = l_slot == 2 ? 0 : l_slot + 1;
+        ++n_issued;
+    };
+    // request r of the stage begun last: r = 0, 1: the B piece (hi, lo); then the A pieces (hi, lo each); r, like every
+    // index parameter below, is a literal at each call site and folds after inlining
+    auto issue_req = [&](const int r) __attribute__((always_inline)) {
+        if (r < 2) {
+            char* dst = lds + st_base + 2 * A_PLANE + r * B_PLANE + wid * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)dst, 16, st_boff, r ? (int)b_lo_off : 0, 0, 0);
+        } else {
+            const int j = (r - 2) >> 1, pl = (r - 2) & 1;
+            char* dst = lds + st_base + pl * A_PLANE + (wid + j * NW) * 1024;
+            const unsigned ao = st_aoff[j];          // (a scalar copy: an array element as the builtin's offset operand
+                                                     //  makes hipcc's host pass drop the kernel without a diagnostic)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, ao, pl ? (int)p.a_lo_off : 0, 0, 0);
+        }
+    };
+    auto issue_stage_now = [&]() __attribute__((always_inline)) {                   // prologue only: a whole stage in one go
+        begin_stage();
+#pragma unroll
+        for (int r = 0; r < RPS; ++r) issue_req(r);
+    };
+    // request `idx` of the `n` stages a step issues (idx < n * RPS): the stage begins with its first request
+    auto issue_seq = [&](const int idx) __attribute__((always_inline)) {
+        if (idx % RPS == 0) begin_stage();
+        issue_req(idx % RPS);
+    };
+
+    // ---- multiplier state ----------------------------------------------------------------------------------------
+    f32x4 acc[TM][TN];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    // fragments: the hi planes are live until a step's last sweep, so they are DOUBLE BUFFERED; bl is dead after the first
+    // sweep and al after the second, so the next step's bl / al are read in place under the sweeps that follow
+    h16x8 fah[2][TM], fbh[2][TN], fal[TM], fbl[TN];
+
+    // fragment reads of the NEXT step, by the sweep they are issued under: 0: ah', bh' into the other set (q in
+    // [0, TM + TN)); 1: bl' in place (q in [0, TN)); 2: al' in place (q in [0, TM))
+    auto read_frag = [&](const int s, const int kind, const int q, const char* slot) __attribute__((always_inline)) {
+        if (kind == 0) {
+            if (q < TM) fah[s][q] = *reinterpret_cast<const h16x8*>(slot + fa_off + q * 1024);
+            else fbh[s][q - TM] = *reinterpret_cast<const h16x8*>(slot + fb_off + (q - TM) * 1024);
+        } else if (kind == 1) {
+            fbl[q] = *reinterpret_cast<const h16x8*>(slot + fb_off + B_PLANE + q * 1024);
+        } else {
+            fal[q] = *reinterpret_cast<const h16x8*>(slot + fa_off + A_PLANE + q * 1024);
+        }
+    };
+
+    int c_unit = blockIdx.x, c_k = 0, c_ke = 0, c_vt = 0, c_chunk = -1, c_slot = 0, g = 0;
+    int pend_mt = -1, pend_n0 = 0;                   // statistics partials waiting in `red` for their flush
+    int* const flag = reinterpret_cast<int*>(red);
+
+    // statistics partials of the tile finished last: the WGM wave rows meet here, one step (one barrier) later
+    auto flush_stats = [&]() __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+            e.stats, 0, e.stats ? (unsigned)((long)p.ras_tiles_m * 2 * e.stats_ld * 4) : 0u, 0x00020000);
+        const int which = (tid >> 7) & 1, col = tid & (BN - 1);
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) sum += red[(w * 2 + which) * BN + col];
+        const int n = pend_n0 + col;
+        const unsigned soff = (tid < 2 * BN && n < e.stats_ld)
+                                  ? (unsigned)((((long)pend_mt * 2 + which) * e.stats_ld + n) * 4) : OOB;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), rsS, soff, 0, 0);
+        pend_mt = -1;
+    };
+
+    // Output tile of unit-tile `vt` through this wave's 4 KiB of ring slot `slot`: 16 pixel rows x 64 channels per
+    // pass; 16-byte chunk c of row r lives at chunk c ^ r (accumulator-shaped writes and row-shaped reads both conflict
+    // free).  Only this wave touches its region: no barrier.  EST + 0 vector-memory stores per wave (out-of-range
+    // offsets for tail rows).
+    auto epilogue = [&](int vt, int slot) __attribute__((always_inline)) {
+        int mt, nt;
+        raster_tile(p, vt, mt, nt);
+        const __amdgpu_buffer_rsrc_t rsY =
+            __builtin_amdgcn_make_buffer_rsrc(e.Y, 0, (unsigned)((long)e.M * e.ldy * 4), 0x00020000);
+        // every index below is re-derived from an opaque copy of the thread id: otherwise the compiler hoists this block's
+        // loop-invariant addresses out of the unit loop and keeps them in registers through the K loop
+        int te = tid;
+        asm volatile("" : "+v"(te));
+        const int e_lane = te & 63, e_wid = te >> 6;
+        const int e_wm = e_wid / WGN, e_wn = e_wid % WGN, e_li = e_lane & 15, e_g = e_lane >> 4;
+        const int m0 = mt * BM + e_wm * WTM, n0 = nt * BN + e_wn * WTN;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] *= SPLIT3_OUTSCALE;
+        if (e.stats) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x4 s1 = acc[0][j], s2 = acc[0][j] * acc[0][j];
+#pragma unroll
+                for (int i = 1; i < TM; ++i) {
+                    s1 += acc[i][j];
+                    s2 += acc[i][j] * acc[i][j];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s1[k] = row16_sum(s1[k]);
+                    s2[k] = row16_sum(s2[k]);
+                }
+                if (e_li == 0) {   // rows past M hold exact zeros (their A pieces were out of range): they add nothing
+                    const int n = e_wn * WTN + j * 16 + e_g * 4;
+                    *reinterpret_cast<f32x4*>(red + (e_wm * 2 + 0) * BN + n) = s1;
+                    *reinterpret_cast<f32x4*>(red + (e_wm * 2 + 1) * BN + n) = s2;
+                }
+            }
+            pend_mt = mt;
+            pend_n0 = nt * BN;
+        }
+        f32x4* const stg = reinterpret_cast<f32x4*>(lds + slot * SLOT + e_wid * 4096);
+        const int rr = e_lane >> 4, cc = e_lane & 15;    // row-shaped view: row rr + 4 k, chunk cc
+        const int nn = n0 + 4 * cc;
+        const bool n_ok = nn < e.Nstore;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) stg[e_li * 16 + ((j * 4 + e_g) ^ e_li)] = acc[i][j];
+            asm volatile("" ::: "memory");
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = stg[(rr + 4 * k) * 16 + (cc ^ (rr + 4 * k))];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = m0 + i * 16 + rr + 4 * k;
+                const unsigned off = (n_ok && m < e.M) ? ((unsigned)m * (unsigned)e.ldy + (unsigned)nn) * 4u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[k]), rsY, off, 0, 0);
+            }
+        }
+    };
+
+    // K range of a tail tile: park the partial sums (sc1), take a ticket; the last arriver adds all ranges in range
+    // order (-> true: the caller runs the epilogue)
+    auto handoff = [&](int vt, int chunk) __attribute__((always_inline)) -> bool {
+        const int tl = vt - p.ts_whole;
+        float* const slot0 = p.ts_partial + (long)tl * p.ts_s * (BM * BN);
+        const __amdgpu_buffer_rsrc_t rsP =
+            __builtin_amdgcn_make_buffer_rsrc(slot0 + (long)chunk * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsP, tid * 16,
+                                                       (i * TN + j) * NTHR * 16, 16);
+        // (`red` carries the flag below: a tail unit has at least two steps, so the statistics partials of the unit
+        //  before it were flushed at the top of its first step)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) {
+            const int ticket = __hip_atomic_fetch_add(p.ts_counters + tl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == p.ts_s - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(p.ts_counters + tl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *flag = last;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int last = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(flag));   // uniform
+        zero_acc();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // everyone has read the flag before `red` is reused
+        if (!last) return false;
+        for (int c = 0; c < p.ts_s; ++c) {
+            const __amdgpu_buffer_rsrc_t rsQ =
+                __builtin_amdgcn_make_buffer_rsrc(slot0 + (long)c * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {       // TN loads in flight at a time (registers)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)     // sc1 loads: never a stale L1 / L2 copy
+                    acc[i][j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                               rsQ, tid * 16, (i * TN + j) * NTHR * 16, 16));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return true;
+    };
+
+    // ---- one K step: MFMAs of D(g) from set P, reads of D(g+1) into set 1 - P, requests in between ---------------
+    // returns false after the last step of this workgroup's stream
+    auto step = [&](const int P) __attribute__((always_inline)) -> bool {
+        __builtin_amdgcn_s_barrier();                // D(g+1) landed for everyone; everyone's reads of D(g) are done
+        asm volatile("" ::: "memory");
+        if (pend_mt >= 0) flush_stats();
+        const bool unit_end = c_k + 1 == c_ke;
+        const bool has_next = !(unit_end && c_unit + stride_units >= n_units);
+        // stages to issue now: up to D(g+3), or D(g+2) in a unit's last step (its slot stages the output tile)
+        int n_issue = (g + (unit_end ? 3 : 4)) - n_issued;
+        {
+            const int avail = loader_avail();
+            n_issue = n_issue < avail ? n_issue : avail;
+            n_issue = n_issue < 0 ? 0 : n_issue;
+        }
+        const int nslot = c_slot == 2 ? 0 : c_slot + 1;
+        const char* const rd = lds + nslot * SLOT;
+#define ACIMG_R_GROUP(G)                                                                                              \
+        {                                                                                                             \
+            constexpr int T_ = (G) / TM, i_ = (G) % TM;                                                               \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                          \
+                if constexpr (T_ == 0)                                                                                \
+                    acc[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbl[j], fah[P][i_], acc[i_][j], 0, 0, 0);     \
+                else if constexpr (T_ == 1)                                                                           \
+                    acc[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[P][j], fal[i_], acc[i_][j], 0, 0, 0);     \
+                else                                                                                                  \
+                    acc[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[P][j], fah[P][i_], acc[i_][j], 0, 0, 0);  \
+            }                                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            if (has_next) {                                                                                           \
+                if constexpr (T_ == 0) {                                                                              \
+                    constexpr int n_ = (TM + TN) / TM;                                                                \
+                    read_frag(1 - P, 0, i_ * n_, rd);                                         \
+                    read_frag(1 - P, 0, i_ * n_ + 1, rd);                                     \
+                    if constexpr (n_ == 3) read_frag(1 - P, 0, i_ * n_ + 2, rd);              \
+                } else if constexpr (T_ == 1) {                                                                       \
+                    constexpr int n_ = TN / TM;                                                                       \
+                    read_frag(0, 1, i_ * n_, rd);                                             \
+                    if constexpr (n_ == 2) read_frag(0, 1, i_ * n_ + 1, rd);                  \
+                } else {                                                                                              \
+                    read_frag(0, 2, i_, rd);                                                  \
+                }                                                                                                     \
+            }                                                                                                         \
+            if (n_issue == 2) {                                                                                       \
+                constexpr int lo_ = (G) * 2 * RPS / NG, hi_ = ((G) + 1) * 2 * RPS / NG;                               \
+                if constexpr (hi_ > lo_) issue_seq(lo_);                                                      \
+                if constexpr (hi_ > lo_ + 1) issue_seq(lo_ + 1);                                              \
+            } else if (n_issue == 1) {                                                                                \
+                constexpr int lo_ = (G) * RPS / NG, hi_ = ((G) + 1) * RPS / NG;                                       \
+                if constexpr (hi_ > lo_) issue_seq(lo_);                                                      \
+            }                                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+        }
+        ACIMG_R_GROUP(0) ACIMG_R_GROUP(1) ACIMG_R_GROUP(2) ACIMG_R_GROUP(3) ACIMG_R_GROUP(4) ACIMG_R_GROUP(5)
+        if constexpr (NG == 12) {
+            ACIMG_R_GROUP(6) ACIMG_R_GROUP(7) ACIMG_R_GROUP(8) ACIMG_R_GROUP(9) ACIMG_R_GROUP(10) ACIMG_R_GROUP(11)
+        }
+#undef ACIMG_R_GROUP
+        // D(g+2) must have landed before the next barrier: everything but the youngest stage, if one was issued
+        // beyond it in this step
+        if (n_issued == g + 4) wait_vmcnt<RPS>();
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ++g;
+        ++c_k;
+        const int slot_now = c_slot;                 // the slot D(g) left: free until the next barrier
+        c_slot = nslot;
+        if (unit_end) {
+            bool whole = true;                       // this workgroup holds the finished tile
+            if (c_chunk >= 0) whole = handoff(c_vt, c_chunk);
+            if (whole) epilogue(c_vt, slot_now);
+            zero_acc();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!has_next) return false;
+            c_unit += stride_units;
+            unit_range(c_unit, c_vt, c_k, c_ke, c_chunk);
+        }
+        return true;
+    };
+
+    // ---- prologue -------------------------------------------------------------------------------------------------
+    if (c_unit >= n_units) return;
+    unit_range(c_unit, c_vt, c_k, c_ke, c_chunk);
+    {
+        // D(0), D(1) exist (a unit has at least two steps); D(2) if the stream has a third step
+        issue_stage_now();
+        issue_stage_now();
+        const bool third = loader_avail() >= 1;
+        if (third) issue_stage_now();
+        if (third) wait_vmcnt<2 * RPS>();
+        else wait_vmcnt<RPS>();
+        __builtin_amdgcn_s_barrier();
+        const char* const rd0 = lds;
+        read_frag(0, 0, 0, rd0); read_frag(0, 0, 1, rd0);
+        read_frag(0, 0, 2, rd0); read_frag(0, 0, 3, rd0);
+        read_frag(0, 0, 4, rd0); read_frag(0, 0, 5, rd0);
+        if constexpr (TM == 4) {
+            read_frag(0, 0, 6, rd0); read_frag(0, 0, 7, rd0);
+        }
+        read_frag(0, 1, 0, rd0); read_frag(0, 1, 1, rd0);
+        read_frag(0, 1, 2, rd0); read_frag(0, 1, 3, rd0);
+        read_frag(0, 2, 0, rd0); read_frag(0, 2, 1, rd0);
+        if constexpr (TM == 4) {
+            read_frag(0, 2, 2, rd0); read_frag(0, 2, 3, rd0);
+        }
+        if (third) wait_vmcnt<RPS>();
+        else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    for (;;) {      // (one shared copy of the unit-end code keeps BOTH hi-plane sets live at the merge: measured worse)
+        if (!step(0)) break;
+        if (!step(1)) break;
+    }
+    // the last tile's statistics partials
+    __builtin_amdgcn_s_barrier();
+    if (pend_mt >= 0) flush_stats();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace acimg

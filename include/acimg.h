@@ -108,6 +108,10 @@ typedef struct AcimgConfig {
                                 estimated time late (0 = together) */
     int32_t trunk_dma_pos;   /* persistent kernel: a K step's operand requests 0 = in one burst after the step barrier,
                                 1 = spread under the MFMA block (B after the first sweep, A after the second) */
+    int32_t trunk_ring;      /* 128-column trunk convs on the RING kernel (one workgroup per CU, three LDS slots, fragments
+                                double buffered in registers, requests spread between the MFMAs): 0 never, 1 where it was
+                                measured to pay, 2 always */
+    int32_t trunk_ring_bm;   /* ring kernel's tile rows: 0 = per shape, else 128 or 256 (experiments) */
 } AcimgConfig;
 int acimg_config_default(AcimgConfig* cfg);
 int acimg_configure(const AcimgConfig* cfg);
@@ -185,6 +189,9 @@ int acimg_conv2d_dgrad_bf16(const AcimgConvDesc* d, const float* gy, int ldgy, c
  * the last, partially filled round of workgroups into K ranges that meet in the workspace (deterministic: fixed
  * range order).  Without it every tile is computed by one workgroup. */
 size_t acimg_conv2d_fwd_split3p_workspace(const AcimgConvDesc* d);
+/* statistics rows acimg_conv2d_fwd_split3p writes for this shape under the current configuration (one per row tile of
+ * the kernel it picks; acimg_conv2d_fwd_split1p keeps acimg_conv2d_fwd_split3_stats_rows) */
+int acimg_conv2d_fwd_split3p_stats_rows(const AcimgConvDesc* d);
 int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
                              float* y, float* stats, void* ws, size_t ws_bytes, void* stream);
 /* The same launch with fp16 OPERAND STORAGE (BASELINE configs[4]: "fp16 with fp32 loss accumulation"): only the hi

@@ -972,6 +972,7 @@ def test_trunk_kernel_variants_agree(device, case):
     """The trunk forward conv in its forms — one tile per workgroup, persistent (a workgroup walks a tile list; the
     next tile's first operand stage is requested under the current tile's last K step, output stores drain under the
     next tile's MFMAs: counted vmcnt), each with and without the tail split, persistent with 128-byte operand rows —
+    and the ring kernel (software-pipelined K loop, 256- and 128-row tiles, tail split) —
     against fp64 and against each other: the BK = 32 forms give the same bits (same K ranges, same MFMA order, partials
     added in range order whoever arrives last); tickets back at zero; statistics equal to rounding."""
     from acimg import _lib, ops
@@ -989,7 +990,6 @@ def test_trunk_kernel_variants_agree(device, case):
     ops.bn_relu_split(plan, x.to(device), one, zero, 1, planes, lo_off, rows, Cc)
     wsplit = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=device)
     ops.conv2d_split3_prepare(plan, d, w.to(device), wsplit)
-    srows = ops.conv2d_fwd_split3_stats_rows(d)
     tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=device)
     outs = {}
     try:
@@ -999,8 +999,15 @@ def test_trunk_kernel_variants_agree(device, case):
                           ("persistent", dict(trunk_persistent=2)),
                           ("staggered", dict(trunk_persistent=2, trunk_stagger=50)),
                           ("spread", dict(trunk_persistent=2, trunk_dma_pos=1)),
-                          ("bk64", dict(trunk_persistent=2, trunk_bk=64)), ("auto", dict())):
+                          ("bk64", dict(trunk_persistent=2, trunk_bk=64)), ("auto", dict()),
+                          ("ring256 whole", dict(trunk_ring=2, trunk_ring_bm=256, tail_split=0)),
+                          ("ring128 whole", dict(trunk_ring=2, trunk_ring_bm=128, tail_split=0)),
+                          ("ring256", dict(trunk_ring=2, trunk_ring_bm=256)),
+                          ("ring128", dict(trunk_ring=2, trunk_ring_bm=128)),
+                          ("ring256 s3", dict(trunk_ring=2, trunk_ring_bm=256, tail_s=3)),
+                          ("ring", dict(trunk_ring=2))):
             _lib.configure(**cfg)
+            srows = ops.conv2d_fwd_split3p_stats_rows(d)     # depends on the kernel the configuration picks
             y = torch.full((N, d.OH, d.OW, K), float("nan"), device=device)
             st = torch.full((srows, 2, K), float("nan"), device=device)
             for _ in range(2):                        # twice: tickets and stage state must be reusable
@@ -1017,8 +1024,11 @@ def test_trunk_kernel_variants_agree(device, case):
         flat = ref.reshape(-1, K)
         close(st[:, 0].sum(0), flat.sum(0), tol=2e-4, what="stats sum " + name)
         close(st[:, 1].sum(0), (flat * flat).sum(0), tol=2e-4, what="stats sumsq " + name)
-    # whole tiles: the same K order in both kernels -> the same bits
+    # whole tiles: the same K order in every kernel -> the same bits (the ring kernel keeps the per-accumulator order
+    # lo*hi, hi*lo, hi*hi of a K step)
     assert torch.equal(outs["persistent whole"][0], outs["one-tile whole"][0])
+    for name in ("ring256 whole", "ring128 whole"):
+        assert torch.equal(outs[name][0], outs["one-tile whole"][0]), name
     # the same plan, different timing -> the same bits (partials are added in range order, whoever arrives last)
     for name in ("persistent", "staggered", "spread", "auto"):
         assert torch.equal(outs[name][0], outs["one-tile"][0]), name

@@ -68,13 +68,13 @@ def main():
         w = (torch.randn(R, R, C, K, generator=g) * 0.05).to(dev)
         wsplit = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=dev)
         ops.conv2d_split3_prepare(plan, d, w, wsplit)
-        nrow = ops.conv2d_fwd_split3_stats_rows(d)
+        nrow = -(-rows // 64)       # enough statistics rows for every variant's row tile
         tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=dev)
         outs, times = [], {n: [] for n, _, _ in variants}
         for name, cfg, path in variants:
             use(cfg, path)
             y = torch.full((N, d.OH, d.OW, K), float("nan"), device=dev)
-            st = torch.zeros(nrow * 2 * K, device=dev)
+            st = torch.zeros(nrow * 2 * K, device=dev)      # rows a variant does not write stay zero
             for _ in range(2):
                 ops.conv2d_fwd_split3p(plan, d, planes, lo, wsplit, y, st, tail_ws=tws)
             torch.cuda.synchronize()
@@ -95,7 +95,8 @@ def main():
         assert int(tws[:4096].view(torch.int32).abs().max()) == 0, "tickets not back at zero"
         y0, s0 = outs[0]
         err = max(float((y - y0).abs().max() / y0.abs().max()) for y, _ in outs[1:]) if len(outs) > 1 else 0.0
-        serr = max(float((s_ - s0).abs().max() / s0.abs().max()) for _, s_ in outs[1:]) if len(outs) > 1 else 0.0
+        tot_s = [s_.view(nrow, 2, K).sum(0) for _, s_ in outs]       # row tiles differ between kernels: column totals
+        serr = max(float((s_ - tot_s[0]).abs().max() / tot_s[0].abs().max()) for s_ in tot_s[1:]) if len(outs) > 1 else 0.0
         assert not torch.isnan(y0).any()
         fl = 2.0 * N * d.OH * d.OW * K * R * R * C
         byt = 4.0 * (N * H * W * C + K * R * R * C + N * d.OH * d.OW * K)
