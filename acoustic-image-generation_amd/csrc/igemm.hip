@@ -1838,6 +1838,10 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
                                 : (const void*)igemm_split3d_kernel<128, 64, 2, 2, 256, 2, 2>;
     if ((long)p.M * d->ldy * 4 >= (1L << 31)) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: output >= 2 GiB");
     if (const int rr = ring_rows(d, terms)) {
+#if defined(ACIMG_STAMP) || defined(ACIMG_ABLATE)
+        p.slab = g_stamp_buf;
+        p.flip = g_stamp_nostore;
+#endif
         // one workgroup per CU walks units blockIdx.x, blockIdx.x + P, ... (whole tiles, then K ranges of the tail tiles)
         p.ras_tiles_m = cdiv(p.M, rr);
         p.ras_gm = std::max(1, 32 / p.ras_gn);       // 32 resident tiles per XCD
@@ -1858,6 +1862,7 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
         p.ts_partial = ws ? reinterpret_cast<float*>(static_cast<char*>(ws) + TS_COUNTER_BYTES) : nullptr;
         const int units = tr.whole + tr.rem * tr.s;
         const int nwg = std::min(units, Pr);
+        p.splits = g_cfg.trunk_stagger > 0 ? 2 : 1;   // ring kernel: waves 4-7 do a step's scalar work before their first MFMA group
         if (rr == 256) hipLaunchKernelGGL((igemm_split3r_kernel<4>), dim3(nwg), dim3(512), lds_r, st, p, units, nwg);
         else hipLaunchKernelGGL((igemm_split3r_kernel<2>), dim3(nwg), dim3(512), lds_r, st, p, units, nwg);
         return check_launch("conv2d_fwd_split3p (ring)");

@@ -37,6 +37,16 @@ struct TileAddrR {
     unsigned b_goff;                       // this lane's row of the wave's B piece, byte offset at k = 0 (or OOB)
 };
 
+// s_waitcnt through the builtin, so that the compiler's own counter bookkeeping sees it (an `asm volatile` wait is opaque:
+// behind it the compiler still protects every fragment register loaded one loop iteration earlier with a conservative
+// lgkmcnt wait in front of its first use - which, in a pipelined loop, waits for the reads issued just before)
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70);
+}
+
 template <int TM>
 __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams p, const int n_units,
                                                                const int stride_units) {
@@ -58,7 +68,7 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
     float* const red = smem + 3 * SLOT / 4;          // [WGM][2][BN] statistics partials; red[0] doubles as the tail flag
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
+    const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id: a scalar (LDS-DMA destinations)
     const int wm = wid / WGN, wn = wid % WGN;
     const int li = lane & 15, g4 = lane >> 4;
     const int prow = lane >> 2, pch = lane & 3;      // this lane's row / physical chunk inside a DMA piece
@@ -99,8 +109,10 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
     Tile lt;
     KCursorP lkc{0, 0, 0, 0};
     int l_unit = blockIdx.x, l_k = 0, l_ke = 0, l_slot = 0, n_issued = 0;
-    unsigned st_aoff[RA] = {}, st_boff = 0;          // the stage being requested: per-lane source offsets
-    int st_base = 0;                                 // ... and its slot's LDS byte offset
+    // the (up to) two stages a step requests: set 0 = the regular one (spread over the step), set 1 = the one a unit's
+    // last step deferred (requested first): per-lane source offsets and the slot's LDS byte offset
+    unsigned st_aoff[2][RA] = {}, st_boff[2] = {0, 0};
+    int st_base[2] = {0, 0};
 
     auto setup = [&](int vt) __attribute__((always_inline)) {
         int mt_, nt_;
@@ -126,57 +138,84 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
         const int n = nt_ * BN + wid * 16 + prow;
         lt.b_goff = n < p.Nld ? (unsigned)(((long)n * Ktot + kc_sw * 8) * 2) : OOB;
     };
-    // stages the loader can still issue, capped at 2 (a unit has at least 2 steps)
-    auto loader_avail = [&]() __attribute__((always_inline)) -> int {
-        const int left = l_ke - l_k;
-        if (left >= 2) return 2;
-        return left + (l_unit + stride_units < n_units ? 2 : 0) >= 2 ? 2 : left;
+    // the loader moves to a unit: `first` = this workgroup's first one, else the next of its list (the caller checked
+    // that there is one); the tile's addresses are integer divisions: once per unit, between two groups of MFMAs
+    auto advance_unit = [&](const bool first) __attribute__((always_inline)) {
+        if (!first) l_unit += stride_units;
+        int vt, chunk;
+        unit_range(l_unit, vt, l_k, l_ke, chunk);
+        setup(vt);
+        lkc = kcursor_at<BK>(l_k, p.C, p.S);
     };
-    auto begin_stage = [&]() __attribute__((always_inline)) {
-        if (l_k == l_ke) {                           // next unit of this workgroup's list
-            if (l_ke != 0) l_unit += stride_units;
-            int vt, chunk;
-            unit_range(l_unit, vt, l_k, l_ke, chunk);
-            setup(vt);
-            lkc = kcursor_at<BK>(l_k, p.C, p.S);
-        }
+    // the loader has a stage to request (its current unit is set up and not exhausted)
+    auto loader_more = [&]() __attribute__((always_inline)) -> bool { return l_k < l_ke; };
+    auto loader_wants_unit = [&]() __attribute__((always_inline)) -> bool {
+        return l_k == l_ke && l_unit + stride_units < n_units;
+    };
+    // describe the next stage in descriptor set `ds` and move the cursor on (needs loader_more())
+    auto begin_stage = [&](const int ds) __attribute__((always_inline)) {
         const int tapoff = ((lkc.r * p.W + lkc.s) * p.lda + lkc.c0) * 2;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int ih = lt.a_ih0[j] + lkc.r, iw = lt.a_iw0[j] + lkc.s;
             const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            st_aoff[j] = ok ? (unsigned)(lt.a_off[j] + tapoff) : OOB;
+            st_aoff[ds][j] = ok ? (unsigned)(lt.a_off[j] + tapoff) : OOB;
         }
-        st_boff = lt.b_goff == OOB ? OOB : lt.b_goff + (unsigned)(lkc.q * (BK * 2));
-        st_base = l_slot * SLOT;
+        st_boff[ds] = lt.b_goff == OOB ? OOB : lt.b_goff + (unsigned)(lkc.q * (BK * 2));
+        st_base[ds] = l_slot * SLOT;
         lkc = kcursor_next<BK>(lkc, p.C, p.S);
         ++l_k;
         l_slot = l_slot == 2 ? 0 : l_slot + 1;
         ++n_issued;
     };
-    // request r of the stage begun last: r = 0, 1: the B piece (hi, lo); then the A pieces (hi, lo each); r, like every
-    // index parameter below, is a literal at each call site and folds after inlining
-    auto issue_req = [&](const int r) __attribute__((always_inline)) {
+    // The same work in pieces, for the steady-state step (descriptor set 0): a piece runs behind the group of MFMAs named
+    // by its argument, right before the request that needs its result, so that these few instructions sit BETWEEN
+    // matrix instructions (a wave's serial chain of scalar / vector instructions is what a K step of this kernel waits
+    // for: ~125 of them in one block cost more than the 48 MFMAs)
+    int fs_tapoff = 0;
+    auto begin_stage_part = [&](const int G) __attribute__((always_inline)) {
+        if (G == 0) {                       // B offset, slot (requests 0, 1)
+            fs_tapoff = ((lkc.r * p.W + lkc.s) * p.lda + lkc.c0) * 2;
+            st_boff[0] = lt.b_goff == OOB ? OOB : lt.b_goff + (unsigned)(lkc.q * (BK * 2));
+            st_base[0] = l_slot * SLOT;
+            l_slot = l_slot == 2 ? 0 : l_slot + 1;
+        }
+        const int GA = NG == 12 ? 3 : 1;    // A pieces: j behind group GA + 4 j (TM = 4) / GA (TM = 2)
+#pragma unroll
+        for (int j = 0; j < RA; ++j)
+            if (G == GA + 4 * j) {
+                const int ih = lt.a_ih0[j] + lkc.r, iw = lt.a_iw0[j] + lkc.s;
+                const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                st_aoff[0][j] = ok ? (unsigned)(lt.a_off[j] + fs_tapoff) : OOB;
+            }
+        if (G == NG - 3) {                  // the cursor moves on once every offset of this stage is formed
+            lkc = kcursor_next<BK>(lkc, p.C, p.S);
+            ++l_k;
+            ++n_issued;
+        }
+    };
+    // request r of the stage described in set `ds`: r = 0, 1: the B piece (hi, lo); then the A pieces (hi, lo each); ds
+    // and r, like every index parameter below, are literals at each call site and fold after inlining
+    auto issue_req = [&](const int ds, const int r) __attribute__((always_inline)) {
+#ifdef ACIMG_ABLATE
+        if (r < 2 ? (p.flip & 4) : (p.flip & 2)) return;     // ablation: no weight- / activation-tile requests
+#endif
         if (r < 2) {
-            char* dst = lds + st_base + 2 * A_PLANE + r * B_PLANE + wid * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)dst, 16, st_boff, r ? (int)b_lo_off : 0, 0, 0);
+            char* dst = lds + st_base[ds] + 2 * A_PLANE + r * B_PLANE + wid * 1024;
+            const unsigned bo = st_boff[ds];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)dst, 16, bo, r ? (int)b_lo_off : 0, 0, 0);
         } else {
             const int j = (r - 2) >> 1, pl = (r - 2) & 1;
-            char* dst = lds + st_base + pl * A_PLANE + (wid + j * NW) * 1024;
-            const unsigned ao = st_aoff[j];          // (a scalar copy: an array element as the builtin's offset operand
+            char* dst = lds + st_base[ds] + pl * A_PLANE + (wid + j * NW) * 1024;
+            const unsigned ao = st_aoff[ds][j];      // (a scalar copy: an array element as the builtin's offset operand
                                                      //  makes hipcc's host pass drop the kernel without a diagnostic)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, ao, pl ? (int)p.a_lo_off : 0, 0, 0);
         }
     };
-    auto issue_stage_now = [&]() __attribute__((always_inline)) {                   // prologue only: a whole stage in one go
-        begin_stage();
+    auto issue_stage_now = [&]() __attribute__((always_inline)) {                   // a whole stage in one go (prologue)
+        begin_stage(0);
 #pragma unroll
-        for (int r = 0; r < RPS; ++r) issue_req(r);
-    };
-    // request `idx` of the `n` stages a step issues (idx < n * RPS): the stage begins with its first request
-    auto issue_seq = [&](const int idx) __attribute__((always_inline)) {
-        if (idx % RPS == 0) begin_stage();
-        issue_req(idx % RPS);
+        for (int r = 0; r < RPS; ++r) issue_req(0, r);
     };
 
     // ---- multiplier state ----------------------------------------------------------------------------------------
@@ -195,6 +234,9 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
     // fragment reads of the NEXT step, by the sweep they are issued under: 0: ah', bh' into the other set (q in
     // [0, TM + TN)); 1: bl' in place (q in [0, TN)); 2: al' in place (q in [0, TM))
     auto read_frag = [&](const int s, const int kind, const int q, const char* slot) __attribute__((always_inline)) {
+#ifdef ACIMG_ABLATE
+        if (p.flip & 16) return;                             // ablation: no fragment reads
+#endif
         if (kind == 0) {
             if (q < TM) fah[s][q] = *reinterpret_cast<const h16x8*>(slot + fa_off + q * 1024);
             else fbh[s][q - TM] = *reinterpret_cast<const h16x8*>(slot + fb_off + (q - TM) * 1024);
@@ -205,6 +247,7 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
         }
     };
 
+    ACIMG_STAMP_DECL
     int c_unit = blockIdx.x, c_k = 0, c_ke = 0, c_vt = 0, c_chunk = -1, c_slot = 0, g = 0;
     int pend_mt = -1, pend_n0 = 0;                   // statistics partials waiting in `red` for their flush
     int* const flag = reinterpret_cast<int*>(red);
@@ -270,7 +313,11 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
         f32x4* const stg = reinterpret_cast<f32x4*>(lds + slot * SLOT + e_wid * 4096);
         const int rr = e_lane >> 4, cc = e_lane & 15;    // row-shaped view: row rr + 4 k, chunk cc
         const int nn = n0 + 4 * cc;
+#ifdef ACIMG_ABLATE
+        const bool n_ok = nn < e.Nstore && (p.flip & 1) == 0;   // ablation: no output stores
+#else
         const bool n_ok = nn < e.Nstore;
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -279,7 +326,8 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
             f32x4 v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = stg[(rr + 4 * k) * 16 + (cc ^ (rr + 4 * k))];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wait_lgkm0();
+            asm volatile("" ::: "memory");
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int m = m0 + i * 16 + rr + 4 * k;
@@ -339,26 +387,59 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
         return true;
     };
 
-    // ---- one K step: MFMAs of D(g) from set P, reads of D(g+1) into set 1 - P, requests in between ---------------
-    // returns false after the last step of this workgroup's stream
-    auto step = [&](const int P) __attribute__((always_inline)) -> bool {
+    // ---- one K step: MFMAs of D(g) from set P, reads of D(g+1), requests in between -------------------------------
+    // returns false after the last step of this workgroup's stream.  Hot path: one barrier, NG groups of TN MFMAs with
+    // one or two ds_read_b128 and at most one LDS-DMA request (a uniform branch) behind each, two counted waits.
+    // FAST (a literal, like P): the steady state - not a unit's last step, exactly one stage owed, the loader has one,
+    // no statistics waiting - with every decision below folded away: per-wave instruction issue is what a K step of a
+    // one-workgroup-per-CU kernel has least of (two waves per SIMD: ~190 scalar and ~140 vector issue slots per wave
+    // and step next to the 48 MFMAs), so the common step carries no control flow beyond the once-per-unit branch.
+    auto step = [&](const int P, const bool FAST) __attribute__((always_inline)) -> bool {
+        ACIMG_STAMP_AT(7);                           // everything not itemised (loop control, statistics flush, copies)
         __builtin_amdgcn_s_barrier();                // D(g+1) landed for everyone; everyone's reads of D(g) are done
         asm volatile("" ::: "memory");
-        if (pend_mt >= 0) flush_stats();
-        const bool unit_end = c_k + 1 == c_ke;
-        const bool has_next = !(unit_end && c_unit + stride_units >= n_units);
-        // stages to issue now: up to D(g+3), or D(g+2) in a unit's last step (its slot stages the output tile)
-        int n_issue = (g + (unit_end ? 3 : 4)) - n_issued;
-        {
-            const int avail = loader_avail();
-            n_issue = n_issue < avail ? n_issue : avail;
-            n_issue = n_issue < 0 ? 0 : n_issue;
-        }
+        ACIMG_STAMP_AT(1);                           // step barrier
+        if (!FAST && pend_mt >= 0) flush_stats();
+        const bool unit_end = FAST ? false : c_k + 1 == c_ke;
+        const bool has_next = FAST ? true : !(unit_end && c_unit + stride_units >= n_units);
+        // stages to request now: up to D(g+3), or D(g+2) in a unit's last step (its slot stages the output tile); the
+        // step behind a unit's last one therefore owes two: the deferred one goes first (`burst`, set 1).  Decided behind
+        // the first group of MFMAs: the matrix pipe is busy while the scalar unit works this out.
+#ifdef ACIMG_ABLATE
+        const bool lo_terms = !(p.flip & 8);         // ablation: only the hi x hi sweep
+#else
+        constexpr bool lo_terms = true;
+#endif
+        // The two waves of a SIMD (w and w + 4) run the same program from the same barrier: left alone they alternate
+        // their MFMAs and then both sit in the non-matrix instructions behind a group at the same time, the matrix pipe
+        // idle.  Waves 4-7 therefore do the step's scalar work BEFORE their first group, waves 0-3 behind it: half a
+        // group of offset that the in-order issue then keeps (one wave's reads and requests under the other's MFMAs).
+        const bool late_half = !FAST && p.splits > 1 && wid >= NW / 2;     // (acimg_configure trunk_stagger > 0)
+        bool burst = false, iss = FAST;
+        auto decide = [&]() __attribute__((always_inline)) {
+            if (FAST) return;                        // (the steady state: begin_stage_part, spread over the groups)
+            const int want = (g + (unit_end ? 3 : 4)) - n_issued;
+            if (want >= 2 && loader_more()) {
+                begin_stage(1);
+                burst = true;
+                if (loader_wants_unit()) advance_unit(false);    // rare: the deferred stage was its unit's last
+            }
+            if (want - (burst ? 1 : 0) >= 1 && loader_more()) {
+                begin_stage(0);
+                iss = true;
+            }
+        };
         const int nslot = c_slot == 2 ? 0 : c_slot + 1;
         const char* const rd = lds + nslot * SLOT;
+        // request slots: without a burst the regular stage is spread over the whole step; with one, the deferred stage
+        // takes the first half of the step (it has less than a step to land) and the regular one the second
 #define ACIMG_R_GROUP(G)                                                                                              \
         {                                                                                                             \
             constexpr int T_ = (G) / TM, i_ = (G) % TM;                                                               \
+            if constexpr ((G) == 0) {                                                                                 \
+                if (late_half) decide();                                                                              \
+            }                                                                                                         \
+            if (T_ == 2 || lo_terms)                                                                                  \
             _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                          \
                 if constexpr (T_ == 0)                                                                                \
                     acc[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbl[j], fah[P][i_], acc[i_][j], 0, 0, 0);     \
@@ -368,27 +449,45 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
                     acc[i_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fbh[P][j], fah[P][i_], acc[i_][j], 0, 0, 0);  \
             }                                                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                        \
-            if (has_next) {                                                                                           \
-                if constexpr (T_ == 0) {                                                                              \
-                    constexpr int n_ = (TM + TN) / TM;                                                                \
-                    read_frag(1 - P, 0, i_ * n_, rd);                                         \
-                    read_frag(1 - P, 0, i_ * n_ + 1, rd);                                     \
-                    if constexpr (n_ == 3) read_frag(1 - P, 0, i_ * n_ + 2, rd);              \
-                } else if constexpr (T_ == 1) {                                                                       \
-                    constexpr int n_ = TN / TM;                                                                       \
-                    read_frag(0, 1, i_ * n_, rd);                                             \
-                    if constexpr (n_ == 2) read_frag(0, 1, i_ * n_ + 1, rd);                  \
-                } else {                                                                                              \
-                    read_frag(0, 2, i_, rd);                                                  \
+            if constexpr ((G) == 0) {                                                                                 \
+                if (!late_half) decide();                                                                             \
+            }                                                                                                         \
+            /* the next step's fragments (read unconditionally: behind the stream's last step they are never used) */ \
+            if constexpr (T_ == 0) {                                                                                  \
+                constexpr int n_ = (TM + TN) / TM;                                                                    \
+                read_frag(1 - P, 0, i_ * n_, rd);                                                                     \
+                read_frag(1 - P, 0, i_ * n_ + 1, rd);                                                                 \
+                if constexpr (n_ == 3) read_frag(1 - P, 0, i_ * n_ + 2, rd);                                          \
+            } else if constexpr (T_ == 1) {                                                                           \
+                constexpr int n_ = TN / TM;                                                                           \
+                read_frag(0, 1, i_ * n_, rd);                                                                         \
+                if constexpr (n_ == 2) read_frag(0, 1, i_ * n_ + 1, rd);                                              \
+            } else if constexpr (i_ < (TM + 1) / 2) {                                                                 \
+                /* al' in place, all of it behind the first half of the last sweep: the reads' latency is covered   */ \
+                /* by the groups that follow, not exposed in front of the step's closing wait                       */ \
+                read_frag(0, 2, 2 * i_, rd);                                                                          \
+                if constexpr (2 * i_ + 1 < TM) read_frag(0, 2, 2 * i_ + 1, rd);                                       \
+            }                                                                                                         \
+            if (FAST) begin_stage_part(G);                                                                            \
+            if constexpr (NG == 12) {                                                                                 \
+                if (burst) {                                                                                          \
+                    if constexpr ((G) < 6) issue_req(1, (G));                                                         \
+                    else if (iss) issue_req(0, (G) - 6);                                                              \
+                } else if (iss) {                                                                                     \
+                    if constexpr ((G) % 2 == 0) issue_req(0, (G) / 2);                                                \
+                }                                                                                                     \
+            } else {                                                                                                  \
+                if (burst) {                                                                                          \
+                    if constexpr ((G) < 2) {                                                                          \
+                        issue_req(1, 2 * (G));                                                                        \
+                        issue_req(1, 2 * (G) + 1);                                                                    \
+                    } else if (iss) issue_req(0, (G) - 2);                                                            \
+                } else if (iss) {                                                                                     \
+                    if constexpr ((G) < 4) issue_req(0, (G));                                                         \
                 }                                                                                                     \
             }                                                                                                         \
-            if (n_issue == 2) {                                                                                       \
-                constexpr int lo_ = (G) * 2 * RPS / NG, hi_ = ((G) + 1) * 2 * RPS / NG;                               \
-                if constexpr (hi_ > lo_) issue_seq(lo_);                                                      \
-                if constexpr (hi_ > lo_ + 1) issue_seq(lo_ + 1);                                              \
-            } else if (n_issue == 1) {                                                                                \
-                constexpr int lo_ = (G) * RPS / NG, hi_ = ((G) + 1) * RPS / NG;                                       \
-                if constexpr (hi_ > lo_) issue_seq(lo_);                                                      \
+            if constexpr ((G) == NG - 2) {                                                                            \
+                if (!FAST && loader_wants_unit()) advance_unit(false);  /* once per unit: the next tile's addresses */ \
             }                                                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                        \
         }
@@ -397,11 +496,13 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
             ACIMG_R_GROUP(6) ACIMG_R_GROUP(7) ACIMG_R_GROUP(8) ACIMG_R_GROUP(9) ACIMG_R_GROUP(10) ACIMG_R_GROUP(11)
         }
 #undef ACIMG_R_GROUP
-        // D(g+2) must have landed before the next barrier: everything but the youngest stage, if one was issued
+        // D(g+2) must have landed before the next barrier: everything but the youngest stage, if one was requested
         // beyond it in this step
-        if (n_issued == g + 4) wait_vmcnt<RPS>();
-        else wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ACIMG_STAMP_AT(4);                           // MFMA / read / request issue (+ the reads' completion: the stamp waits)
+        if (FAST || n_issued == g + 4) wait_vm<RPS>();
+        else wait_vm<0>();
+        wait_lgkm0();
+        ACIMG_STAMP_AT(0);                           // own DMA pieces of D(g+2) landed
         ++g;
         ++c_k;
         const int slot_now = c_slot;                 // the slot D(g) left: free until the next barrier
@@ -409,9 +510,11 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
         if (unit_end) {
             bool whole = true;                       // this workgroup holds the finished tile
             if (c_chunk >= 0) whole = handoff(c_vt, c_chunk);
+            ACIMG_STAMP_AT(5);                       // hand-off of a K range (tail units)
             if (whole) epilogue(c_vt, slot_now);
             zero_acc();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wait_lgkm0();
+            ACIMG_STAMP_AT(6);                       // epilogue
             if (!has_next) return false;
             c_unit += stride_units;
             unit_range(c_unit, c_vt, c_k, c_ke, c_chunk);
@@ -424,34 +527,54 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
     unit_range(c_unit, c_vt, c_k, c_ke, c_chunk);
     {
         // D(0), D(1) exist (a unit has at least two steps); D(2) if the stream has a third step
+        advance_unit(true);
         issue_stage_now();
         issue_stage_now();
-        const bool third = loader_avail() >= 1;
+        if (loader_wants_unit()) advance_unit(false);
+        const bool third = loader_more();
         if (third) issue_stage_now();
-        if (third) wait_vmcnt<2 * RPS>();
-        else wait_vmcnt<RPS>();
+        if (loader_wants_unit()) advance_unit(false);
+        if (third) wait_vm<2 * RPS>();
+        else wait_vm<RPS>();
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         const char* const rd0 = lds;
-        read_frag(0, 0, 0, rd0); read_frag(0, 0, 1, rd0);
-        read_frag(0, 0, 2, rd0); read_frag(0, 0, 3, rd0);
-        read_frag(0, 0, 4, rd0); read_frag(0, 0, 5, rd0);
-        if constexpr (TM == 4) {
-            read_frag(0, 0, 6, rd0); read_frag(0, 0, 7, rd0);
-        }
-        read_frag(0, 1, 0, rd0); read_frag(0, 1, 1, rd0);
-        read_frag(0, 1, 2, rd0); read_frag(0, 1, 3, rd0);
-        read_frag(0, 2, 0, rd0); read_frag(0, 2, 1, rd0);
-        if constexpr (TM == 4) {
-            read_frag(0, 2, 2, rd0); read_frag(0, 2, 3, rd0);
-        }
-        if (third) wait_vmcnt<RPS>();
-        else wait_vmcnt<0>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < TM + TN; ++q) read_frag(0, 0, q, rd0);
+#pragma unroll
+        for (int q = 0; q < TN; ++q) read_frag(0, 1, q, rd0);
+#pragma unroll
+        for (int q = 0; q < TM; ++q) read_frag(0, 2, q, rd0);
+        if (third) wait_vm<RPS>();
+        else wait_vm<0>();
+        wait_lgkm0();
     }
-    for (;;) {      // (one shared copy of the unit-end code keeps BOTH hi-plane sets live at the merge: measured worse)
-        if (!step(0)) break;
-        if (!step(1)) break;
+    // Steady steps run in PAIRS (register sets 0 -> 1 -> 0), every other step alone from set 0 with the next step's hi
+    // planes copied back from set 1 behind it (32 v_mov): the loop then has ONE register-set parity, and no merge point
+    // keeps both sets alive (two parities x two step forms, merged, spilled > 200 registers).
+    auto steady_pair = [&]() __attribute__((always_inline)) -> bool {
+        return c_k + 2 < c_ke && n_issued == g + 3 && pend_mt < 0 && l_ke - l_k >= 2;   // the loader stays inside its unit
+    };
+    for (;;) {
+        while (steady_pair()) {                      // the tight loop: nothing but steady steps
+            step(0, true);
+            step(1, true);
+        }
+        if (!step(0, false)) break;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fah[0][i] = fah[1][i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fbh[0][j] = fbh[1][j];
     }
+#ifdef ACIMG_STAMP
+    if (p.slab && lane == 0) {
+        unsigned* dbg = reinterpret_cast<unsigned*>(p.slab) + ((long)blockIdx.x * NW + wid) * 16;
+#pragma unroll
+        for (int i = 0; i < 14; ++i) dbg[i] = st_acc[i];
+        dbg[14] = (unsigned)(__builtin_amdgcn_s_memtime() - st_begin);
+        dbg[15] = (unsigned)g;
+    }
+#endif
     // the last tile's statistics partials
     __builtin_amdgcn_s_barrier();
     if (pend_mt >= 0) flush_stats();

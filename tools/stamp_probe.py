@@ -1,7 +1,10 @@
 """Where the persistent trunk kernel's waves spend their cycles (diagnostic library with in-kernel s_memtime stamps:
 tools/build_stamp.sh -> tools/debug/libacimg_stamp.so).  Per shape and K-step depth: shader cycles per wave, split
 into: waiting for the own DMA pieces | step barrier | DMA issue | fragment reads (incl. their latency) | MFMA block
-issue | end-of-tile barrier | epilogue | other.     python tools/stamp_probe.py"""
+issue | end-of-tile barrier | epilogue | other.     python tools/stamp_probe.py
+    python tools/stamp_probe.py ring[=128|256] [H,W,C,K,R,s ...]   the ring kernel (round 3): wait dma = end-of-step vmcnt wait,
+    barrier = step barrier, mfma issue = the whole issue block of a step incl. the completion of its fragment reads,
+    tile barrier = K-range hand-off, epi rest = epilogue"""
 import ctypes as C
 import os
 import sys
@@ -22,15 +25,17 @@ NAMES = ["wait dma", "barrier", "dma issue", "frag reads", "mfma issue", "tile b
 
 
 def main():
+    ring = [a for a in sys.argv[1:] if a.startswith("ring")]
+    shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:] if a.count(",") == 5] or SHAPES
     dev = torch.device("cuda:0")
     L = _lib.load()
     L.acimg_debug_stamp_buffer.restype = C.c_int
     L.acimg_debug_stamp_buffer.argtypes = [C.c_void_p]
-    N = 32
+    N = int(os.environ.get("TRUNK_BATCH", "32"))
     g = torch.Generator(device="cpu").manual_seed(1)
     dbg = torch.zeros(512 * 8 * 16, dtype=torch.int32, device=dev)
     L.acimg_debug_stamp_buffer(dbg.data_ptr())
-    for (H, W, Cc, K, R, s) in SHAPES:
+    for (H, W, Cc, K, R, s) in shapes:
         d = ops.conv_desc(N, H, W, Cc, K, R, R, s, "SAME")
         rows = N * H * W
         lo = -(-rows * Cc * 2 // 256) * 256
@@ -42,11 +47,16 @@ def main():
         wsplit = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=dev)
         ops.conv2d_split3_prepare(plan, d, w, wsplit)
         y = torch.empty(N, d.OH, d.OW, K, device=dev)
-        st = torch.zeros(ops.conv2d_fwd_split3_stats_rows(d) * 2 * K, device=dev)
+        st = torch.zeros(-(-rows // 64) * 2 * K, device=dev)
         tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=dev)
-        for bk, nostore in ((32, 0), (32, 1)):
+        extra = [(32, int(b)) for b in os.environ.get("STAMP_BITS", "").split(",") if b]
+        for bk, nostore in [(32, 0), (32, 1)] + extra:
             L.acimg_debug_no_output_stores(nostore)
-            _lib.configure(trunk_persistent=2, trunk_bk=bk, tail_split=0)
+            if ring:
+                rbm = int(ring[0].split("=")[1]) if "=" in ring[0] else 256
+                _lib.configure(trunk_ring=2, trunk_ring_bm=rbm, tail_split=0)
+            else:
+                _lib.configure(trunk_persistent=2, trunk_bk=bk, tail_split=0)
             for _ in range(3):
                 ops.conv2d_fwd_split3p(plan, d, planes, lo, wsplit, y, st, tail_ws=tws)
             torch.cuda.synchronize()
@@ -60,15 +70,17 @@ def main():
             v = v[v[:, 14] > 0]
             tot = v[:, 14].mean()
             ksteps = R * R * Cc // bk
-            tiles = -(-rows // 128) * -(-K // 128)
+            tiles = -(-rows // (rbm if ring else 128)) * -(-K // 128)
             nwg = v.shape[0] // 8
             per_wave_steps = ksteps * tiles / nwg
             print("%s%dx%d %d->%d %dx%d  BK=%d  %d workgroups, %.1f tiles each, %d K steps/tile: kernel %.1f us, %.0f cycles/wave "
-                  "(%.2f GHz), %.0f cycles per K step" % ("[output stores dropped] " if nostore else "", H, W, Cc, K, R, R, bk, nwg, tiles / nwg, ksteps,
+                  "(%.2f GHz), %.0f cycles per K step" % (("[ablation bits %d] " % nostore) if nostore else "", H, W, Cc, K, R, R, bk, nwg, tiles / nwg, ksteps,
                                                            e0.elapsed_time(e1) * 1e3, tot,
                                                            tot / (e0.elapsed_time(e1) * 1e-3) / 1e9 * 1e-0 / 1e0 / 1e0 * 1e0 / 1e0 if False else tot / (e0.elapsed_time(e1) * 1e3) / 1e3,
                                                            tot / per_wave_steps))
             mf = (24 if bk == 32 else 48) * 16
+            if ring:
+                mf = (48 if rbm == 256 else 24) * 16
             print("    " + "  ".join("%s %4.1f%%" % (n, 100.0 * v[:, i].mean() / tot) for i, n in enumerate(NAMES)) +
                   "   | MFMA pipe floor per step (2 or 4 waves/SIMD share it): %d cycles per wave" % mf)
     _lib.configure()
