@@ -126,6 +126,7 @@ PROTOTYPES = {
     "acimg_randn": (_I, [_P, _L, C.c_uint64, C.c_uint64, _P]),
     "acimg_sqerr_channels": (_I, [_P, _P, _L, _I, _P, _P]),
     "acimg_zero": (_I, [_P, _SZ, _P]),
+    "acimg_spin": (_I, [C.c_uint64, _P, _P]),
     "acimg_sumsq": (_I, [_P, _L, _P, _P, _SZ, _P]),
     "acimg_axpy": (_I, [_F, _P, _P, _L, _P]),
     "acimg_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P]),
@@ -201,7 +202,8 @@ def configure_from_env(env=None):
         if env.get(var):
             kw[field] = int(env[var])
     for var, field in (("ACIMG_NO_SPLITK_HANDOFF", "splitk_handoff"), ("ACIMG_NO_WGRAD_HALO", "wgrad_halo"),
-                       ("ACIMG_NO_TAIL_SPLIT", "tail_split"), ("ACIMG_NO_PERSISTENT", "trunk_persistent")):
+                       ("ACIMG_NO_TAIL_SPLIT", "tail_split"), ("ACIMG_NO_PERSISTENT", "trunk_persistent"),
+                       ("ACIMG_NO_RING", "trunk_ring")):
         if env.get(var):
             kw[field] = 0
     if env.get("ACIMG_SPLIT3_TILE"):

@@ -59,6 +59,19 @@ def average_moving_statistics(flat_state, moving_ranges, group=None):
     return flat_state
 
 
+def allreduce_sums(values, device=None, group=None):
+    """sum over ranks of a few host numbers (validation loss sum, data-set size): every rank gets the same totals, so a
+    decision taken on them (best epoch -> a checkpoint, which contains a collective) is the same on every rank.  The
+    reduction is done in float64; single process: returned as given."""
+    vals = [float(v) for v in values]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return vals
+    cuda = dist.get_backend(group) == "nccl"
+    t = torch.tensor(vals, dtype=torch.float64, device=device if cuda else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.tolist()
+
+
 def shards_per_rank(global_batch, shard, world):
     """Strong scaling: a FIXED global batch is cut into shards of `shard` images (the batch-norm group size: every
     shard is normalised with its own batch statistics, on whichever rank it runs); each rank takes
@@ -75,13 +88,11 @@ def shards_per_rank(global_batch, shard, world):
 class GradComm(object):
     """Bucketed, stream-overlapped all-reduce of a flat gradient buffer."""
 
-    def __init__(self, flat_grad, buckets, group=None):
+    def __init__(self, flat_grad, buckets, group=None, force=False):
+        """force: keep the exchange on at world size 1 (rehearses the RCCL path on a one-GPU box)"""
         self.flat = flat_grad
         self.buckets = [(int(a), int(b)) for a, b, *_ in buckets]
         self.group = group
-        # ACIMG_DP_FORCE=1 keeps the exchange on at world size 1 (rehearses the RCCL path on a one-GPU box)
-        import os
-        force = os.environ.get("ACIMG_DP_FORCE") == "1"
         self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force)
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.cuda = flat_grad.is_cuda

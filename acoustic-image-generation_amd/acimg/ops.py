@@ -53,6 +53,16 @@ class Workspace(object):
         self.buf = None
         self.version = 0
         self._tickets = None
+        self._side = None
+
+    @property
+    def side(self):
+        """the workspace of the calls this workspace's plans put on their SIDE lane (a second stream): a child of its
+        own, so that two sessions / trainers in one process - whose plans run on different main streams at the same
+        time - never share a split-K slab through a per-device singleton"""
+        if self._side is None:
+            self._side = Workspace(self.device)
+        return self._side
 
     @property
     def tickets(self):
@@ -160,36 +170,35 @@ def current_stream_handle(device=None):
     return torch.cuda.current_stream(device).cuda_stream
 
 
-_SIDE = {}        # (device, main stream) -> side stream;  device -> workspace of the side-lane calls
+_SIDE = {}        # (device, main stream) -> side stream
 
 
 def side_lane(device):
-    """The SIDE LANE of the current stream of a device: a second HIP stream (one per main stream, so that two plans
-    running on two streams do not couple through it) and the device's side workspace.  Plans put the weight gradient
-    of a layer there (`Plan.add(..., side=True)` between `Plan.fork()` and `Plan.join()`), so that it runs beside the
-    data gradient of the same layer on the main stream: the two read the same gradient, write disjoint buffers and
-    each leaves part of the chip idle (slab tails, split-K hand-offs, 48-tile layers)."""
-    dkey = str(device)
-    if dkey not in _SIDE:
-        _SIDE[dkey] = Workspace(device)
-    skey = (dkey, torch.cuda.current_stream(device).cuda_stream)
+    """The SIDE LANE of the current stream of a device: a second HIP stream, one per main stream, so that two plans
+    running on two streams do not couple through it (their side WORKSPACE belongs to the plan's own workspace:
+    `Workspace.side`).  Plans put the weight gradient of a layer there (`Plan.add(..., side=True)` between
+    `Plan.fork()` and `Plan.join()`), so that it runs beside the data gradient of the same layer on the main stream:
+    the two read the same gradient, write disjoint buffers and each leaves part of the chip idle (slab tails, split-K
+    hand-offs, 48-tile layers)."""
+    skey = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if skey not in _SIDE:
         _SIDE[skey] = torch.cuda.Stream(device=device)
-    return _SIDE[skey], _SIDE[dkey]
+    return _SIDE[skey]
 
 
 def _runs_beside(a, b, work):
-    """True if a small kernel on stream b completes while stream a is still busy with `work` (two streams that share a
-    hardware queue serialise: the runtime maps streams onto a few queues in an order the program cannot see)"""
+    """True if a small kernel on stream b completes while stream a is still busy (two streams that share a hardware queue
+    serialise: the runtime maps streams onto a few queues in an order the program cannot see).  The load on `a` is the
+    library's own timed spin (`acimg_spin`: one wave reading the shader clock for ~2 ms), the probe on `b` a 32-byte
+    `acimg_zero`: no vendor kernel runs inside the product package."""
     ea, eb = torch.cuda.Event(), torch.cuda.Event()
-    flag = torch.zeros(8, device=work.device)
+    L = _L()
     torch.cuda.synchronize(work.device)
     with torch.cuda.stream(a):
-        for _ in range(6):
-            work = torch.mm(work, work).clamp_(-1.0, 1.0)
+        _lib.check(L.acimg_spin(4000000, work.data_ptr(), a.cuda_stream), "spin")      # ~2 ms at ~2 GHz
         ea.record(a)
     with torch.cuda.stream(b):
-        flag.add_(1.0)
+        _lib.check(L.acimg_zero(work.data_ptr() + 64, 32, b.cuda_stream), "zero")
         eb.record(b)
     while not eb.query() and not ea.query():
         pass
@@ -201,7 +210,7 @@ def _runs_beside(a, b, work):
 def concurrent_streams(device, base, want, pool=8):
     """up to `want` new streams that really run beside `base` and beside each other (measured, a few ms each); fewer if
     the runtime has fewer free hardware queues — the caller then shares lanes, which costs time, never correctness"""
-    work = torch.rand(2048, 2048, device=device) * 0.01
+    work = torch.zeros(64, device=device)
     chosen, cands = [base], [torch.cuda.Stream(device=device) for _ in range(pool)]
     for c in cands:
         if len(chosen) > want:
@@ -213,7 +222,6 @@ def concurrent_streams(device, base, want, pool=8):
 
 def set_side_lane(device, main_stream, side_stream):
     """use `side_stream` as the side lane of plans run on `main_stream` (side_stream = main_stream: no second lane)"""
-    side_lane(device)      # creates the device's side workspace
     _SIDE[(str(device), main_stream.cuda_stream)] = side_stream
 
 
@@ -233,7 +241,7 @@ class Plan(object):
     @property
     def side_ws(self):
         """workspace of the calls added with side=True (the main workspace when the plan is eager / not on a GPU)"""
-        return self.ws if (self.eager or not self._cuda) else side_lane(self.device)[1]
+        return self.ws if (self.eager or not self._cuda) else self.ws.side
 
     def add_hook(self, pyfn, name="hook"):
         """a host callback run in order between kernel launches (e.g. fire a gradient all-reduce)"""
@@ -262,7 +270,7 @@ class Plan(object):
 
         def _fork():
             ev.record(torch.cuda.current_stream(dev))
-            side_lane(dev)[0].wait_event(ev)
+            side_lane(dev).wait_event(ev)
         self.add_hook(_fork, "fork")
 
     def make_join(self):
@@ -273,7 +281,7 @@ class Plan(object):
         ev, dev = torch.cuda.Event(), self.device
 
         def _join():
-            ev.record(side_lane(dev)[0])
+            ev.record(side_lane(dev))
             torch.cuda.current_stream(dev).wait_event(ev)
         return _join
 
@@ -318,7 +326,7 @@ class Plan(object):
         return self
 
     def _side_handle(self):
-        return side_lane(self.device)[0].cuda_stream if self.side else None
+        return side_lane(self.device).cuda_stream if self.side else None
 
     def run(self, stream=None):
         if self._resolved is None or self._ws_version != self._versions():
@@ -348,7 +356,7 @@ class Plan(object):
                 continue
             on_side = i in side
             if i + offset in indices:
-                lane = side_lane(self.device)[0] if on_side else ts
+                lane = side_lane(self.device) if on_side else ts
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(lane)

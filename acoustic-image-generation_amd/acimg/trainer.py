@@ -152,9 +152,12 @@ class Trainer(object):
             return self.graphs[N]
         # a different batch size (last partial batch): same variables, new buffers + plans
         mi = type(self.modelimages)(input_shape=[224, 298, 3], num_classes=None, precision=self.modelimages.precision,
-                                    stages=getattr(self.modelimages, "stages", 1))
+                                    stages=getattr(self.modelimages, "stages", 1),
+                                    stage_cut=getattr(self.modelimages, "STAGE_CUT", 8),
+                                    side_lane=getattr(self.modelimages, "side_lane", True))
         ma = type(self.modelac)(input_shape=[36, 48, 12], embedding=self.modelac.embedding,
-                                num_skip=self.modelac.num_skip, precision=self.modelac.precision)
+                                num_skip=self.modelac.num_skip, precision=self.modelac.precision,
+                                side_lane=self.modelac.side_lane)
         mi._register = lambda store: None
         ma_heads = self.modelac.heads
 
@@ -169,14 +172,21 @@ class Trainer(object):
                 join()
             self.comm.bucket_ready(i)
 
-    def enable_data_parallel(self, group=None):
-        """All-reduce the flat gradient across ranks (torch.distributed must be initialised): five
-        contiguous buckets, each fired from its hook in the recorded backward plan."""
+    def enable_data_parallel(self, group=None, exchange="auto", force=False):
+        """All-reduce the flat gradient across ranks (torch.distributed must be initialised).  exchange:
+          "bucketed": five contiguous buckets, each fired from its hook in the recorded backward plan on an exchange stream
+                      (the all-reduce overlaps the rest of the backward pass: BASELINE.json's north_star form);
+          "whole":    ONE all-reduce of the whole flat gradient behind the backward pass;
+          "auto":     bucketed on the one-stream entries (train_step), whole on the pipelined entry, whose trained part
+                      already runs a pipeline tick behind the trunk stages (the slack budget).
+        force: exchange even at world size 1 (rehearsal of the RCCL path on a one-GPU box)."""
+        assert exchange in ("auto", "bucketed", "whole"), exchange
         store = self.session.store
         self.buckets = dp.make_buckets(store.train_ranges(), self.bucket_boundaries)
         assert len(self.buckets) == 5, self.buckets
-        self.comm = dp.GradComm(store.grad, self.buckets, group)
+        self.comm = dp.GradComm(store.grad, self.buckets, group, force=force)
         self.group = group
+        self.exchange = exchange
         return self.comm
 
     def sync_moving_statistics(self):
@@ -220,14 +230,22 @@ class Trainer(object):
             self._feed(g, batch, eps)
         else:
             self._noise(g, eps)
-        if probe is None:
-            g.plan_train.run()      # hooks inside fire the bucketed all-reduce when data-parallel
-        else:
-            g.plan_train.run_probed(probe[0], probe[1])
+        whole = self.comm is not None and getattr(self, "exchange", "auto") == "whole"
+        held, self.hold_exchange = self.hold_exchange, self.hold_exchange or whole
+        try:
+            if probe is None:
+                g.plan_train.run()      # hooks inside fire the bucketed all-reduce when data-parallel
+            else:
+                g.plan_train.run_probed(probe[0], probe[1])
+        finally:
+            self.hold_exchange = held
         store = self.session.store
         scale = 1.0
         if self.comm is not None and self.comm.enabled:
-            self.comm.wait()
+            if whole:
+                self.comm.allreduce_all()
+            else:
+                self.comm.wait()
             scale = self.comm.grad_scale
         self.global_step += 1
         lr_t = ops.adam_lr_t(self.learning_rate, self.global_step)
@@ -317,7 +335,8 @@ class Trainer(object):
             # buckets, no separate exchange stream): the trained part has a whole tick of slack behind the trunk stages,
             # so nothing needs to overlap inside it; every collective call costs host time, and every stream beyond the
             # runtime's 4 hardware queues shares a queue with one of the lanes (RCCL's own stream is the fourth)
-            held, self.hold_exchange = self.hold_exchange, True
+            bucketed = getattr(self, "exchange", "auto") == "bucketed" and item.get("accum") is None
+            held, self.hold_exchange = self.hold_exchange, self.hold_exchange or not bucketed
             try:
                 if probe is None:
                     pipe["b"].run()
@@ -327,8 +346,37 @@ class Trainer(object):
                 self.hold_exchange = held
             store = self.session.store
             scale = 1.0
-            if self.comm is not None and self.comm.enabled:
-                self.comm.allreduce_all()
+            acc = item.get("accum")
+            if acc is not None:
+                # shard i of n of a strong-scaling step (train_step_sharded): gradients and losses are accumulated on this
+                # stream; the exchange and the ONE Adam update follow the last shard
+                i, n = acc
+                L = _lib.load()
+                sth = ops.current_stream_handle(self.session.device)
+                if i == 0:
+                    self._acc.copy_(store.grad)
+                    self._acc_loss = g.losses[:5].clone()
+                else:
+                    _lib.check(L.acimg_axpy(1.0, store.grad.data_ptr(), self._acc.data_ptr(), store.grad.numel(), sth),
+                               "axpy")
+                    self._acc_loss = self._acc_loss + g.losses[:5]
+                if i + 1 < n:
+                    pipe["ev"]["b"].record(pipe["sb"])
+                    pipe["recorded"].add("b")
+                    return
+                store.grad.copy_(self._acc)
+                world = 1
+                if self.comm is not None and self.comm.enabled:
+                    self.comm.allreduce_all()
+                    world = self.comm.world
+                scale = 1.0 / (n * world)
+                if item.get("tag") is not None:
+                    pipe["finished"].append((item["tag"], self._acc_loss / n))
+            elif self.comm is not None and self.comm.enabled:
+                if bucketed:
+                    self.comm.wait()
+                else:
+                    self.comm.allreduce_all()
                 scale = self.comm.grad_scale
             self.global_step += 1
             lr_t = ops.adam_lr_t(self.learning_rate, self.global_step)
@@ -337,7 +385,7 @@ class Trainer(object):
                                              store.train_numel(), lr_t, 0.9, 0.999, 1e-8, scale,
                                              ops.current_stream_handle(self.session.device))
             _lib.check(rc, "adam_step")
-            if item.get("tag") is not None:
+            if acc is None and item.get("tag") is not None:
                 # a private copy of this batch's losses (the graph's buffer is rewritten by the next batch)
                 pipe["finished"].append((item["tag"], g.losses[:5].clone()))
             pipe["ev"]["b"].record(pipe["sb"])
@@ -404,8 +452,17 @@ class Trainer(object):
             carried, self._pipe = self._pipe["finished"], None
         pipe = self._pipeline(g)
         pipe["finished"] = carried + pipe["finished"]
-        item = dict(video=None if batch is None else batch[2], targets=None if batch is None else (batch[0], batch[1]),
-                    eps=eps, tag=tag)
+        # the targets are consumed two calls later, on the trained part's stream: they are staged NOW (a device copy per
+        # batch in flight), so a loader may reuse its host buffers as soon as this call returns; the images are copied
+        # in this call (trunk stage 1 runs in it)
+        targets = None
+        if batch is not None:
+            dev = self.session.device
+            targets = (torch.as_tensor(batch[0]).to(dev, torch.float32, copy=True),
+                       torch.as_tensor(batch[1]).to(dev, torch.float32, copy=True))
+            if eps is not None:
+                eps = torch.as_tensor(eps).to(dev, torch.float32, copy=True)
+        item = dict(video=None if batch is None else batch[2], targets=targets, eps=eps, tag=tag)
         res = self._advance(pipe, item, probe)
         return res if res is not None else out
 
@@ -431,12 +488,34 @@ class Trainer(object):
         cur.wait_stream(pipe["sb"])
         return out
 
-    def train_step_sharded(self, shards, eps=None, probe=None):
+    def train_step_sharded(self, shards, eps=None, probe=None, pipelined=False, tag=None):
         """Strong-scaling step: `shards` = this rank's micro-batches (each of the primary graph's size: the BN group),
         run one after the other with their gradients accumulated; ONE exchange of the accumulated gradient, ONE Adam
-        update with scale 1 / (shards * world).  With one shard per rank this is `train_step` (overlapped buckets)."""
+        update with scale 1 / (shards * world).  With one shard per rank this is `train_step` (overlapped buckets).
+        pipelined: the shards go through the lanes of `train_step_pipelined` - inside a step every shard sees the same
+        weights and the frozen trunk reads none of them, so the trunk of shard i + 1 (and of the next step's first
+        shards) runs beside the trained part of shard i; gradients and losses are accumulated on the trained part's
+        stream in shard order: bit-identical to the one-stream form.  Returns None then (`flush_pipeline()` finishes the
+        shards in flight; `pop_finished()` returns the mean losses of the steps submitted with a `tag`)."""
+        if pipelined:
+            g = self.primary
+            if self._pipe is not None and self._pipe["g"] is not g:
+                self.flush_pipeline()
+                self._pipe = None
+            pipe = self._pipeline(g)
+            if self._acc is None:
+                self._acc = torch.zeros_like(self.session.store.grad)
+            dev = self.session.device
+            for i, b in enumerate(shards):
+                e = None if eps is None else torch.as_tensor(eps[i]).to(dev, torch.float32, copy=True)
+                item = dict(video=b[2], targets=(torch.as_tensor(b[0]).to(dev, torch.float32, copy=True),
+                                                 torch.as_tensor(b[1]).to(dev, torch.float32, copy=True)),
+                            eps=e, tag=tag, accum=(i, len(shards)))
+                self._advance(pipe, item, probe)
+            return None
         if len(shards) == 1:
             return self.train_step(shards[0], eps=None if eps is None else eps[0], sync=probe is None, probe=probe)
+        self.flush_pipeline()          # a batch in flight reads the input buffers this call is about to overwrite
         store = self.session.store
         g = self.primary
         if self._acc is None:
@@ -608,6 +687,11 @@ class Trainer(object):
                 self.flush_pipeline()
                 for i, r in self.pop_finished():
                     report(i, r)
+            if self.comm is not None and self.comm.enabled:
+                # data parallel: validate with ONE set of BN moving statistics (their mean over ranks, a collective every
+                # rank enters here, unconditionally); _evaluate reduces its sums over ranks, so `total_loss` - and with
+                # it every branch below that contains a collective (_save_checkpoint) - is the same on all ranks
+                self.sync_moving_statistics()
             total_loss = self._evaluate(session, 'validation', valid_data)
             self.log('{}: {} - Epoch: {}\t Validation_mse_Loss: {:6f}'.format(datetime.now(), FLAGS.exp_name, epoch,
                                                                               total_loss))
@@ -639,6 +723,9 @@ class Trainer(object):
             n = labels.shape[0]
             data_set_size += n
             loss_sum += r["mse"] * n
+        if self.comm is not None and self.comm.enabled:     # every rank validates its own shard of `data`
+            loss_sum, data_set_size = dp.allreduce_sums([loss_sum, data_set_size], self.session.device,
+                                                        getattr(self, "group", None))
         return loss_sum / data_set_size
 
     def test(self, test_data=None):

@@ -51,14 +51,14 @@ class Act(object):
 
 class UNetAc(object):
 
-    def __init__(self, input_shape=None, num_frames=12, embedding=False, num_skip=1, precision="split"):
+    def __init__(self, input_shape=None, num_frames=12, embedding=False, num_skip=1, precision="split", side_lane=True):
         """precision: "split" = the large convs on the split-MFMA kernels (fp32-class results), "f32" = every
         conv on the exact-f32 MFMA kernel"""
         assert precision in ("split", "f32")
         self.precision = precision
         self.split_min_rows = 16384      # below this the f32 kernel (64x64 tiles + split-K) fills the chip better
         # backward: weight gradients on the plan's side lane (a second HIP stream), beside the data gradients
-        self.side_lane = os.environ.get("ACIMG_NO_SIDE_LANE") is None
+        self.side_lane = bool(side_lane)
         self._wsplit_bufs = {}
         self.scope = 'UNetAcRes'
         self.num_frames = num_frames

@@ -32,7 +32,7 @@ BN_EPS = 1e-5
 
 class ResNet50Model(object):
 
-    def __init__(self, input_shape=None, num_classes=None, precision="f16x3", stages=None):
+    def __init__(self, input_shape=None, num_classes=None, precision="f16x3", stages=None, stage_cut=8, side_lane=True):
         """precision: arithmetic of the frozen trunk convs — "f16x3" (split-fp16 MFMA, fp32-class
         results, default), "f32" (exact-f32 MFMA) or "f16" (fp16 OPERAND STORAGE: the same data path, but the 52 trunk
         convs fetch and multiply only the hi fp16 plane of activations and weights — one MFMA per product, fp32
@@ -51,15 +51,16 @@ class ResNet50Model(object):
         # then run on the plan's side lane beside conv1 .. conv3 (with two stages the stage streams take that role and
         # the 4 hardware queues are spent on the pipeline's lanes).
         if stages is None:
-            stages = int(os.environ.get("ACIMG_TRUNK_STAGES", "2")) if precision in ("f16x3", "f16") else 1
+            stages = 2 if precision in ("f16x3", "f16") else 1
         assert stages in (1, 2)
         if precision not in ("f16x3", "f16"):
             stages = 1
         self.stages = stages
         # units in stage 1: 8 = blocks 1 + 2 + the first unit of block 3 (measured: 5: 7.53, 6: 7.30, 7: 7.18, 8: 7.06,
         # 9: 7.19 ms/step; the two trunk stages and the trained part should take about the same time)
-        self.STAGE_CUT = int(os.environ.get("ACIMG_STAGE_CUT", "8"))
-        self.side_lane = os.environ.get("ACIMG_NO_SIDE_LANE") is None and stages == 1
+        # (constructor arguments, not environment variables: stages, stage_cut, side_lane)
+        self.STAGE_CUT = int(stage_cut)
+        self.side_lane = bool(side_lane) and stages == 1
         self.num_classes = num_classes
         self.height = input_shape[0]
         self.width = input_shape[1]

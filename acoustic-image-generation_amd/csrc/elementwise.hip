@@ -1336,6 +1336,27 @@ int acimg_loss_finalize(const float* sums, const float* kl, int N, double count,
     return check_launch("loss_finalize");
 }
 
+}  // extern "C"
+namespace acimg {
+__global__ void spin_kernel(unsigned long long cycles, unsigned* out) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long t = t0;
+    while (t - t0 < cycles) {          // every wave reaches the exit: the clock only moves forward
+        __builtin_amdgcn_s_sleep(32);
+        t = __builtin_amdgcn_s_memtime();
+    }
+    if (threadIdx.x == 0 && out) out[0] = (unsigned)(t - t0);
+}
+}  // namespace acimg
+extern "C" {
+
+int acimg_spin(uint64_t cycles, void* out, void* stream) {
+    if (cycles > 0xFFFFFFFFull) return fail(ACIMG_EINVAL, "spin: at most 2^32 cycles");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)cycles,
+                       static_cast<unsigned*>(out));
+    return check_launch("spin");
+}
+
 int acimg_zero(void* ptr, size_t bytes, void* stream) {
     hipError_t e = hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream);
     if (e != hipSuccess) return fail(ACIMG_ELAUNCH, "zero: %s", hipGetErrorString(e));

@@ -639,7 +639,7 @@ static TileCfg pick_cfg(int M, int Ngemm) {
 
 // Tuning record (acimg_configure): plain ints, defaults compiled in, written only by acimg_configure and never by a
 // launch; the launch heuristics below read it instead of the process environment.
-static AcimgConfig g_cfg = {320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0};
+static AcimgConfig g_cfg = {320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0};
 
 static int pick_splits(int M, int Ngemm, TileCfg c, int kiters) {
     // measured on the generator's 12x16 layers (192-288 tiles of 64x64, 36+ K steps: tools/splitk_sweep.sh):
@@ -1189,7 +1189,7 @@ int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
 
 int acimg_config_default(AcimgConfig* c) {
     if (!c) return fail(ACIMG_EINVAL, "config_default: null");
-    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 0, 0};
+    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0};
     return ACIMG_OK;
 }
 
@@ -1511,13 +1511,22 @@ static bool split3p_persistent(const Split3Cfg& c, long tiles) {
 }
 
 // Ring kernel (igemm_split3r_kernel.hpp) for a pre-split trunk conv, and with how many tile rows: 0 = not on it.
-// 256-row tiles halve the operand and fragment bytes per MFMA but leave half as many tiles: taken where at least two
-// rounds of them exist on the 256 CUs (tools/trunk_shapes.py, profiles/r03/).
+// Measured per shape at batch 32 and 30 (tools/trunk_shapes.py, profiles/r03/trunk_shapes_r03*.txt): in its steady state
+// the ring kernel's K loop is 8-14 % faster than the two-workgroups-per-CU kernels' (long-K layers whose tiles fill one
+// round of the 256 CUs), but with ONE workgroup per CU it pays more for tile quantisation (a 1.04-round layer leaves
+// 246 CUs idle for a round, where 512 slots leave a quarter of the chip) and for short-K tiles (the output tile's stores
+// and the deferred stage at every unit boundary).  trunk_ring = 1 therefore takes it where it won: layers of at most
+// ~1.2 rounds of 128x128 tiles over the CUs (the 14x19 stage) with at least 64 K steps, on 128-row tiles with the tail
+// cut into K ranges; trunk_ring = 2 forces it (experiments, tests).
 static int ring_rows(const AcimgConvDesc* d, int terms) {
     if (!g_cfg.trunk_ring || terms != 3) return 0;
     const int M = d->N * d->OH * d->OW;
+    if ((long)M * d->ldy * 4 >= (1L << 31)) return 0;      // 32-bit output descriptor (see fwd_presplit)
     const Split3Cfg c = pick_split3(M, d->K);
     if (c.bm != 128 || c.bn != 128) return 0;
+    const long t128 = (long)cdiv(M, 128) * cdiv(d->K, 128);
+    const int kiters = d->R * d->S * (d->C / 32);
+    if (g_cfg.trunk_ring == 1) return (t128 > 256 && t128 <= 300 && kiters >= 64) ? 128 : 0;
     if (g_cfg.trunk_ring_bm) return g_cfg.trunk_ring_bm;
     const long t256 = (long)cdiv(M, 256) * cdiv(d->K, 128);
     return t256 >= 500 ? 256 : 128;
@@ -1536,6 +1545,10 @@ int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out) {
     out[0] = c.bm;
     out[1] = c.bn;
     out[2] = split3p_persistent(c, (long)cdiv(M, c.bm) * cdiv(d->K, c.bn)) ? 1 : 0;
+    if (const int rr = ring_rows(d, 3)) {      // the ring kernel: its row tile, flag 2
+        out[0] = rr;
+        out[2] = 2;
+    }
     return ACIMG_OK;
 }
 
@@ -1836,8 +1849,10 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
     const void* fn = which == 0 ? (const void*)igemm_split3d_kernel<128, 128, 2, 4, 512, 2, 2>
                    : which == 1 ? (const void*)igemm_split3d_kernel<64, 128, 1, 4, 256, 2, 2>
                                 : (const void*)igemm_split3d_kernel<128, 64, 2, 2, 256, 2, 2>;
-    if ((long)p.M * d->ldy * 4 >= (1L << 31)) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: output >= 2 GiB");
-    if (const int rr = ring_rows(d, terms)) {
+    // the persistent and the ring kernel address the output through a 32-bit buffer descriptor; a larger output (per-GPU
+    // batches around 512 on the first trunk units) falls back to the one-tile kernel's 64-bit pointer stores
+    const bool big_out = (long)p.M * d->ldy * 4 >= (1L << 31);
+    if (const int rr = big_out ? 0 : ring_rows(d, terms)) {
 #if defined(ACIMG_STAMP) || defined(ACIMG_ABLATE)
         p.slab = g_stamp_buf;
         p.flip = g_stamp_nostore;
@@ -1867,7 +1882,7 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
         else hipLaunchKernelGGL((igemm_split3r_kernel<2>), dim3(nwg), dim3(512), lds_r, st, p, units, nwg);
         return check_launch("conv2d_fwd_split3p (ring)");
     }
-    const bool persistent = split3p_persistent(c, T);
+    const bool persistent = !big_out && split3p_persistent(c, T);
     // K-step depth of the persistent kernel: 32 = the one-tile kernel's image (2 workgroups / CU); 64 = full 128-byte
     // operand lines per DMA request, 1 workgroup / CU (measured slower on every trunk shape: experiments only)
     const int bk = persistent && g_cfg.trunk_bk && terms == 3 ? g_cfg.trunk_bk : 32;

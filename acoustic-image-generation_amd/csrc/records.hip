@@ -107,12 +107,12 @@ inline bool map_entry(Span e, Span& key, Span& val) {
 
 inline bool key_is(Span k, const char* s) { return k.n == strlen(s) && memcmp(k.p, s, k.n) == 0; }
 
-// first int64 of a Feature (Int64List, packed or not); false when the feature holds none
-inline bool feature_int64(Span feat, int64_t& out) {
+// first int64 of a Feature (Int64List, packed or not); false when the feature holds none; `ok` goes false on a
+// malformed sub-message (the caller refuses the record)
+inline bool feature_int64(Span feat, int64_t& out, bool& ok) {
     const uint8_t* p = feat.p;
     const uint8_t* end = feat.p + feat.n;
     Field f;
-    bool ok = true;
     while (next_field(p, end, f, ok)) {
         if (f.num != 3 || f.wt != 2) continue;
         const uint8_t* q = f.sub.p;
@@ -247,7 +247,7 @@ int acimg_sequence_example_decode(const uint8_t* rec, size_t len, AcimgSequenceD
             if (!map_entry(e.sub, key, val)) { ok = false; break; }
             if (f.num == 1) {                                        // context: int64 scalars
                 int64_t v;
-                if (!feature_int64(val, v)) continue;
+                if (!feature_int64(val, v, ok)) continue;
                 if (key_is(key, "classes")) dims->classes = v;
                 else if (key_is(key, "location")) dims->location = v;
                 else if (key_is(key, "audio_image/height")) dims->audio_height = v;
@@ -266,6 +266,17 @@ int acimg_sequence_example_decode(const uint8_t* rec, size_t len, AcimgSequenceD
         }
     }
     if (!ok) return fail(ACIMG_EINVAL, "sequence_example_decode: malformed protobuf");
+    // The context dimensions come from the file: a dimension that is present must be a sane positive size BEFORE any
+    // product is formed (H = W = -1 would overflow into a plausible byte count; a direct C-ABI caller has no NumPy
+    // allocation failure to save it).  1 <= d <= 65536 keeps every product below 2^48 * 4.
+    {
+        const int64_t* dimv[8] = {&dims->audio_height, &dims->audio_width, &dims->audio_depth, &dims->mics, &dims->samples,
+                                  &dims->video_height, &dims->video_width, &dims->video_depth};
+        for (int i = 0; i < 8; ++i)
+            if (*dimv[i] != 0 && (*dimv[i] < 1 || *dimv[i] > (i == 4 ? (int64_t)1 << 24 : 65536)))   // samples: 2^24
+                return fail(ACIMG_EINVAL, "sequence_example_decode: context dimension %d = %lld is out of range", i,
+                            (long long)*dimv[i]);
+    }
     // steps of every list; bytes per step must match the context dimensions (tf.reshape would fail otherwise)
     int64_t* steps_out[3] = {&dims->audio_image_steps, &dims->audio_data_steps, &dims->video_steps};
     const int64_t step_bytes[3] = {dims->audio_height * dims->audio_width * dims->audio_depth * 4, 0,
@@ -286,7 +297,7 @@ int acimg_sequence_example_decode(const uint8_t* rec, size_t len, AcimgSequenceD
                                 raw.n, (long long)step_bytes[0]);
                 if (audio_images) {
                     const int64_t H = dims->audio_height, W = dims->audio_width, D = dims->audio_depth;
-                    if ((size_t)((step + 1) * H * W * D) > audio_images_cap)
+                    if (step >= (int64_t)1 << 24 || (size_t)((step + 1) * H * W * D) > audio_images_cap)
                         return fail(ACIMG_EWORKSPACE, "sequence_example_decode: audio_images buffer too small");
                     // tf.image.flip_left_right then flip_up_down (:314-315): out[h][w] = in[H-1-h][W-1-w]
                     float* dst = audio_images + step * H * W * D;
@@ -310,7 +321,7 @@ int acimg_sequence_example_decode(const uint8_t* rec, size_t len, AcimgSequenceD
                     return fail(ACIMG_EINVAL, "sequence_example_decode: video/image step of %zu bytes, context says %lld",
                                 raw.n, (long long)step_bytes[2]);
                 if (video) {
-                    if ((size_t)((step + 1) * step_bytes[2]) > video_cap)
+                    if (step >= (int64_t)1 << 24 || (size_t)((step + 1) * step_bytes[2]) > video_cap)
                         return fail(ACIMG_EWORKSPACE, "sequence_example_decode: video buffer too small");
                     memcpy(video + step * step_bytes[2], raw.p, raw.n);
                 }

@@ -71,11 +71,25 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="one stream, one batch at a time (Trainer.train_step) instead of the two-lane pipeline "
                          "(Trainer.train_step_pipelined: the frozen trunk of batch t + 1 beside the trained part of batch t)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "bucketed", "whole"],
+                    help="data-parallel gradient exchange: bucketed = five buckets fired from hooks inside the backward "
+                         "plan on an exchange stream (all-reduce overlapped with backward); whole = one all-reduce of the "
+                         "flat gradient behind the backward pass; auto = bucketed on the one-stream step, whole on the "
+                         "pipelined step (its trained part runs a pipeline tick behind the trunk stages)")
+    ap.add_argument("--dp-force", action="store_true",
+                    help="with RANK / WORLD_SIZE = 1 in the environment: initialise RCCL and run the exchange at world "
+                         "size 1 (rehearsal of the data-parallel path on a one-GPU box)")
+    ap.add_argument("--trunk-stages", type=int, default=0, choices=[0, 1, 2],
+                    help="pipeline stages of the frozen trunk (0 = the model's default: 2 for the split-MFMA trunk)")
+    ap.add_argument("--stage-cut", type=int, default=8, help="bottleneck units in trunk stage 1 (of 16)")
+    ap.add_argument("--no-side-lane", action="store_true",
+                    help="record the plans without the second HIP stream for weight gradients / projection shortcuts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the configs[1] (UNet RGB VAE) and configs[2] (2-skip, batch 64) side measurements")
     ap.add_argument("--cpu-batch", type=int, default=32, help="BASELINE.md §3: the CPU leg runs the GPU leg's batch")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU steps (BASELINE.md §3: >= 10) after --cpu-warmup")
+    ap.add_argument("--cpu-warmup", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every host core this process may run on")
     ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds of timed CPU work after which no further "
                                                                      "timed step starts")
@@ -103,10 +117,11 @@ def host_cores():
 
 def cpu_baseline(args):
     """CPU oracle train step: the SAME step as the GPU leg — same generator variant (--num-skip), same
-    batch (32) — on a BOUNDED sample: 1 warm-up step, then up to --cpu-steps (3) timed steps, stopping early once
-    --cpu-budget seconds (default 150) of timed work are spent (at least one timed step), so the default bench.py run
-    stays within a few minutes; BASELINE.md's 3 + 10 steps would not.  `cores` = the thread count actually set with
-    torch.set_num_threads (affinity mask capped by the cgroup CPU quota).  Progress goes to stderr."""
+    batch (32) — on a BOUNDED sample: --cpu-warmup (2) warm-up steps, then up to --cpu-steps (10) timed steps (about
+    6 s each on the GPU box's 16-core share: ~75 s), stopping early once --cpu-budget seconds (default 150) of timed
+    work are spent (at least one timed step), so the default bench.py run stays within a few minutes.  `cores` = the
+    thread count actually set with torch.set_num_threads (affinity mask capped by the cgroup CPU quota).  Progress
+    goes to stderr."""
     from oracle import trainer as otr
 
     n = args.cpu_threads if getattr(args, "cpu_threads", 0) else host_cores()
@@ -115,9 +130,12 @@ def cpu_baseline(args):
     budget = float(getattr(args, "cpu_budget", 150.0))
     orc = otr.Oracle(num_skip=args.num_skip, learning_rate=1e-4)
     ac, mf, vid, eps = otr.synthetic_batch(args.cpu_batch, seed=1234)
+    warm = int(getattr(args, "cpu_warmup", 1))
     t0 = time.perf_counter()
-    orc.train_step(ac, mf, vid, eps)
-    print("[cpu_baseline] warm-up step (batch %d, %d threads): %.1f s" % (args.cpu_batch, n, time.perf_counter() - t0),
+    for _ in range(warm):
+        orc.train_step(ac, mf, vid, eps)
+    print("[cpu_baseline] %d warm-up step(s) (batch %d, %d threads): %.1f s" % (warm, args.cpu_batch, n,
+                                                                               time.perf_counter() - t0),
           file=sys.stderr, flush=True)
     done = 0
     t0 = time.perf_counter()
@@ -130,8 +148,8 @@ def cpu_baseline(args):
     return {"value": rate, "unit": "images/s", "cores": n, "kind": "port",
             "gflops": rate * 41.7,
             "sample": "CPU oracle (PyTorch fp32 restatement of the TF-1 graph; TF-1 unavailable offline): the same "
-                      "TrainerMask train step, %d-skip generator, batch %d, %d timed steps (%.0f s) after 1 warm-up, "
-                      "%d threads" % (args.num_skip, args.cpu_batch, done, dt, n)}
+                      "TrainerMask train step, %d-skip generator, batch %d, %d timed steps (%.0f s) after %d warm-up, "
+                      "%d threads" % (args.num_skip, args.cpu_batch, done, dt, warm, n)}
 
 
 def load_traffic_profile(kernel_name):
@@ -192,6 +210,44 @@ def secondary_unet_rgb(args):
                           "dtype": "f32 (f16x3 / bf16x3 split MFMA)"}}
 
 
+TILE_THREADS = {(128, 128): "2,4,512", (64, 128): "1,4,256", (128, 64): "2,2,256"}
+
+
+def dominant_trunk_kernel(g, f16):
+    """the trunk forward-conv kernel instance (tile shape / kernel form) that carries the most FLOPs of a recorded step:
+    (indices of its launches in g.plan_train, {index: algorithmic FLOP}, {index: algorithmic bytes}, kernel name)"""
+    from acimg import ops
+    cand = {}
+    for i, (name, fn, a) in enumerate(g.plan_train.calls):
+        if name == "conv2d_fwd_split3p" and f16:      # the trunk's pre-split LDS-DMA kernels
+            d = a[0]._obj
+            key = ops.conv2d_fwd_split3_tiling(d)
+        elif name == "conv2d_fwd" and not f16:
+            d = a[0]._obj
+            key = ops.conv2d_fwd_tiling(d)
+            if key[2] != 1:
+                continue
+        else:
+            continue
+        cand.setdefault(key, []).append((i, 2.0 * d.N * d.OH * d.OW * d.K * d.R * d.S * (3 if d.R == 7 else d.C)))
+    tile = max(cand, key=lambda k: sum(f for _, f in cand[k]))
+    probe_idx = set(i for i, _ in cand[tile])
+    flops = dict(cand[tile])
+    alg_bytes = {}
+    for i in probe_idx:
+        d = g.plan_train.calls[i][2][0]._obj
+        alg_bytes[i] = 4.0 * (d.N * d.H * d.W * d.C + d.K * d.R * d.S * d.C + d.N * d.OH * d.OW * d.K)
+    if not f16:
+        kernel_name = "igemm_f32_kernel<%d,%d,...,false,true>" % (tile[0], tile[1])
+    elif len(tile) > 2 and tile[2] == 2:
+        kernel_name = "igemm_split3r_kernel<%d>" % (tile[0] // 64)    # the ring kernel (TM = rows / 64)
+    elif len(tile) > 2 and tile[2]:
+        kernel_name = "igemm_split3dp_kernel<32, 0, 3>"    # the persistent form of the 128x128 trunk kernel
+    else:
+        kernel_name = "igemm_split3d_kernel<%d,%d,%s,2,2,3>" % (tile[0], tile[1], TILE_THREADS[tile[:2]])
+    return probe_idx, flops, alg_bytes, kernel_name
+
+
 def secondary_configs2(args):
     """BASELINE configs[2]: the TrainerMask step with the 2-skip generator at batch 64 on one GPU"""
     from acimg.flags import FLAGS
@@ -221,9 +277,26 @@ def secondary_configs2(args):
     dt = (time.perf_counter() - t0) / 10
     tr.flush_pipeline()
     torch.cuda.synchronize()
+    # roofline of this configuration's dominant kernel: HIP events around its launches in 3 one-stream steps (the kernel
+    # with the chip to itself, as for the headline's `roofline`)
+    f16 = args.precision == "f16x3"
+    probe_idx, flops, alg_bytes, kernel_name = dominant_trunk_kernel(g, f16)
+    ev = []
+    for _ in range(3):
+        tr.train_step(sync=False, probe=(probe_idx, ev))
+    torch.cuda.synchronize()
+    ms = sum(e0.elapsed_time(e1) for _, e0, e1 in ev)
+    fl = sum(flops[i] for i, _, _ in ev)
+    peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+    ach = fl / (ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": kernel_name, "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "hw_flop_factor": 3 if f16 else 1, "hw_frac": ach * (3 if f16 else 1) / peak,
+            "alg_bytes": sum(alg_bytes.values()) / len(alg_bytes), "traffic": None,
+            "launches_per_step": len(probe_idx), "avg_launch_ms": ms / len(ev),
+            "measured": "HIP events around every launch of the kernel in 3 one-stream steps after the timed region"}
     return {"workload": "BASELINE configs[2]: TrainerMask train step, ResNet-50-mod + UNetAcRes 2-skip "
                         "(models/unet_acresnet2skip.py), batch 64", "value": B / dt, "unit": "images/s",
-            "ms_per_step": dt * 1e3, "dtype": "f32", "final_loss": tr._scalars(g)["loss"]}
+            "ms_per_step": dt * 1e3, "dtype": "f32", "final_loss": tr._scalars(g)["loss"], "roofline": roof}
 
 
 def synthetic_inputs(B, seed):
@@ -349,12 +422,13 @@ def main():
                              % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    force_dp = os.environ.get("ACIMG_DP_FORCE") == "1" and "RANK" in os.environ   # one-rank RCCL rehearsal
+    force_dp = args.dp_force and "RANK" in os.environ   # one-rank RCCL rehearsal
+    side_lane = not args.no_side_lane
     if (world > 1 or force_dp) and not args.no_pipeline:
         # streams of a data-parallel pipelined step: trunk stage 1, trunk stage 2, trained part, RCCL's = 4 = the runtime's
         # hardware queues; the trained part's side lane (neutral inside the pipeline: 7.28 ms with or without it) would
         # be a fifth one sharing a queue with another
-        os.environ["ACIMG_NO_SIDE_LANE"] = "1"
+        side_lane = False
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -369,14 +443,15 @@ def main():
     FLAGS.model, FLAGS.ae, FLAGS.num_skip_conn = "UNet", 0, args.num_skip
     B = args.batch
     sess = Session(dev)
-    tr = Trainer(UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=args.num_skip),
-                 ResNet50Model(input_shape=[224, 298, 3], num_classes=None, precision=args.precision),
+    tr = Trainer(UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=args.num_skip, side_lane=side_lane),
+                 ResNet50Model(input_shape=[224, 298, 3], num_classes=None, precision=args.precision,
+                               stages=args.trunk_stages or None, stage_cut=args.stage_cut, side_lane=side_lane),
                  learning_rate=1e-4, session=sess)
     g = tr._build_functions(batch_size=B)
     tr.modelimages.initialize(seed=1238)
     tr.modelac.initialize(seed=1239)
     if world > 1 or force_dp:
-        tr.enable_data_parallel()
+        tr.enable_data_parallel(exchange=args.exchange, force=force_dp)
     # synthetic inputs, resident in HBM before the timed region (seed differs per rank)
     fill_inputs(g, B, 1234 + rank)
     strong = args.scaling == "strong"
@@ -390,39 +465,15 @@ def main():
 
     # the dominant kernel = the trunk forward-conv kernel instance (tile shape) that carries the most FLOPs
     f16 = args.precision == "f16x3"
-    cand = {}
-    for i, (name, fn, a) in enumerate(g.plan_train.calls):
-        if name == "conv2d_fwd_split3p" and f16:      # the trunk's pre-split LDS-DMA kernel (igemm_split3d_kernel)
-            d = a[0]._obj
-            key = ops.conv2d_fwd_split3_tiling(d)
-        elif name == "conv2d_fwd" and not f16:
-            d = a[0]._obj
-            key = ops.conv2d_fwd_tiling(d)
-            if key[2] != 1:
-                continue
-        else:
-            continue
-        cand.setdefault(key, []).append((i, 2.0 * d.N * d.OH * d.OW * d.K * d.R * d.S * (3 if d.R == 7 else d.C)))
-    tile = max(cand, key=lambda k: sum(f for _, f in cand[k]))
-    probe_idx = set(i for i, _ in cand[tile])
+    probe_idx, flops, alg_bytes, kernel_name = dominant_trunk_kernel(g, f16)
     shared = g.plan_train.shared_calls()
-    flops = dict(cand[tile])
-    alg_bytes = {}
-    for i in probe_idx:
-        d = g.plan_train.calls[i][2][0]._obj
-        alg_bytes[i] = 4.0 * (d.N * d.H * d.W * d.C + d.K * d.R * d.S * d.C + d.N * d.OH * d.OW * d.K)
-    TILE_THREADS = {(128, 128): "2,4,512", (64, 128): "1,4,256", (128, 64): "2,2,256"}
-    if not f16:
-        kernel_name = "igemm_f32_kernel<%d,%d,...,false,true>" % (tile[0], tile[1])
-    elif len(tile) > 2 and tile[2]:
-        kernel_name = "igemm_split3dp_kernel<32, 0, 3>"    # the persistent form of the 128x128 trunk kernel
-    else:
-        kernel_name = "igemm_split3d_kernel<%d,%d,%s,2,2,3>" % (tile[0], tile[1], TILE_THREADS[tile[:2]])
-    pipelined = not strong and not args.no_pipeline and f16
+    pipelined = not args.no_pipeline and f16
 
     def one_step(probe=None):
         if strong:
-            tr.train_step_sharded(shards, probe=probe)
+            # the shards of a step go through the same lanes (Trainer.train_step_sharded(pipelined=True)): K calls = K x
+            # shards trunks + K x shards trained parts + K exchanges + K Adam updates
+            tr.train_step_sharded(shards, probe=probe, pipelined=pipelined)
         elif pipelined:
             # steady state: this call runs the frozen trunk of one batch (lane A) and conv_map + generator + backward +
             # Adam of the previous one (lane B): K calls = K trunks + K optimisation steps, nothing skipped
@@ -529,6 +580,10 @@ def main():
                        "per_gpu_batch": images_per_step // world, "global_batch": images_per_step,
                        "bn_group": B, "shards_per_gpu_per_step": len(shards) if strong else 1,
                        "parallelism": "dp%d" % world, "launches_per_step": len(g.plan_train) + 2,
+                       "exchange": (None if not (world > 1 or force_dp) else
+                                    "whole flat gradient, one all-reduce behind the backward pass"
+                                    if (args.exchange == "whole" or strong or (args.exchange == "auto" and pipelined)) else
+                                    "5 buckets fired from hooks in the backward plan on an exchange stream (overlapped)"),
                        "lanes": ("%d HIP streams measured to run side by side: trunk units 1-8 of batch n | trunk units 9-16 "
                                  "of batch n-1 | conv_map + generator + backward + exchange + Adam of batch n-2; every batch's "
                                  "arithmetic is the one-stream step's" % tr._pipe["lanes"]) if pipelined else "1"},

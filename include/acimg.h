@@ -139,7 +139,7 @@ int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* ws
 int acimg_conv2d_split3_prepare_multi(int n, const AcimgConvDesc* const* descs, const float* const* w, void* const* out,
                                       const int* mode, void* stream);
 int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d);
-/* out[3] = {BM, BN, 1 if acimg_conv2d_fwd_split3p runs this shape on the persistent kernel} */
+/* out[3] = {BM, BN, kernel of acimg_conv2d_fwd_split3p for this shape: 0 one tile per workgroup, 1 persistent, 2 ring} */
 int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out);
 int acimg_conv2d_fwd_split3(const AcimgConvDesc* d, const float* x, const void* wsplit, const float* bias,
                             float* y, const float* in_scale, const float* in_shift, int in_relu, float* stats,
@@ -440,6 +440,10 @@ int acimg_randn(float* out, long n, uint64_t seed, uint64_t offset, void* stream
 
 /* stream-ordered memset to zero (loss accumulators, gradient buffers) */
 int acimg_zero(void* ptr, size_t bytes, void* stream);
+/* A load for stream-concurrency probes: ONE wave keeps `stream` busy for `cycles` shader cycles (s_memtime; bounded by
+ * 2^32) and then writes the elapsed cycles to out[0] (4 bytes, device memory).  The host library uses it to find HIP
+ * streams that really run beside each other (the runtime maps streams onto a few hardware queues). */
+int acimg_spin(uint64_t cycles, void* out, void* stream);
 
 /* out[c] += sum over pixels of (a-b)^2 for channel c (dense [pixels][C], C<=64; caller zeroes out):
  * the per-3-channel test MSEs of trainer/mfcctrainer.py:105-117 are sums of 3 of these / count. */

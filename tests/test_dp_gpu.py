@@ -95,6 +95,50 @@ if rank == 0:
     # rank 0's own trajectory uses rank-0 BN statistics, as the reference run above does
     assert err <= 2e-4 * scale + 2e-6, (err, scale)
     print("dp parity ok: max |dw| %%.3e (max |w| %%.3e)" %% (err, scale))
+# strong-scaling step through the lanes: two shards per rank, accumulated, ONE exchange, ONE Adam: the pipelined form
+# equals the one-stream form bit for bit on both ranks
+sh = [otr.synthetic_batch(2, seed=500 + 10 * rank + i) for i in range(2)]
+tr_a, sess_a = make(); tr_a.enable_data_parallel()
+tr_b, sess_b = make(); tr_b.enable_data_parallel()
+tr_a.train_step_sharded([b[:3] for b in sh], eps=[b[3] for b in sh])
+tr_b.train_step_sharded([b[:3] for b in sh], eps=[b[3] for b in sh], pipelined=True)
+tr_b.flush_pipeline()
+torch.cuda.synchronize()
+assert tr_a.global_step == tr_b.global_step == 1
+assert torch.equal(sess_a.store.flat["train"], sess_b.store.flat["train"])
+del tr_a, tr_b, sess_a, sess_b, tr_p, sess_p
+# Trainer.train() under data parallelism (ADVICE r2): every rank trains and validates on its OWN shard of the data, so
+# the per-rank validation losses differ; the best-epoch decision (which leads into _save_checkpoint's collective) must
+# still be the same on both ranks: moving statistics are averaged before validation, the loss sums are reduced.
+from acimg.data import SyntheticDataLoader
+import tempfile, re
+FLAGS.checkpoint_dir = %(ckpt)r; FLAGS.exp_name = "dp"
+FLAGS.restore_checkpoint = FLAGS.init_checkpoint = FLAGS.acoustic_init_checkpoint = FLAGS.visual_init_checkpoint = None
+FLAGS.latent_loss = 1e-6
+sess_t = Session(dev)
+tr_t = Trainer(UNetAc(input_shape=[36, 48, 12]), ResNet50Model(input_shape=[224, 298, 3]), learning_rate=1e-3,
+               num_epochs=3, session=sess_t)
+tr_t._build_functions(batch_size=2)
+tr_t.enable_data_parallel()
+lines = []
+tr_t.log = lines.append
+best = tr_t.train(SyntheticDataLoader(4, 2, seed=40 + rank), SyntheticDataLoader(2, 2, seed=60 + rank))
+va = [float(re.search(r"Validation_mse_Loss: ([0-9.]+)", ln).group(1)) for ln in lines if "- Epoch:" in ln]
+allv = [None, None]
+dist.all_gather_object(allv, va)
+assert allv[0] == allv[1] and len(va) == 3, allv           # one validation number per epoch, the same on both ranks
+wt = sess_t.store.flat["train"].clone()
+gt = [torch.empty_like(wt) for _ in range(world)]
+dist.all_gather(gt, wt)
+assert torch.equal(gt[0], gt[1])
+bn = sess_t.store.flat["state"].clone()
+gb = [torch.empty_like(bn) for _ in range(world)]
+dist.all_gather(gb, bn)
+assert torch.equal(gb[0], gb[1]), "moving statistics after the last checkpoint's averaging"
+if rank == 0:
+    d = os.path.join(FLAGS.checkpoint_dir, "dp")
+    assert os.path.exists(os.path.join(d, "model.txt")) and os.path.exists(os.path.join(d, "epoch_random.ckpt.index"))
+    print("dp train() ok", va)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok", out["loss"])
 '''
@@ -102,10 +146,80 @@ print("rank", rank, "ok", out["loss"])
 
 def test_two_ranks_share_averaged_gradients(tmp_path):
     script = tmp_path / "dp_gpu_worker.py"
-    script.write_text(WORKER % {"root": ROOT, "port": 29600 + os.getpid() % 2000})
+    script.write_text(WORKER % {"root": ROOT, "port": 29600 + os.getpid() % 2000, "ckpt": str(tmp_path / "ckpt")})
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
-    assert "dp parity ok" in outs[0]
+    assert "dp parity ok" in outs[0] and "dp train() ok" in outs[0]
+
+
+RCCL_WORKER = r'''
+import os, sys
+ROOT = %(root)r
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "acoustic-image-generation_amd"))
+import torch, torch.distributed as dist
+# launched by torch.distributed.run in a FRESH process: nothing has touched the GPU before this point
+torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+dist.init_process_group("nccl", device_id=dev)          # "nccl" IS RCCL on ROCm
+assert dist.get_world_size() == 1
+from acimg.flags import FLAGS
+from acimg.session import Session
+from acimg.trainer import Trainer
+from acimg.unet_acresnet import UNetAc
+from acimg.vision import ResNet50Model
+from oracle import trainer as otr
+FLAGS.model, FLAGS.ae = "UNet", 0
+
+def make(side_lane=True):
+    sess = Session(dev)
+    tr = Trainer(UNetAc(input_shape=[36, 48, 12], side_lane=side_lane), ResNet50Model(input_shape=[224, 298, 3], side_lane=side_lane),
+                 learning_rate=1e-3, session=sess)
+    tr._build_functions(batch_size=2)
+    tr.modelimages.initialize(seed=11); tr.modelac.initialize(seed=12)
+    return tr, sess
+
+batches = [otr.synthetic_batch(2, seed=800 + i) for i in range(3)]
+plain, ps = make()
+for ac, mf, vid, eps in batches:
+    plain.train_step((ac, mf, vid), eps=eps)
+torch.cuda.synchronize()
+want = ps.store.flat["train"].clone()
+# the sum over ONE rank is the identity: every exchange form must leave the plain step's bits
+for name, exchange, pipelined in (("bucketed, one stream (--no-pipeline)", "bucketed", False), ("whole, one stream", "whole", False),
+                                  ("whole, pipelined (bench default)", "auto", True), ("bucketed, pipelined", "bucketed", True)):
+    tr, sess = make(side_lane=not pipelined)
+    comm = tr.enable_data_parallel(exchange=exchange, force=True)
+    assert comm.enabled and comm.world == 1
+    for ac, mf, vid, eps in batches:
+        if pipelined:
+            tr.train_step_pipelined((ac, mf, vid), eps=eps)
+        else:
+            tr.train_step((ac, mf, vid), eps=eps)
+    tr.flush_pipeline()
+    torch.cuda.synchronize()
+    assert tr.global_step == 3
+    assert torch.equal(sess.store.flat["train"], want), (name, float((sess.store.flat["train"] - want).abs().max()))
+    print("rccl world-1:", name, "== plain step")
+    del tr, sess
+dist.barrier(); dist.destroy_process_group()
+print("rccl ok")
+'''
+
+
+def test_rccl_exchange_at_world_size_one(tmp_path):
+    """The RCCL path itself (backend "nccl", the exchange stream, bucket hooks, `allreduce_all`) in a FRESH subprocess
+    launched under torch.distributed.run before anything touches the GPU: at world size 1 the all-reduce is the
+    identity, so the bucketed-overlapped and the whole-buffer form, on the one-stream and on the pipelined entry, must
+    all reproduce the plain step bit for bit."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER % {"root": ROOT})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90), str(script)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = p.stdout.decode()
+    assert p.returncode == 0, out[-3000:]
+    assert "rccl ok" in out and out.count("== plain step") == 4

@@ -193,6 +193,18 @@ state = torch.cat([torch.full((8,), 0.1), torch.full((8,), float(rank)), torch.f
 dp.average_moving_statistics(state, [(8, 8), (16, 8)])
 assert torch.equal(state[:8], torch.full((8,), 0.1)) and torch.equal(state[8:16], torch.full((8,), 0.5))
 assert torch.equal(state[16:], torch.full((8,), 15.0))
+# validation under data parallelism (Trainer.train): each rank's loss sum and sample count differ; the reduced totals -
+# and with them the best-epoch branch that leads into a collective - are the same on every rank
+tot = dp.allreduce_sums([1.5 + rank, 3 + rank])
+assert tot == [4.0, 7.0], tot
+best = 0.6
+took = (tot[0] / tot[1]) <= best
+flags = [None, None]
+dist.all_gather_object(flags, took)
+assert flags[0] == flags[1]
+# a forced exchange at world size > 1 is the plain exchange; the `force` argument (bench.py --dp-force) replaces the
+# environment variable the constructor used to read
+assert dp.GradComm(torch.zeros(n), buckets, force=True).enabled
 import tempfile
 marker = os.path.join(%(tmp)r, "writer_%%d" %% rank)
 if dp.is_writer():
@@ -295,8 +307,11 @@ def test_library_reads_no_environment_and_configure_validates(lib):
     cfg = _lib.Config()
     assert lib.acimg_config_default(C.byref(cfg)) == 0
     assert (cfg.splitk_cut, cfg.splitk_target, cfg.splitk_handoff, cfg.wgrad_minpix, cfg.wgrad_halo, cfg.split3_tile_bm,
-            cfg.split3_tile_bn, cfg.tail_split, cfg.tail_s, cfg.trunk_persistent, cfg.trunk_bk, cfg.trunk_stagger, cfg.trunk_dma_pos) == (320, 768, 1, 128, 1, 0, 0, 1,
-                                                                                                  0, 1, 0, 0, 0)
+            cfg.split3_tile_bn, cfg.tail_split, cfg.tail_s, cfg.trunk_persistent, cfg.trunk_bk, cfg.trunk_stagger, cfg.trunk_dma_pos,
+            cfg.trunk_ring, cfg.trunk_ring_bm) == (320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0)
+    # the ring kernel's row tile decides the statistics rows of a pre-split conv: 14x19 512->512 3x3 at batch 32 is on it
+    d14 = ops.conv_desc(32, 14, 19, 512, 512, 3, 3)
+    assert ops.conv2d_fwd_split3p_stats_rows(d14) == -(-32 * 14 * 19 // 128)
     d = ops.conv_desc(4, 12, 16, 128, 128, 3, 3)
     base = ops.conv2d_fwd_tiling(d)
     assert base[2] > 1

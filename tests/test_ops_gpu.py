@@ -993,13 +993,14 @@ def test_trunk_kernel_variants_agree(device, case):
     tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=device)
     outs = {}
     try:
-        for name, cfg in (("one-tile whole", dict(trunk_persistent=0, tail_split=0)),
-                          ("persistent whole", dict(trunk_persistent=2, tail_split=0)),
-                          ("one-tile", dict(trunk_persistent=0)),
-                          ("persistent", dict(trunk_persistent=2)),
-                          ("staggered", dict(trunk_persistent=2, trunk_stagger=50)),
-                          ("spread", dict(trunk_persistent=2, trunk_dma_pos=1)),
-                          ("bk64", dict(trunk_persistent=2, trunk_bk=64)), ("auto", dict()),
+        for name, cfg in (("one-tile whole", dict(trunk_persistent=0, tail_split=0, trunk_ring=0)),
+                          ("persistent whole", dict(trunk_persistent=2, tail_split=0, trunk_ring=0)),
+                          ("one-tile", dict(trunk_persistent=0, trunk_ring=0)),
+                          ("persistent", dict(trunk_persistent=2, trunk_ring=0)),
+                          ("staggered", dict(trunk_persistent=2, trunk_stagger=50, trunk_ring=0)),
+                          ("spread", dict(trunk_persistent=2, trunk_dma_pos=1, trunk_ring=0)),
+                          ("bk64", dict(trunk_persistent=2, trunk_bk=64, trunk_ring=0)),
+                          ("auto no ring", dict(trunk_ring=0)), ("auto", dict()),
                           ("ring256 whole", dict(trunk_ring=2, trunk_ring_bm=256, tail_split=0)),
                           ("ring128 whole", dict(trunk_ring=2, trunk_ring_bm=128, tail_split=0)),
                           ("ring256", dict(trunk_ring=2, trunk_ring_bm=256)),
@@ -1030,7 +1031,8 @@ def test_trunk_kernel_variants_agree(device, case):
     for name in ("ring256 whole", "ring128 whole"):
         assert torch.equal(outs[name][0], outs["one-tile whole"][0]), name
     # the same plan, different timing -> the same bits (partials are added in range order, whoever arrives last)
-    for name in ("persistent", "staggered", "spread", "auto"):
+    # (the shipped choice, "auto", may put a shape on the ring kernel: other tail ranges, not the same bits)
+    for name in ("persistent", "staggered", "spread", "auto no ring"):
         assert torch.equal(outs[name][0], outs["one-tile"][0]), name
     for name in ("staggered", "spread"):
         assert torch.equal(outs[name][1], outs["persistent"][1]), name

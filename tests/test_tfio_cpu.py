@@ -234,6 +234,16 @@ def test_native_record_reader_detects_corruption(tmp_path):
     empty = str(tmp_path / "empty.tfrecord")
     open(empty, "wb").close()
     assert tfio.read_tfrecord_native(empty) == []
+    # context dimensions from the file are range-checked BEFORE any product is formed: H = W = -1 (whose product with a
+    # depth of 12 * 4 would "match" a 48-byte step), a zero and a huge dimension are all refused with EINVAL
+    for h, w, d_, nbytes in ((-1, -1, 12, 48), (1 << 40, 1, 1, 4), (-36, -48, 12, 36 * 48 * 12 * 4)):
+        ctx = OrderedDict([("classes", np.array([1])), ("location", np.array([1])),
+                           ("audio_image/height", np.array([h])), ("audio_image/width", np.array([w])),
+                           ("audio_image/depth", np.array([d_]))])
+        bad = tfio.build_sequence_example(ctx, OrderedDict([("audio/image", [b"\0" * nbytes])]))
+        with pytest.raises(Exception) as ei:
+            tfio.decode_sequence_example_native(bad)
+        assert "out of range" in str(ei.value), str(ei.value)
 
 
 def test_reader_on_hand_built_known_answer_bundle(tmp_path):

@@ -37,7 +37,7 @@ def l2_err(got, ref):
     return float((got - ref).norm() / max(float(ref.norm()), 1e-30))
 
 
-def build(device, num_skip, embedding, batch, lr=1e-3, precision="f16x3", bench_defaults=False):
+def build(device, num_skip, embedding, batch, lr=1e-3, precision="f16x3", bench_defaults=False, side_lane=True, stages=None):
     from acimg.flags import FLAGS
     from acimg.session import Session
     from acimg.trainer import Trainer
@@ -52,9 +52,9 @@ def build(device, num_skip, embedding, batch, lr=1e-3, precision="f16x3", bench_
     orc = otr.Oracle(num_skip=num_skip, embedding=embedding, learning_rate=lr, latent_loss=FLAGS.latent_loss,
                      randomize=True)
     sess = Session(device)
-    mi = ResNet50Model(input_shape=[224, 298, 3], num_classes=None, precision=precision)
+    mi = ResNet50Model(input_shape=[224, 298, 3], num_classes=None, precision=precision, stages=stages, side_lane=side_lane)
     ma = UNetAc(input_shape=[36, 48, 12], embedding=embedding, num_skip=num_skip,
-                precision="split" if precision == "f16x3" else "f32")
+                precision="split" if precision == "f16x3" else "f32", side_lane=side_lane)
     if not bench_defaults:
         ma.split_min_rows = 0   # exercise the split-MFMA generator convs even at the tiny test batch
     tr = Trainer(ma, mi, learning_rate=lr, session=sess)
@@ -93,7 +93,7 @@ def tf_adam_fp64(p, g, m, v, step, lr):
 
 
 @pytest.mark.parametrize("num_skip,embedding,precision", [(1, False, "f16x3"), (1, False, "f32"), (2, False, "f16x3"),
-                                                         (0, True, "f32")])
+                                                         (0, True, "f32"), (0, False, "f16x3")])
 def test_train_step_matches_oracle(device, num_skip, embedding, precision):
     """Three consecutive optimisation steps, each compared from IDENTICAL state (the HIP state is
     re-synchronised from the oracle before every step): forward tensors, loss terms, every gradient,
@@ -345,8 +345,8 @@ def test_bench_configuration_matches_oracle(device):
 
 def test_configs2_two_skip_batch64(device):
     """BASELINE configs[2]: `unet_acresnet` 2-skip generator at batch 64 (models/unet_acresnet2skip.py:82-83 under
-    trainer/mfcctrainer.py:28-82).  Forward against the oracle (loss terms, ResNet feature, mean / std, generated
-    images: 1e-3), plus the size-independent properties: a replayed step is bit-identical, the reported MSE is the
+    trainer/mfcctrainer.py:28-82).  One whole oracle step at that size (loss terms, mean / std, generated images, the
+    gradient of every trained variable: 1e-3), plus the size-independent properties: a replayed step is bit-identical, the reported MSE is the
     MSE of the generated images, and the step lowers the loss on a repeated batch."""
     from oracle import trainer as otr
 
@@ -359,12 +359,25 @@ def test_configs2_two_skip_batch64(device):
     g = tr.primary
     out1, g1 = g.modelac.output.clone(), st.grad.clone()
     feat1 = g.modelimages.output.clone()
-    with torch.no_grad():
-        mean, std, out, _ = orc.forward(vid, mf, eps, True)
-        L = orc.losses(ac, mean, std, out)
+    # ONE oracle step (forward + backward) at this size: loss terms, feature, mean / std, images, and the gradient of
+    # every trained variable (per-variable L2 norms and the L2 error), ReLU / tie patterns taken from the HIP run as
+    # in the other train-step tests
+    acts = saved_activations(g)
+    masks = dict((k, v > 0) for k, v in acts.items())
+    for key, src in (("minmax/conv2_0", acts["layer2/conv_2"]), ("minmax/feature", acts["conv_map"])):
+        masks[key] = (src == src.amin(dim=(1, 2, 3), keepdim=True), src == src.amax(dim=(1, 2, 3), keepdim=True))
+    ref = orc.train_step(ac, mf, vid, eps, keep_grads=True, relu_masks=masks)
     for k in ("mse", "huber", "latent", "reg", "loss"):
-        assert abs(r1[k] - float(L[k])) <= TOL * max(abs(float(L[k])), 1e-8), (k, r1[k], float(L[k]))
-    assert rel_err(out1, out) < TOL and rel_err(g.modelac.mean, mean) < TOL and rel_err(g.modelac.std, std) < TOL
+        assert abs(r1[k] - ref[k]) <= TOL * max(abs(ref[k]), 1e-8), (k, r1[k], ref[k])
+    assert rel_err(out1, ref["output"]) < TOL and rel_err(g.modelac.mean, ref["mean"]) < TOL
+    assert rel_err(g.modelac.std, ref["std"]) < TOL
+    grads = st.grad_dict()
+    worst_l2 = max(((l2_err(grads[k], gr), k) for k, gr in ref["grads"].items()))
+    print("configs[2] batch 64 gradients: worst L2 error %.2e (%s)" % worst_l2)
+    assert worst_l2[0] < TOL, worst_l2
+    for k, gr in ref["grads"].items():
+        n_ref = float(gr.double().norm())
+        assert abs(float(grads[k].double().norm()) - n_ref) <= TOL * max(n_ref, 1e-12), k
     mse = float(((out1.double().cpu() - ac.double()) ** 2).mean())
     assert abs(r1["mse"] - mse) <= 1e-5 * mse
     # replay from the same state: bit-identical
@@ -379,6 +392,82 @@ def test_configs2_two_skip_batch64(device):
     for _ in range(3):
         r3 = tr.train_step(None, eps=eps)
     assert r3["mse"] < r1["mse"]
+
+
+def test_sharded_step_pipelined_equals_one_stream(device):
+    """`train_step_sharded(pipelined=True)` (bench.py --scaling strong): the shards of a strong-scaling step go through
+    the pipeline's lanes (trunk of shard i + 1 beside the trained part of shard i; accumulation, the exchange and the
+    one Adam update on the trained part's stream) - two steps of four shards, bit-identical to the one-stream form in
+    weights, Adam moments, batch-norm moving statistics and the mean losses of each step."""
+    from oracle import trainer as otr
+
+    steps = [[otr.synthetic_batch(2, seed=700 + 10 * s_ + i) for i in range(4)] for s_ in range(2)]
+    tr, orc, sess = build(device, 1, False, 2)
+    seq = []
+    for shards in steps:
+        r = tr.train_step_sharded([b[:3] for b in shards], eps=[b[3] for b in shards])
+        seq.append([r[k] for k in ("mse", "huber", "latent", "reg", "loss")])
+    torch.cuda.synchronize()
+    st = sess.store
+    want = (st.flat["train"].clone(), st.flat["state"].clone(), st.adam_m.clone(), st.adam_v.clone())
+    tr2, orc2, sess2 = build(device, 1, False, 2)
+    for t, shards in enumerate(steps):
+        assert tr2.train_step_sharded([b[:3] for b in shards], eps=[b[3] for b in shards], pipelined=True, tag=t) is None
+    tr2.flush_pipeline()
+    got = dict((t, [r[k] for k in ("mse", "huber", "latent", "reg", "loss")]) for t, r in tr2.pop_finished())
+    torch.cuda.synchronize()
+    assert tr2.global_step == 2 == tr.global_step
+    st2 = sess2.store
+    assert torch.equal(st2.flat["train"], want[0]), float((st2.flat["train"] - want[0]).abs().max())
+    assert torch.equal(st2.flat["state"], want[1])
+    assert torch.equal(st2.adam_m, want[2]) and torch.equal(st2.adam_v, want[3])
+    for t in range(2):      # the one-stream form averages on the host in float32 tensors too: same bits
+        assert got[t] == pytest.approx(seq[t], rel=1e-6, abs=0), (got[t], seq[t])
+
+
+def test_pipelined_schedule_at_bench_size(device):
+    """The schedule bench.py times, at the size it times it (batch 32, f16x3, three lanes): 8 DIFFERENT batches through
+    `train_step_pipelined` - with a partial batch of 16 in the middle (another graph: the pipeline drains and refills)
+    and an explicit `flush_pipeline()` between two full batches - against the same 8 batches through `train_step` on a
+    second trainer: weights, Adam moments, batch-norm moving statistics and every batch's loss terms BIT-IDENTICAL.
+    At this size a trunk stage is ~3 ms of kernels per lane, so the cross-stage hand-offs (boundary tensor / event "x",
+    `xfinal` / event "b", per-stage arenas, statistics and tail workspaces) are exercised where they could race."""
+    from oracle import trainer as otr
+
+    B = 32
+    sizes = [B, B, B, 16, B, B, B, B]
+    batches = [otr.synthetic_batch(n, seed=900 + i) for i, n in enumerate(sizes)]
+    tr, orc, sess = build(device, 1, False, B, lr=1e-4, bench_defaults=True)
+    seq = []
+    for ac, mf, vid, eps in batches:
+        r = tr.train_step((ac, mf, vid), eps=eps)
+        seq.append([r[k] for k in ("mse", "huber", "latent", "reg", "loss")])
+    torch.cuda.synchronize()
+    st = sess.store
+    want = (st.flat["train"].clone(), st.flat["state"].clone(), st.adam_m.clone(), st.adam_v.clone())
+    del tr, orc, sess
+    torch.cuda.empty_cache()
+
+    tr2, orc2, sess2 = build(device, 1, False, B, lr=1e-4, bench_defaults=True)
+    got = {}
+    for i, (ac, mf, vid, eps) in enumerate(batches):
+        tr2.train_step_pipelined((ac, mf, vid), eps=eps, tag=i)
+        if i == 5:
+            tr2.flush_pipeline()                    # mid-stream drain: the next call refills the lanes
+            assert tr2.global_step == 6
+        for t, r in tr2.pop_finished():
+            got[t] = [r[k] for k in ("mse", "huber", "latent", "reg", "loss")]
+    assert tr2._pipe["lanes"] >= 2, "the lanes did not get streams of their own: nothing overlapped"
+    tr2.flush_pipeline()
+    for t, r in tr2.pop_finished():
+        got[t] = [r[k] for k in ("mse", "huber", "latent", "reg", "loss")]
+    torch.cuda.synchronize()
+    assert tr2.global_step == len(batches) and sorted(got) == list(range(len(batches)))
+    st2 = sess2.store
+    assert torch.equal(st2.flat["train"], want[0]), float((st2.flat["train"] - want[0]).abs().max())
+    assert torch.equal(st2.flat["state"], want[1]), "batch-norm moving statistics"
+    assert torch.equal(st2.adam_m, want[2]) and torch.equal(st2.adam_v, want[3])
+    assert [got[i] for i in range(len(batches))] == seq
 
 
 def test_sharded_step_accumulates_like_data_parallel(device):
@@ -427,9 +516,7 @@ def test_side_lane_is_only_a_schedule(device, monkeypatch):
     ac, mf, vid, eps = otr.synthetic_batch(2, seed=77)
     res = {}
     for lane in (True, False):
-        if not lane:
-            monkeypatch.setenv("ACIMG_NO_SIDE_LANE", "1")       # host-side switch read when the model is constructed
-        tr, orc, sess = build(device, 1, False, 2)
+        tr, orc, sess = build(device, 1, False, 2, side_lane=lane)      # a constructor argument of both models
         assert tr.modelac.side_lane == lane
         g = tr.graphs[2]
         assert bool(g.plan_train.side) == lane

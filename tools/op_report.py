@@ -1,8 +1,5 @@
 """Per-call report of the recorded train step, measured in place: every C-ABI call of the plan is bracketed with
 events (Plan.run_probed) over a few steps.  Run on the GPU box.  usage: python tools/op_report.py [batch] [first_call] [trainer_mask|unet_rgb|unet_sound]"""
-import os
-
-os.environ.setdefault("ACIMG_NO_SIDE_LANE", "1")   # per-op attribution: one stream (overlapped ops would be charged each other's time)
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "acoustic-image-generation_amd"))
@@ -21,8 +18,9 @@ sess = Session(dev)
 gen = torch.Generator().manual_seed(1234)
 if workload == "trainer_mask":
     FLAGS.model, FLAGS.ae, FLAGS.num_skip_conn = "UNet", 0, 1
-    tr = Trainer(UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=1),
-                 ResNet50Model(input_shape=[224, 298, 3], num_classes=None), learning_rate=1e-4, session=sess)
+    # per-op attribution: one stream, one trunk stage (overlapped ops would be charged each other's time)
+    tr = Trainer(UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=1, side_lane=False),
+                 ResNet50Model(input_shape=[224, 298, 3], num_classes=None, side_lane=False), learning_rate=1e-4, session=sess)
     g = tr._build_functions(batch_size=B)
     tr.modelimages.initialize(seed=1238)
     tr.modelac.initialize(seed=1239)
