@@ -16,6 +16,7 @@
 #include "igemm_split3d_kernel.hpp"
 #include "igemm_split3dp_kernel.hpp"
 #include "igemm_split3r_kernel.hpp"
+#include "igemm_split3r2_kernel.hpp"
 #include <cstdlib>
 #include <algorithm>
 
@@ -1202,7 +1203,7 @@ int acimg_configure(const AcimgConfig* c) {
     if (c->trunk_stagger < 0 || c->trunk_stagger > 100) return fail(ACIMG_EINVAL, "configure: trunk_stagger is a percentage");
     if (c->trunk_bk != 0 && c->trunk_bk != 32 && c->trunk_bk != 64)
         return fail(ACIMG_EINVAL, "configure: trunk_bk must be 0 (per layer), 32 or 64");
-    if (c->trunk_ring < 0 || c->trunk_ring > 2) return fail(ACIMG_EINVAL, "configure: trunk_ring is 0, 1 or 2");
+    if (c->trunk_ring < 0 || c->trunk_ring > 4) return fail(ACIMG_EINVAL, "configure: trunk_ring is 0 .. 4");
     if (c->trunk_ring_bm != 0 && c->trunk_ring_bm != 128 && c->trunk_ring_bm != 256)
         return fail(ACIMG_EINVAL, "configure: trunk_ring_bm must be 0 (per shape), 128 or 256");
     if (c->split3_tile_bm || c->split3_tile_bn) {
@@ -1526,10 +1527,21 @@ static int ring_rows(const AcimgConvDesc* d, int terms) {
     if (c.bm != 128 || c.bn != 128) return 0;
     const long t128 = (long)cdiv(M, 128) * cdiv(d->K, 128);
     const int kiters = d->R * d->S * (d->C / 32);
-    if (g_cfg.trunk_ring == 1) return (t128 > 256 && t128 <= 300 && kiters >= 64) ? 128 : 0;
+    if (g_cfg.trunk_ring == 1 || g_cfg.trunk_ring == 4) return (t128 > 256 && t128 <= 300 && kiters >= 64) ? 128 : 0;
+    if (g_cfg.trunk_ring == 3) return 0;
     if (g_cfg.trunk_ring_bm) return g_cfg.trunk_ring_bm;
     const long t256 = (long)cdiv(M, 256) * cdiv(d->K, 128);
     return t256 >= 500 ? 256 : 128;
+}
+
+// Two-slot ring kernel (igemm_split3r2_kernel.hpp: 128x128 tiles, two workgroups per CU): trunk_ring 3 = every 128x128
+// shape, 4 = every 128x128 shape the ring kernel's rule does not take
+static bool use_ring2(const AcimgConvDesc* d, int terms) {
+    if (g_cfg.trunk_ring < 3 || terms != 3) return false;
+    const int M = d->N * d->OH * d->OW;
+    if ((long)M * d->ldy * 4 >= (1L << 31)) return false;
+    const Split3Cfg c = pick_split3(M, d->K);
+    return c.bm == 128 && c.bn == 128;
 }
 
 int acimg_conv2d_fwd_split3p_stats_rows(const AcimgConvDesc* d) {
@@ -1548,6 +1560,8 @@ int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out) {
     if (const int rr = ring_rows(d, 3)) {      // the ring kernel: its row tile, flag 2
         out[0] = rr;
         out[2] = 2;
+    } else if (use_ring2(d, 3)) {
+        out[2] = 3;                            // the two-slot ring kernel
     }
     return ACIMG_OK;
 }
@@ -1749,7 +1763,7 @@ static int dgrad_split_onthefly(const AcimgConvDesc* d, const float* gy, int ldg
 // ---- tail split of the trunk kernel: which tiles to cut, and into how many K ranges ------------------------
 struct TailPlan { int whole, s, rem; };
 static int resident_slots(int which, const void* fn, int threads, size_t lds) {
-    static int cache[7] = {0, 0, 0, 0, 0, 0, 0};
+    static int cache[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (!cache[which]) {
         int dev = 0, ncu = 0, per = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -1757,7 +1771,7 @@ static int resident_slots(int which, const void* fn, int threads, size_t lds) {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, threads, lds) != hipSuccess || ncu <= 0 || per <= 0) {
             (void)hipGetLastError();
             ncu = 256;                    // MI355X; no device (CPU-side sizing queries): same answer
-            per = which >= 4 ? 1 : (which == 0 || which == 3) ? 2 : 3;
+            per = which == 7 ? 2 : which >= 4 ? 1 : (which == 0 || which == 3) ? 2 : 3;
         }
         cache[which] = ncu * per;
     }
@@ -1881,6 +1895,28 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
         if (rr == 256) hipLaunchKernelGGL((igemm_split3r_kernel<4>), dim3(nwg), dim3(512), lds_r, st, p, units, nwg);
         else hipLaunchKernelGGL((igemm_split3r_kernel<2>), dim3(nwg), dim3(512), lds_r, st, p, units, nwg);
         return check_launch("conv2d_fwd_split3p (ring)");
+    }
+    if (use_ring2(d, terms)) {
+        const size_t lds_2 = (size_t)2 * 4 * 128 * 64 + 8 * 1024 + 2 * 2 * 128 * 4;
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)igemm_split3r2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_2);
+            attr2 = true;
+        }
+        const int P2 = resident_slots(7, (const void*)igemm_split3r2_kernel, 512, lds_2);
+        TailPlan t2{T, 1, 0};
+        if (ws && ws_bytes >= acimg_conv2d_fwd_split3p_workspace(d)) t2 = pick_tail(T, P2, p.kiters, TS_MAX_UNITS);
+        p.ts_whole = t2.whole; p.ts_s = t2.s;
+        p.ts_counters = static_cast<int*>(ws);
+        p.ts_partial = ws ? reinterpret_cast<float*>(static_cast<char*>(ws) + TS_COUNTER_BYTES) : nullptr;
+        const int units = t2.whole + t2.rem * t2.s;
+        const int nwg = std::min(units, P2);
+#if defined(ACIMG_STAMP) || defined(ACIMG_ABLATE)
+        p.slab = g_stamp_buf;
+        p.flip = g_stamp_nostore;
+#endif
+        hipLaunchKernelGGL(igemm_split3r2_kernel, dim3(nwg), dim3(512), lds_2, st, p, units, nwg);
+        return check_launch("conv2d_fwd_split3p (ring2)");
     }
     const bool persistent = !big_out && split3p_persistent(c, T);
     // K-step depth of the persistent kernel: 32 = the one-tile kernel's image (2 workgroups / CU); 64 = full 128-byte

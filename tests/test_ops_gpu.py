@@ -1006,7 +1006,8 @@ def test_trunk_kernel_variants_agree(device, case):
                           ("ring256", dict(trunk_ring=2, trunk_ring_bm=256)),
                           ("ring128", dict(trunk_ring=2, trunk_ring_bm=128)),
                           ("ring256 s3", dict(trunk_ring=2, trunk_ring_bm=256, tail_s=3)),
-                          ("ring", dict(trunk_ring=2))):
+                          ("ring", dict(trunk_ring=2)),
+                          ("ring2 whole", dict(trunk_ring=3, tail_split=0)), ("ring2", dict(trunk_ring=3))):
             _lib.configure(**cfg)
             srows = ops.conv2d_fwd_split3p_stats_rows(d)     # depends on the kernel the configuration picks
             y = torch.full((N, d.OH, d.OW, K), float("nan"), device=device)
@@ -1036,6 +1037,7 @@ def test_trunk_kernel_variants_agree(device, case):
         assert torch.equal(outs[name][0], outs["one-tile"][0]), name
     for name in ("staggered", "spread"):
         assert torch.equal(outs[name][1], outs["persistent"][1]), name
+    # the two-slot ring kernel sums a K step's three terms in another order (lo*hi, hi*hi, hi*lo): equal to rounding
     y0 = outs["one-tile whole"][0]
     for name in outs:
         assert float((outs[name][0] - y0).abs().max()) <= 4e-6 * float(y0.abs().max()), name
