@@ -149,3 +149,72 @@ def test_init_model_from_known_answer_bundle(device):
     b = next(iter(SyntheticDataLoader(2, 2, seed=3).data))
     r = tr.train_step((b[0], b[1], b[2]))
     assert np.isfinite(r["loss"])
+
+
+def test_tfrecord_loader_feeds_the_trainer(device, tmp_path):
+    """`TFRecordDataLoader` (acimg/data.py): the reference's on-disk format end to end - GZIP TFRecords of SequenceExamples
+    (convert_data.py:247-279) -> native reader (`_parse_sequence`, dataloader/outdoor_data_mfcc.py:263-343, LR + UD flip)
+    -> device low-pass + MFCC with `_normalize_mfcc` (:558-575, :696-703, :796-876) -> per-frame maps (:634-679) ->
+    frames re-batched (:99-104) -> `Trainer.train()`.  Every tensor of every batch against the pinned CPU oracle of the
+    front end and a NumPy restatement of the maps; then one epoch of training + validation straight from the files."""
+    from collections import OrderedDict
+
+    from acimg import tfio
+    from acimg.data import TFRecordDataLoader
+    from acimg.flags import FLAGS
+    from oracle import frontend as ofe
+
+    rng = np.random.RandomState(3)
+    recs, truth = [], []
+    for r in range(2):
+        ai = rng.rand(12, 36, 48, 12).astype(np.float32) * 5 - 1
+        sa = (rng.randn(12, 1024) * 800).astype(np.int32)
+        vi = rng.randint(0, 256, size=(12, 224, 298, 3)).astype(np.uint8)
+        ctx = OrderedDict([("classes", np.array([3 + r])), ("location", np.array([7])),
+                           ("audio_image/height", np.array([36])), ("audio_image/width", np.array([48])),
+                           ("audio_image/depth", np.array([12])), ("audio_data/mics", np.array([1])),
+                           ("audio_data/samples", np.array([1024])), ("video/height", np.array([224])),
+                           ("video/width", np.array([298])), ("video/depth", np.array([3]))])
+        lists = OrderedDict([("audio/image", [a.tobytes() for a in ai]), ("audio/data", [s.tobytes() for s in sa]),
+                             ("video/image", [v.tobytes() for v in vi])])
+        recs.append(tfio.build_sequence_example(ctx, lists))
+        truth.append((ai, sa, vi, 3 + r))
+    paths = []
+    for i, rec in enumerate(recs):
+        p = str(tmp_path / ("part%d.tfrecord" % i))
+        tfio.write_tfrecord(p, [rec], compression="GZIP")
+        paths.append(p)
+    listing = tmp_path / "train.txt"
+    listing.write_text("\n".join(paths) + "\n")
+    dl = TFRecordDataLoader(str(listing), 8, device=device)
+    assert dl.num_samples == 24 and dl.total_batches == 3
+    batches = list(dl.data)
+    assert [b[0].shape[0] for b in batches] == [8, 8, 8]
+    ac = torch.cat([b[0] for b in batches]).numpy()
+    mf = torch.cat([b[1] for b in batches]).numpy()
+    vid = torch.cat([b[2] for b in batches]).numpy()
+    act = torch.cat([b[3] for b in batches]).numpy()
+    mfl = torch.cat([b[5] for b in batches]).numpy()
+    for r, (ai, sa, vi, cls) in enumerate(truth):
+        sl = slice(12 * r, 12 * r + 12)
+        a = ai[:, ::-1, ::-1, :].astype(np.float32)                      # flip_left_right + flip_up_down (:314-315)
+        a = a - a.min(axis=(1, 2, 3), keepdims=True)
+        a = a / a.max(axis=(1, 2, 3), keepdims=True)
+        np.testing.assert_array_equal(ac[sl], a)
+        np.testing.assert_array_equal(vid[sl], vi[..., ::-1].astype(np.float32) * np.float32(1.0 / 255.0))
+        want = np.stack([ofe.normalize_mfcc(v) for v in ofe.mfcc(sa)])
+        np.testing.assert_allclose(mf[sl], want, rtol=2e-5, atol=2e-6)
+        low = ofe.butter_lowpass_filter(sa)
+        want_low = np.stack([ofe.normalize_mfcc(v) for v in ofe.mfcc(low)])
+        np.testing.assert_allclose(mfl[sl], want_low, rtol=2e-5, atol=2e-6)
+        assert (act[sl].argmax(1) == cls).all() and act[sl].sum() == 12
+    # one epoch of Trainer.train() straight from the files (training and validation loaders over the same two files)
+    FLAGS.checkpoint_dir, FLAGS.exp_name = None, "tfr"
+    FLAGS.restore_checkpoint = FLAGS.init_checkpoint = None
+    FLAGS.acoustic_init_checkpoint = FLAGS.visual_init_checkpoint = None
+    tr, sess = make(device, epochs=1)
+    lines = []
+    tr.log = lines.append
+    best = tr.train(TFRecordDataLoader(paths, 8, device=device), TFRecordDataLoader(paths[:1], 8, device=device))
+    assert tr.global_step == 3 and np.isfinite(best) and 0 < best < 1
+    assert sum("Training_mse_Loss" in ln for ln in lines) == 3
