@@ -15,6 +15,7 @@ from .ops import ACT_NONE, ACT_RELU
 from .params import Var, up4
 from .session import get_default_session
 from .vision import load_state_file
+from .unet_vae import AssociatorAudio          # noqa: F401  (models/multimodal.py:139-285: the conv associator)
 
 Z = 150
 

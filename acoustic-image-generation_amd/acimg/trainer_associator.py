@@ -2,7 +2,10 @@
 single-associator step of trainer/trainer_proietta.py:104-146: the encoder VAE's statistics go through the
 associator, the acoustic-image decoder reconstructs from z = mean + std * eps, loss = MSE + Huber +
 mean_b(0.5 * sum_j(mu^2 + s^2 - log(1e-8 + s^2) - 1)) / 1e6, Adam on the associator's variables.  The encoder
-statistics arrive as a device buffer [N, 2*DIN] (any encoder's fused [mean | std] head output).
+statistics arrive as a device buffer [N, 2*DIN] (any encoder's fused [mean | std] head output); the CONV associator
+`AssociatorAudio` (models/multimodal.py:139-285) takes the spectrogram [N,193,257,1] itself, runs its batch norms in
+training mode, and adds the l2_regularizer(8e-5) terms of its conv_conv_pool kernels, which
+tf.losses.get_total_loss() collects, to the loss.
 
 One step = ONE recorded plan: associator forward -> decoder forward -> reconstruction loss (+ gradient) ->
 decoder data gradients down to d loss / d (mean, std) (KL term included) -> associator backward; then Adam over
@@ -41,10 +44,15 @@ class TrainerAssociator(object):
         ma, md = self.modelassociator, self.modelac
         g = _Graph()
         g.N = N
-        g.stats = z(N, 2 * ma.DIN)            # [mean | std] of the encoder VAE
+        conv = bool(getattr(ma, "IMAGE_INPUT", False))
         g.acoustic = z(N, 36, 48, 12)
         g.eps = z(N, 150)
-        ma._build_model(g.stats[:, :ma.DIN], g.stats[:, ma.DIN:], session=sess)
+        if conv:
+            g.stats = z(N, ma.height, ma.width, ma.channels)      # the associator's own input (spectrogram)
+            ma._build_model(g.stats, session=sess)
+        else:
+            g.stats = z(N, 2 * ma.DIN)        # [mean | std] of the encoder VAE
+            ma._build_model(g.stats[:, :ma.DIN], g.stats[:, ma.DIN:], session=sess)
         md._build_model(g.acoustic, ma.mean, ma.std, session=sess, eps=g.eps)
         g.sums, g.losses = z(4), z(8)
         g.g_logit = z(N, 36, 48, 12)
@@ -54,9 +62,19 @@ class TrainerAssociator(object):
         p.extend(ma.plan_fwd)
         p.extend(md.plan_fwd)
         ops.recon_loss(p, md.yhat.t, g.acoustic, g.g_logit, g.sums, count, 1.0, 1.0)
-        ops.loss_finalize(p, g.sums, md.kl, N, count, _LATENT_W, 0.0, 1.0, 1.0, g.losses)
+        st = sess.store
+        wd, nreg = 0.0, 0
+        if conv:                                  # kernel regularisers of the conv associator: one pass each way
+            roff, nreg = ma.reg_range()
+            wd = ma.WD
+            wreg = ops.LazyPtr(lambda: st.flat["train"][roff:roff + nreg])
+            greg = ops.LazyPtr(lambda: st.grad[roff:roff + nreg])
+            ops.sumsq(p, wreg, nreg, ops.Ptr(g.sums, 2))
+        ops.loss_finalize(p, g.sums, md.kl, N, count, _LATENT_W, 0.5 * wd, 1.0, 1.0, g.losses)
         md.record_backward(p, g.g_logit, _LATENT_W / N)
         ma.record_backward(p, md.g_ext)
+        if nreg:
+            ops.axpy(p, wd, wreg, greg, nreg)
         g.plan_train = p
         sess.finalize()
         rng = [(n, o, c) for n, o, c in sess.store.train_ranges() if n.startswith(ma.scope + "/")]
@@ -89,4 +107,4 @@ class TrainerAssociator(object):
                                              0.999, 1e-8, 1.0, ops.current_stream_handle(self.session.device))
             _lib.check(rc, "adam_step")
         v = g.losses[:5].tolist()
-        return OrderedDict(mse=v[0], huber=v[1], latent=v[2], loss=v[4])
+        return OrderedDict(mse=v[0], huber=v[1], latent=v[2], reg=v[3], loss=v[4])

@@ -45,6 +45,8 @@ class UNetVAE(object):
     # (layer, upsample filters, upsample kernel (kh, kw), skip layer)
     DEC = None
     COUT = None
+    HEAD_NAMES = ("mean", "variance")
+    ENCODER_ONLY = False
 
     def __init__(self, input_shape=None, precision="split"):
         """precision: "split" = layers with >= 32 channels on both sides run on the split-MFMA kernels (forward
@@ -84,6 +86,8 @@ class UNetVAE(object):
             widths[name] = F_
             cin = F_
         t.append(("heads", None, None, (self.HEAD[0], self.HEAD[1], cin, self.Z)))
+        if self.ENCODER_ONLY:
+            return t
         t.append(("dense", "dense", None, (self.Z, self.HEAD[0] * self.HEAD[1])))
         t.append(("conv", "conv2d", None, (3, 3, 1, 128)))
         cin = 128
@@ -117,7 +121,7 @@ class UNetVAE(object):
             elif kind == "deconv":
                 store.add(Var("%s/%s/bias" % (s, name), (shape[2],), "vec", "train"))
             elif kind == "heads":
-                self.heads = FusedHeads(s, shape[2], self.Z, True, hw=self.HEAD, names=("mean", "variance"))
+                self.heads = FusedHeads(s, shape[2], self.Z, True, hw=self.HEAD, names=self.HEAD_NAMES)
                 store.add_fused(self.heads)
             elif kind == "dense":
                 store.add(Var("%s/dense/kernel" % s, shape, "dense", "train"))
@@ -263,6 +267,12 @@ class UNetVAE(object):
         return L
 
     def _record_forward(self, plan, sizes):
+        net = self._record_encoder(plan, sizes)
+        self._record_latent_and_decoder(plan, sizes, net)
+
+    def _record_encoder(self, plan, sizes):
+        """input padding, the conv-conv-pool encoder (skip tensors into their concat slices) and the fused heads GEMM:
+        leaves `conv5` and `heads_out` [N, 2Z] = [head 0 | head 1]"""
         N = self.N
         z = self.session.zeros
         H, W = self.height, self.width
@@ -299,6 +309,14 @@ class UNetVAE(object):
         self.heads_out = z(N, 2 * Zn)
         self.d_heads = ops.conv_desc(N, 1, 1, kin, 2 * Zn, 1, 1, 1, "VALID", ldx=kin, ldy=2 * Zn, ldw=2 * Zn)
         ops.conv2d_fwd(plan, self.d_heads, net.t, self._P("heads/kernel"), self._P("heads/bias"), self.heads_out)
+        return net
+
+    def _record_latent_and_decoder(self, plan, sizes, net):
+        N = self.N
+        z = self.session.zeros
+        H, W = self.height, self.width
+        hh, hw = self.HEAD
+        Zn = self.Z
         self.zbuf = z(N, Zn)
         self.kl = z(N)
         ops.latent_linear_fwd(plan, self.heads_out, self.eps, self.zbuf, Zn, self.kl, N, Zn)
@@ -336,6 +354,35 @@ class UNetVAE(object):
         ops.conv2d_fwd(plan, self.d_final, net.ptr, self._P("final/kernel"), self._P("final/bias"), self.yhat.ptr)
 
     # ---- backward ---------------------------------------------------------------------------------------
+    def _gbuf(self, a):
+        z = self.session.zeros
+        return Act(z(a.N, a.H, a.W, up4(a.C)), a.N, a.H, a.W, a.C)
+
+    def _cbr_back(self, plan, name, gy, dx, res=None):
+        """gy: gradient w.r.t. the layer's ReLU output (overwritten with the pre-BN gradient);
+        dx: where the gradient w.r.t. the layer's input goes (None for the first layer)"""
+        L = self.layers[name]
+        K = L.d.K
+        ops.bn_bwd(plan, L.raw.ptr, L.raw.ld, gy.ptr, gy.ld, L.scale, L.shift, L.save_mean, L.save_invstd,
+                   self._P(L.bn + "/gamma"), L.y.pixels, up4(K), gy.ptr, gy.ld, self._G(L.bn + "/gamma"),
+                   self._G(L.bn + "/beta"))
+        if self._use_split(L.d):
+            ops.conv2d_wgrad_split3(plan, L.d, L.x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"),
+                                    self._G(name + "/bias"), bf16=self._bf16)
+        else:
+            ops.conv2d_wgrad(plan, L.d, L.x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
+        if dx is not None and self._use_split(L.d):
+            wt = self._wsplit(name, ops.conv2d_split3_dgrad_weight_bytes(L.d), "dgrad")
+            ops.conv2d_split3_prepare_dgrad(plan, L.d, self._P(name + "/kernel"), wt)
+            ops.conv2d_dgrad_split3(plan, L.d, gy.ptr, gy.ld, wt, dx.ptr,
+                                    res.ptr if res is not None else None, res.ld if res is not None else 0,
+                                    None, 0, lddx=dx.ld, bf16=self._bf16)
+        elif dx is not None:
+            ops.conv2d_dgrad(plan, L.d, gy.ptr, gy.ld, self._P(name + "/kernel"), dx.ptr,
+                             res.ptr if res is not None else None, res.ld if res is not None else 0,
+                             None, 0, lddx=dx.ld)
+
+
     def record_backward(self, plan, g_logit, kl_weight):
         """g_logit: gradient w.r.t. the PRE-sigmoid output [N,H,W,up4(cout)] (from recon_loss);
         kl_weight: d loss / d kl[n] (trainer/trainer.py:61-73: 1 / (1e6 * N * Z), the 0.5 is inside kl)."""
@@ -343,32 +390,10 @@ class UNetVAE(object):
         z = self.session.zeros
         Zn = self.Z
 
-        def gbuf(a):
-            return Act(z(a.N, a.H, a.W, up4(a.C)), a.N, a.H, a.W, a.C)
+        gbuf = self._gbuf
 
         def cbr_back(name, gy, dx, res=None):
-            """gy: gradient w.r.t. the layer's ReLU output (overwritten with the pre-BN gradient);
-            dx: where the gradient w.r.t. the layer's input goes (None for the first layer)"""
-            L = self.layers[name]
-            K = L.d.K
-            ops.bn_bwd(plan, L.raw.ptr, L.raw.ld, gy.ptr, gy.ld, L.scale, L.shift, L.save_mean, L.save_invstd,
-                       self._P(L.bn + "/gamma"), L.y.pixels, up4(K), gy.ptr, gy.ld, self._G(L.bn + "/gamma"),
-                       self._G(L.bn + "/beta"))
-            if self._use_split(L.d):
-                ops.conv2d_wgrad_split3(plan, L.d, L.x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"),
-                                        self._G(name + "/bias"), bf16=self._bf16)
-            else:
-                ops.conv2d_wgrad(plan, L.d, L.x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
-            if dx is not None and self._use_split(L.d):
-                wt = self._wsplit(name, ops.conv2d_split3_dgrad_weight_bytes(L.d), "dgrad")
-                ops.conv2d_split3_prepare_dgrad(plan, L.d, self._P(name + "/kernel"), wt)
-                ops.conv2d_dgrad_split3(plan, L.d, gy.ptr, gy.ld, wt, dx.ptr,
-                                        res.ptr if res is not None else None, res.ld if res is not None else 0,
-                                        None, 0, lddx=dx.ld, bf16=self._bf16)
-            elif dx is not None:
-                ops.conv2d_dgrad(plan, L.d, gy.ptr, gy.ld, self._P(name + "/kernel"), dx.ptr,
-                                 res.ptr if res is not None else None, res.ld if res is not None else 0,
-                                 None, 0, lddx=dx.ld)
+            return self._cbr_back(plan, name, gy, dx, res)
 
         # final 1x1 conv (sigmoid folded into g_logit)
         g_final = Act(g_logit, N, self.height, self.width, self.COUT)
@@ -406,6 +431,17 @@ class UNetVAE(object):
         ops.conv2d_dgrad(plan, self.d_dense, g_dns1, nd, self._P("dense/kernel"), g_z)
         g_heads = z(N, 2 * Zn)
         ops.latent_linear_bwd(plan, self.heads_out, self.eps, g_z, Zn, kl_weight, g_heads, N, Zn)
+        self._backward_encoder(plan, g_heads, g_skip)
+        self._grad_bufs = dict(g_z=g_z, g_heads=g_heads)
+
+    def _backward_encoder(self, plan, g_heads, g_skip):
+        """g_heads [N, 2Z]: gradient w.r.t. the fused heads output; heads weight + data gradient, then the encoder"""
+        Zn = self.Z
+        gbuf = self._gbuf
+
+        def cbr_back(name, gy, dx, res=None):
+            return self._cbr_back(plan, name, gy, dx, res)
+
         g = gbuf(self.conv5)
         ops.conv2d_wgrad(plan, self.d_heads, self.conv5.t, g_heads, 2 * Zn, self._G("heads/kernel"),
                          self._G("heads/bias"))
@@ -425,7 +461,6 @@ class UNetVAE(object):
             else:
                 g = gbuf(L1.x)
                 cbr_back(L1.name, g_mid, g)
-        self._grad_bufs = dict(g_z=g_z, g_heads=g_heads)
 
 
 class UNet(UNetVAE):
@@ -448,3 +483,63 @@ class UNetSound(UNetVAE):
 
     def __init__(self, input_shape=None, precision="split"):
         super(UNetSound, self).__init__(input_shape or [99, 257, 1], precision)
+
+
+class AssociatorAudio(UNetVAE):
+    """models/multimodal.py:139-285: the conv associator - a spectrogram ENCODER (conv_conv_pool x 5, strided-conv
+    "pools", batch norm in training mode) with two 12x16 VALID heads, mean and std = softplus(.), whose outputs stand
+    where the dense associators' do: the halves of ONE [N, 300] buffer that `UNetAcZ` takes as its external latent
+    statistics.  Same protocol as the dense associators (acimg/multimodal.py): `_build_model(inputs)` sets `mean`,
+    `std`, `plan_fwd`, `train_vars`; `record_backward(plan, g_ext)` consumes d loss / d [mean | std]."""
+    SCOPE, CIN, WD, HEAD, COUT = "AssociatorAudio", 1, 8e-5, (12, 16), None
+    Z = 150
+    ENC = [("1", 16, (3, 3), "VALID"), ("2", 16, (3, 3), "SAME"), ("3", 64, (3, 3), "SAME"), ("4", 128, (3, 3), "SAME"),
+           ("5", 128, None, None)]
+    DEC = []
+    HEAD_NAMES = ("mean", "std")
+    ENCODER_ONLY = True
+    IMAGE_INPUT = True
+
+    def __init__(self, input_shape=None, precision="split"):
+        super(AssociatorAudio, self).__init__(input_shape or [193, 257, 1], precision)
+
+    def _build_model(self, inputs, session=None, training=True):
+        """inputs: device buffer [N,193,257,1] (the STFT-magnitude spectrogram)"""
+        sess = session or get_default_session()
+        self.session = sess
+        self._register(sess.store)
+        N = inputs.shape[0]
+        assert tuple(inputs.shape[1:]) == (self.height, self.width, self.channels)
+        self.N, self.training = N, training
+        z = sess.zeros
+        H, W = self.height, self.width
+        self.images = inputs
+        self.xpad = Act(z(N, H, W, up4(self.CIN)), N, H, W, self.CIN)
+        sizes, h, w = {}, H, W
+        for name, F_, pool, pad in self.ENC:
+            sizes[name] = (h, w, F_)
+            if pool is not None:
+                h, w = (-(-h // 2), -(-w // 2)) if pad == "SAME" else ((h - pool[0]) // 2 + 1, (w - pool[1]) // 2 + 1)
+        assert (h, w) == tuple(self.HEAD)
+        self.cat = {}
+        self.layers = OrderedDict()
+        p = sess.new_plan()
+        self._record_encoder(p, sizes)
+        Zn = self.Z
+        self.ext = z(N, 2 * Zn)             # [mean | std = softplus(raw)]
+        ops.grad_slice(p, self.heads_out, 2 * Zn, self.ext, 2 * Zn, None, 0, N, Zn)
+        ops.softplus_fwd(p, ops.Ptr(self.heads_out, Zn), 2 * Zn, ops.Ptr(self.ext, Zn), 2 * Zn, N, Zn)
+        self.plan_fwd = p
+        self.mean, self.std = self.ext[:, :Zn], self.ext[:, Zn:]
+        self.network = OrderedDict(input=inputs, is_training=None, keep_prob=None, features=self.conv5.t)
+        self.train_vars = [n for n in sess.store.tf_names() if n.startswith(self.scope + "/") and
+                           not n.endswith(("moving_mean", "moving_variance"))]
+
+    def record_backward(self, plan, g_ext):
+        """g_ext [N, 300]: d loss / d [mean | std] (e.g. `UNetAcZ.g_ext`)"""
+        N, Zn = self.N, self.Z
+        g_heads = self.session.zeros(N, 2 * Zn)
+        ops.grad_slice(plan, g_ext, 2 * Zn, g_heads, 2 * Zn, None, 0, N, Zn)
+        ops.softplus_bwd(plan, ops.Ptr(self.heads_out, Zn), 2 * Zn, ops.Ptr(g_ext, Zn), 2 * Zn, ops.Ptr(g_heads, Zn),
+                         2 * Zn, N, Zn)
+        self._backward_encoder(plan, g_heads, {})

@@ -69,6 +69,22 @@ def forward(p, scope, mean, std, relu_masks=None):
     return outs[0], F.softplus(outs[1]), outs[1], masks
 
 
+def step_loss_audio(pa, pdec, spec, x, eps, relu_masks_a=None, relu_masks_d=None):
+    """the same step with the CONV associator `AssociatorAudio` (models/multimodal.py:139-285: a spectrogram encoder
+    in training mode, batch-norm batch statistics) in front of the decoder; tf.losses.get_total_loss() also collects
+    the l2_regularizer(8e-5) terms of its conv_conv_pool kernels"""
+    from . import unet_vae
+    fa, new_stats = unet_vae.forward(pa, spec, None, model="AssociatorAudio", training=True, relu_masks=relu_masks_a)
+    m, s = fa["mean"], fa["std"]
+    fw = unet_acoustic.forward(pdec, x, eps, m, s, relu_masks=relu_masks_d)
+    kl = 0.5 * (m * m + s * s - torch.log(1e-8 + s * s) - 1).sum(1)
+    latent = kl.mean(0) / 1000000
+    mse, hub = tfsem.mse_loss(x, fw["output"]), tfsem.huber_loss(x, fw["output"])
+    reg = sum(tfsem.l2_regularizer(w, 8e-5) for n, w in pa.items() if unet_vae.regularized(n))
+    return dict(loss=latent + mse + hub + reg, mse=mse, huber=hub, latent=latent, reg=reg, mean=m, std=s,
+                output=fw["output"], masks_a=fa["masks"], masks_d=fw["masks"], new_stats=new_stats)
+
+
 def step_loss(pa, scope, pdec, x, eps, mean_in, std_in, relu_masks_a=None, relu_masks_d=None):
     m, s, _, masks_a = forward(pa, scope, mean_in, std_in, relu_masks_a)
     fw = unet_acoustic.forward(pdec, x, eps, m, s, relu_masks=relu_masks_d)

@@ -32,6 +32,12 @@ CONFIGS = {
                            ("4", 64, (3, 3), "SAME"), ("5", 128, None, None)],
                       dec=[("6", 64, (2, 2), "4"), ("7", 32, (2, 2), "3"), ("8", 8, (3, 2), "2"), ("9", 8, (3, 3), "1")],
                       cout=1, input_hw=(99, 257)),
+    # models/multimodal.py:139-285: the conv ENCODER of a spectrogram with two 12x16 VALID heads, std = softplus(.);
+    # no decoder (`encoder_only`): it feeds the acoustic-image decoder of models/unet_z.py
+    "AssociatorAudio": dict(scope="AssociatorAudio", cin=1, wd=8e-5, Z=150, head=(12, 16),
+                            enc=[("1", 16, (3, 3), "VALID"), ("2", 16, (3, 3), "SAME"), ("3", 64, (3, 3), "SAME"),
+                                 ("4", 128, (3, 3), "SAME"), ("5", 128, None, None)],
+                            dec=[], cout=None, input_hw=(193, 257), heads=("mean", "std"), encoder_only=True),
 }
 
 
@@ -62,8 +68,11 @@ def param_shapes(model="UNet"):
         widths[name] = F_
         cin = F_
     hh, hw = cfg["head"]
-    conv("mean", hh, hw, cin, cfg["Z"])
-    conv("variance", hh, hw, cin, cfg["Z"])
+    hn = cfg.get("heads", ("mean", "variance"))
+    conv(hn[0], hh, hw, cin, cfg["Z"])
+    conv(hn[1], hh, hw, cin, cfg["Z"])
+    if cfg.get("encoder_only"):
+        return s
     s[sc + "/dense/kernel"] = (cfg["Z"], hh * hw)
     s[sc + "/dense/bias"] = (hh * hw,)
     conv("conv2d", 3, 3, 1, 128)
@@ -198,8 +207,11 @@ def forward(p, x, eps, model="UNet", training=True, relu_masks=None, bf16_operan
             net = cbr("layer%s/pool_2" % name, "layer%s/bn_pool_2" % name, net, 2, pad)
             acts["pool" + name] = net
     N = x.shape[0]
-    mean = tfsem.conv2d(net, p[sc + "/mean/kernel"], p[sc + "/mean/bias"], 1, "VALID").reshape(N, -1)
-    var = tfsem.conv2d(net, p[sc + "/variance/kernel"], p[sc + "/variance/bias"], 1, "VALID").reshape(N, -1)
+    hn = cfg.get("heads", ("mean", "variance"))
+    mean = tfsem.conv2d(net, p["%s/%s/kernel" % (sc, hn[0])], p["%s/%s/bias" % (sc, hn[0])], 1, "VALID").reshape(N, -1)
+    var = tfsem.conv2d(net, p["%s/%s/kernel" % (sc, hn[1])], p["%s/%s/bias" % (sc, hn[1])], 1, "VALID").reshape(N, -1)
+    if cfg.get("encoder_only"):        # models/multimodal.py:172-176: std = softplus(conv)
+        return dict(mean=mean, std=torch.nn.functional.softplus(var), raw_std=var, acts=acts, masks=masks_out), new_stats
     z = mean + var * eps
     hh, hw = cfg["head"]
     net = relu("dense", z @ p[sc + "/dense/kernel"] + p[sc + "/dense/bias"]).reshape(N, hh, hw, 1)

@@ -135,3 +135,80 @@ def test_joint_mlp(which, widths):
     print("%s: worst gradient %s %.2e" % (which, worst[1], worst[0]))
     assert worst[0] < 1e-3, worst
     assert rel(m.g_input.view(N, H, W, ctot), grads[-1]) < 1e-3
+
+
+def test_conv_associator_audio_step():
+    """`AssociatorAudio` (models/multimodal.py:139-285: the conv associator - conv_conv_pool x 5 on a 193x257x1
+    spectrogram, batch norm in training mode, two 12x16 VALID heads, std = softplus) in front of the frozen `unet_z`
+    decoder, the single-associator step of trainer/trainer_proietta.py:104-146 with the kernel regularisers that
+    tf.losses.get_total_loss() collects: mean / std / generated images, loss terms, every gradient of the associator
+    (kernels, biases, BN gamma / beta, heads), BN moving statistics, vs the fp64 oracle; a few steps lower the loss and
+    move only `AssociatorAudio/` variables."""
+    from acimg import multimodal
+    from acimg.session import Session
+    from acimg.trainer_associator import TrainerAssociator
+    from acimg.unet_acoustic import UNetAcZ
+    from oracle import multimodal as om
+    from oracle import unet_acoustic as oa
+    from oracle import unet_vae as ouv
+    from tests.test_unet_acoustic_gpu import _masks
+
+    dev = torch.device("cuda:0")
+    N = 4
+    sess = Session(dev)
+    tr = TrainerAssociator(multimodal.AssociatorAudio(), UNetAcZ(), learning_rate=1e-3, session=sess)
+    g = tr._build_functions(batch_size=N)
+    pa = ouv.init_params("AssociatorAudio", seed=31, dtype=torch.float64, bias_std=0.05, bn_jitter=0.1)
+    pd = oa.init_params(seed=32, dtype=torch.float64, bias_std=0.05)
+    tr.modelassociator.initialize(state={k: v.float() for k, v in pa.items()})
+    tr.modelac.initialize(state={k: v.float() for k, v in pd.items()})
+    gen = torch.Generator().manual_seed(33)
+    spec = torch.rand(N, 193, 257, 1, generator=gen, dtype=torch.float64)
+    x = torch.rand(N, 36, 48, 12, generator=gen, dtype=torch.float64)
+    eps = torch.randn(N, 150, generator=gen, dtype=torch.float64)
+    before = {k: v.clone() for k, v in sess.store.state_dict().items()}
+    r = tr.train_step((spec.float().to(dev), x.float().to(dev)), eps.float().to(dev), apply=False)
+    torch.cuda.synchronize()
+    ma, md = tr.modelassociator, tr.modelac
+    masks_a = {}
+    for name, L in ma.layers.items():
+        masks_a[name] = (L.y.t[..., L.y.off:L.y.off + L.y.C] > 0).cpu()
+    free = om.step_loss_audio(pa, pd, spec, x, eps)
+    flips = sum(int((free["masks_a"][k] != masks_a[k].reshape(free["masks_a"][k].shape)).sum()) for k in masks_a)
+    total = sum(v.numel() for v in masks_a.values())
+    print("AssociatorAudio: ReLU pattern differs from the fp64 oracle's in %d of %d places" % (flips, total))
+    assert flips < 200
+    assert rel(ma.mean, free["mean"]) < 1e-4 and rel(ma.std, free["std"]) < 1e-4       # forward vs the free-running oracle
+    p = {k: v.clone().requires_grad_(True) for k, v in pa.items()}
+    ref = om.step_loss_audio(p, pd, spec, x, eps, {k: v.reshape(free["masks_a"][k].shape) for k, v in masks_a.items()},
+                             _masks(md))
+    assert rel(ma.mean, ref["mean"].detach()) < 1e-4 and rel(ma.std, ref["std"].detach()) < 1e-4
+    assert rel(md.output, ref["output"].detach()) < 1e-4
+    for k in ("mse", "huber", "latent", "reg", "loss"):
+        assert abs(r[k] - float(ref[k])) <= 1e-4 * abs(float(ref[k])) + 1e-12, (k, r[k], float(ref[k]))
+    names = [k for k in p if ouv.trainable(k)]
+    grads = dict(zip(names, torch.autograd.grad(ref["loss"], [p[k] for k in names])))
+    got = sess.store.grad_dict()
+    worst = ("", 0.0)
+    for k, v in grads.items():
+        if k.endswith("/bias") and "/layer" in k:
+            # a conv bias under a batch norm has an exactly-zero gradient: ~0 relative to its kernel's on both sides
+            kmax = float(grads[k[:-4] + "kernel"].abs().max())
+            assert float(got[k].abs().max()) < 1e-4 * kmax and float(v.abs().max()) < 1e-6 * kmax, k
+            continue
+        e = rel(got[k], v)
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    print("AssociatorAudio: worst gradient %s %.2e" % worst)
+    assert worst[1] < 1e-3, worst
+    after_bn = sess.store.state_dict()
+    for k, v in ref["new_stats"].items():
+        assert rel(after_bn[k], v.detach()) < 1e-4, "BN moving statistic " + k
+    # a few optimisation steps: the loss falls, and only the associator's variables move
+    first = tr.train_step(None, eps.float().to(dev))
+    for _ in range(10):
+        last = tr.train_step(None, eps.float().to(dev))
+    assert last["loss"] < first["loss"]
+    after = sess.store.state_dict()
+    for k, v in before.items():
+        moved = not torch.equal(v, after[k])
+        assert moved == k.startswith("AssociatorAudio/"), (k, moved)
