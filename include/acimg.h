@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ACIMG_VERSION 201
+#define ACIMG_VERSION 202
 
 #define ACIMG_OK 0
 #define ACIMG_EINVAL (-1)     /* bad descriptor / shape / alignment */
