@@ -372,15 +372,29 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                // everyone has read the flag before `red` is reused
         if (!last) return false;
-        for (int c = 0; c < p.ts_s; ++c) {
-            const __amdgpu_buffer_rsrc_t rsQ =
+        // the s partial tiles of this unit's tile, added in range order.  The loads are what this takes (s x 128 KiB per
+        // tile from L2 / HBM at ~65 GB/s per CU): TWO ranges x TN fragments (8 loads of 1 KiB per wave) are in flight at a
+        // time - with 4 the reduction was latency-bound (one ~1.5 us round trip per 4 KiB and wave: 53 us of tail for
+        // ten 4-range tiles, profiles/r03/trunk_shapes_r03i_ring_tail_sweep.txt)
+        for (int c = 0; c < p.ts_s; c += 2) {
+            const bool two = c + 1 < p.ts_s;
+            const __amdgpu_buffer_rsrc_t rsQ0 =
                 __builtin_amdgcn_make_buffer_rsrc(slot0 + (long)c * (BM * BN), 0, BM * BN * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsQ1 = __builtin_amdgcn_make_buffer_rsrc(
+                slot0 + (long)(c + (two ? 1 : 0)) * (BM * BN), 0, two ? BM * BN * 4 : 0, 0x00020000);   // size 0: reads zeros
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {       // TN loads in flight at a time (registers)
+            for (int i = 0; i < TM; ++i) {
+                f32x4 v0[TN], v1[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j)     // sc1 loads: never a stale L1 / L2 copy
-                    acc[i][j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                               rsQ, tid * 16, (i * TN + j) * NTHR * 16, 16));
+                    v0[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                          rsQ0, tid * 16, (i * TN + j) * NTHR * 16, 16));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    v1[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                          rsQ1, tid * 16, (i * TN + j) * NTHR * 16, 16));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = (acc[i][j] + v0[j]) + v1[j];
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

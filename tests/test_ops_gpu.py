@@ -1093,11 +1093,11 @@ def test_pipeline_lanes_are_measured(device):
     lanes = ops.concurrent_streams(device, cur, 3)
     assert 1 <= len(lanes) <= 3
     assert len(set(s.cuda_stream for s in lanes + [cur])) == len(lanes) + 1
-    work = torch.rand(2048, 2048, device=device) * 0.01
+    work = torch.zeros(64, device=device)        # scratch of the library's own spin / zero kernels (no vendor GEMM)
     for s in lanes:
         assert ops._runs_beside(cur, s, work) and ops._runs_beside(s, cur, work)
     # a stream never runs beside itself
     assert not ops._runs_beside(cur, cur, work)
     ops.set_side_lane(device, lanes[0], lanes[0])          # "no second lane" is a valid side lane
     with torch.cuda.stream(lanes[0]):
-        assert ops.side_lane(device)[0] == lanes[0]
+        assert ops.side_lane(device) == lanes[0]
