@@ -1190,7 +1190,7 @@ int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
 
 int acimg_config_default(AcimgConfig* c) {
     if (!c) return fail(ACIMG_EINVAL, "config_default: null");
-    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0};
+    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0};
     return ACIMG_OK;
 }
 
@@ -1206,6 +1206,7 @@ int acimg_configure(const AcimgConfig* c) {
     if (c->trunk_ring < 0 || c->trunk_ring > 4) return fail(ACIMG_EINVAL, "configure: trunk_ring is 0 .. 4");
     if (c->trunk_ring_bm != 0 && c->trunk_ring_bm != 128 && c->trunk_ring_bm != 256)
         return fail(ACIMG_EINVAL, "configure: trunk_ring_bm must be 0 (per shape), 128 or 256");
+    if (c->trunk_b_brick < 0 || c->trunk_b_brick > 1) return fail(ACIMG_EINVAL, "configure: trunk_b_brick is 0 or 1");
     if (c->split3_tile_bm || c->split3_tile_bn) {
         const int bm = c->split3_tile_bm, bn = c->split3_tile_bn;
         if (!((bm == 128 && bn == 128) || (bm == 64 && bn == 128) || (bm == 128 && bn == 64)))
@@ -1566,8 +1567,32 @@ int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out) {
     return ACIMG_OK;
 }
 
+// Row-major planes [hi | lo][ldw][R*S*C], then (C % 32 == 0) the same weights once more in LDS-TILE ORDER: for every
+// (128-column tile nt, K step q of 32) the two 8 KiB plane images exactly as the trunk kernels keep them in LDS
+// (64-byte rows, logical chunk kc of row r at chunk kc ^ swz(r)), so a wave's LDS-DMA request for a weight piece is one
+// contiguous KiB = eight whole 128-byte lines instead of sixteen 64-byte pieces of rows 2*R*S*C bytes apart.
+static size_t split3_rowmajor_bytes(const AcimgConvDesc* d) { return (size_t)2 * d->ldw * d->R * d->S * d->C * 2; }
+static size_t split3_brick_bytes(const AcimgConvDesc* d) {
+    return d->C % 32 ? 0 : (size_t)cdiv(d->ldw, 128) * (d->R * d->S * d->C / 32) * 2 * 8192;
+}
 size_t acimg_conv2d_split3_weight_bytes(const AcimgConvDesc* d) {
-    return (size_t)2 * d->ldw * d->R * d->S * d->C * 2;
+    return split3_rowmajor_bytes(d) + split3_brick_bytes(d);
+}
+
+// one thread per 16-byte chunk of the tile-ordered image: brick (nt, q, plane), row, physical chunk
+__global__ void split3_brick_kernel(const char* __restrict__ planes, char* __restrict__ bricks, const int Nrows,
+                                    const int Ktot, const long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int pch = (int)(i & 3), row = (int)((i >> 2) & 127), plane = (int)((i >> 9) & 1);
+    const long bq = i >> 10;
+    const int kit = Ktot / 32;
+    const int nt = (int)(bq / kit), q = (int)(bq - (long)nt * kit);
+    const int n = nt * 128 + row;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (n < Nrows)
+        v = *reinterpret_cast<const uint4*>(planes + (((long)plane * Nrows + n) * Ktot + q * 32 + ((pch ^ swz(row)) << 3)) * 2);
+    *reinterpret_cast<uint4*>(bricks + i * 16) = v;
 }
 
 int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream) {
@@ -1576,7 +1601,13 @@ int acimg_conv2d_split3_prepare(const AcimgConvDesc* d, const float* w, void* ws
     const int Ktot = d->R * d->S * d->C;
     hipLaunchKernelGGL((split3_prepare_kernel<SplitF16, false>), dim3(cdiv(Ktot, 32), cdiv(d->ldw, 32)), dim3(256), 0,
                        (hipStream_t)stream, w, d->R * d->S, d->C, d->K, d->ldw, d->ldw, static_cast<_Float16*>(wsplit));
-    return check_launch("split3_prepare");
+    rc = check_launch("split3_prepare");
+    if (rc || !split3_brick_bytes(d)) return rc;
+    const long total = (long)(split3_brick_bytes(d) / 16);
+    hipLaunchKernelGGL(split3_brick_kernel, dim3((unsigned)cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const char*>(wsplit), static_cast<char*>(wsplit) + split3_rowmajor_bytes(d), d->ldw, Ktot,
+                       total);
+    return check_launch("split3_prepare (tile order)");
 }
 
 int acimg_conv2d_bf16_prepare(const AcimgConvDesc* d, const float* w, void* wsplit, void* stream) {
@@ -1845,6 +1876,7 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
     if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31) || (long)x_lo_off < plane)
         return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: operand >= 2 GiB or overlapping planes");
     p.a_bytes = (unsigned)a_bytes; p.b_bytes = (unsigned)b_bytes; p.a_lo_off = (unsigned)x_lo_off;
+    p.b_brick = g_cfg.trunk_b_brick ? (unsigned)split3_rowmajor_bytes(d) : 0u;
     EpiParams& e = p.e;
     e.Y = y; e.ldy = d->ldy; e.M = p.M; e.Nstore = d->K; e.act = d->act;
     e.stats = stats; e.stats_ld = d->ldw; e.vec = 1;

@@ -51,6 +51,7 @@ struct IgemmParams {
     int Nld;    // NN: valid floats per B row (multiple of 4)
     unsigned a_bytes, b_bytes;  // extents for the buffer resource descriptors
     unsigned a_lo_off;          // split3p: byte distance from the hi plane to the lo plane of A
+    unsigned b_brick;           // split3p: byte offset of the weight image in LDS-tile order (0 = row-major planes only)
     // XCD-aware tile rasterisation (igemm_split3d_kernel, 1-D grid of ras_tiles_m * ras_tiles_n workgroups):
     // workgroup L runs on XCD L % 8; every XCD walks its own contiguous share of the tile order
     // (bands of ras_gm row tiles) x (groups of ras_gn column tiles) x (rows) x (columns), so the ~64 tiles

@@ -122,7 +122,11 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
     const int kc_sw = pch ^ (BK == 32 ? swz(prow) : (prow & 7));
     const int Ktot = p.ntaps * p.C;
     const int ohw = p.OH * p.OW;
-    const unsigned b_lo_off = (unsigned)((long)p.Nld * Ktot * 2);
+    // weight pieces: row-major planes (a lane's 16 bytes sit in row n, 2 Ktot bytes from the next row's), or - BK = 32,
+    // p.b_brick - the image in LDS-tile order, where piece (nt, q, plane, wave) is one contiguous KiB
+    const bool brick = BK == 32 && p.b_brick != 0;
+    const unsigned b_lo_off = brick ? 8192u : (unsigned)((long)p.Nld * Ktot * 2);
+    const unsigned b_kstep = brick ? 16384u : (unsigned)(BK * 2);
 
     const __amdgpu_buffer_rsrc_t rsA =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
@@ -154,7 +158,9 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
                 t.a_off[j] = 0;
             }
             const int n = t.nt * BN + row;
-            t.b_goff[j] = n < p.Nld ? (unsigned)(((long)n * Ktot + kc_sw * 8) * 2) : OOB;
+            t.b_goff[j] = brick ? p.b_brick + (unsigned)t.nt * (unsigned)(Ktot / 32) * 16384u + (unsigned)(wid + j * NW) * 1024u +
+                                      (unsigned)lane * 16u
+                          : n < p.Nld ? (unsigned)(((long)n * Ktot + kc_sw * 8) * 2) : OOB;
         }
         return t;
     };
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
         if (p.flip & 4) return;                    // ablation: no weight-tile requests
 #endif
         char* st = lds + slot * STAGE;
-        const unsigned kbyte = (unsigned)(kc.q * (BK * 2));
+        const unsigned kbyte = (unsigned)kc.q * b_kstep;
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
             const unsigned boff = t.b_goff[j] == OOB ? OOB : t.b_goff[j] + kbyte;

@@ -112,6 +112,8 @@ typedef struct AcimgConfig {
                                 double buffered in registers, requests spread between the MFMAs): 0 never, 1 where it was
                                 measured to pay, 2 always */
     int32_t trunk_ring_bm;   /* ring kernel's tile rows: 0 = per shape, else 128 or 256 (experiments) */
+    int32_t trunk_b_brick;   /* persistent kernel: weight tiles fetched from the image in LDS-tile order (one contiguous
+                                KiB = eight whole 128-byte lines per request instead of sixteen 64-byte row pieces) */
 } AcimgConfig;
 int acimg_config_default(AcimgConfig* cfg);
 int acimg_configure(const AcimgConfig* cfg);
