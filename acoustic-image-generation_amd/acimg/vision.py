@@ -28,6 +28,7 @@ BLOCKS = (("block1", 64, 3, 1), ("block2", 128, 4, 2), ("block3", 256, 6, 2), ("
 WEIGHT_DECAY = 5e-4   # resnet_arg_scope(weight_decay=5e-4), models/vision.py:54
 BN_DECAY = 0.997
 BN_EPS = 1e-5
+PLANE_SLACK = 2 * 15 * 2048 * 2 + 512   # a split-format plane ends on a whole 16-pixel brick: <= 15 pixels more, twice
 
 
 class ResNet50Model(object):
@@ -186,8 +187,8 @@ class ResNet50Model(object):
         if self._split:
             # split-format arenas (two fp16 planes per tensor = the bytes of the fp32 tensor)
             u8 = lambda n: torch.zeros(int(n), dtype=torch.uint8, device=sess.device)  # noqa: E731
-            self.planes_a, self.planes_b = u8(4 * mx_io + 512), u8(4 * mx_io + 512)
-            self.planes_1, self.planes_2 = u8(4 * mx_r1 + 512), u8(4 * mx_r2 + 512)
+            self.planes_a, self.planes_b = u8(4 * mx_io + PLANE_SLACK), u8(4 * mx_io + PLANE_SLACK)
+            self.planes_1, self.planes_2 = u8(4 * mx_r1 + PLANE_SLACK), u8(4 * mx_r2 + PLANE_SLACK)
             if self.stages == 2:
                 # stage 2's own arenas (sized for its units) and the tensor that crosses the stage boundary
                 hh, ww = ph, pw
@@ -201,9 +202,9 @@ class ResNet50Model(object):
                         r12, r22 = max(r12, N * hh * ww * db), max(r22, N * oh * ow * db)
                         r32, io2 = max(r32, N * oh * ow * d), max(io2, N * oh * ow * d)
                     hh, ww = oh, ow
-                self.planes_x = u8(4 * xb + 512)
-                self.planes_a2, self.planes_b2 = u8(4 * io2 + 512), u8(4 * io2 + 512)
-                self.planes_12, self.planes_22 = u8(4 * r12 + 512), u8(4 * r22 + 512)
+                self.planes_x = u8(4 * xb + PLANE_SLACK)
+                self.planes_a2, self.planes_b2 = u8(4 * io2 + PLANE_SLACK), u8(4 * io2 + PLANE_SLACK)
+                self.planes_12, self.planes_22 = u8(4 * r12 + PLANE_SLACK), u8(4 * r22 + PLANE_SLACK)
                 self.arena_r12, self.arena_r22 = z(r12), z(r22)
                 self.arena_r32, self.arena_sc2 = z(r32), z(r32)
         self.xfinal = z(N, h, w, 2048)          # block4 output, kept for the conv_map weight gradient
@@ -298,8 +299,9 @@ class ResNet50Model(object):
 
     @staticmethod
     def _lo_off(rows, c):
-        """byte offset of the lo plane of a [rows, c] split-format tensor"""
-        return -(-rows * c * 2 // 256) * 256
+        """byte offset of the lo plane of a [rows, c] split-format tensor = acimg_split_plane_bytes(rows, c): planes are
+        whole 16-pixel x 32-channel bricks (include/acimg.h, pre-split activation format)"""
+        return -(-rows // 16) * 16 * c * 2
 
     def _conv_bn_planes(self, plan, scope, xplanes, hw, cin, kh, kw, cout, stride, padding, out, training, side=False,
                         tag=""):

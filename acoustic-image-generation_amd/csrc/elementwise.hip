@@ -927,28 +927,52 @@ __global__ __launch_bounds__(256) void sqerr_channels_kernel(const float* a, con
 
 
 // ------------------------------------------------------------------------------------------
-// producers of the split-fp16 activation format (two fp16 planes [rows][ld], lo plane lo_off bytes after
-// the hi plane; values carry the 2^-2 scale) consumed by igemm_split3p_kernel
+// producers of the split-fp16 activation format consumed by the trunk kernels (igemm_split3d_kernel.hpp, "bricks"): two
+// fp16 planes, lo plane lo_off bytes after the hi plane, values carry the 2^-2 scale.  A plane of a [P pixels][C] tensor
+// (C % 32 == 0) is ceil(P / 16) x C / 32 bricks of 1 KiB: brick (f >> 4, c >> 5) holds 16 rows (f & 15) of 64 bytes, the
+// logical 16-byte chunk (c >> 3) & 3 of a row at physical chunk ((c >> 3) ^ swz(f)) & 3, swz(f) = -(f >> 2) & 3 - the LDS
+// image of 16 tile rows, so the consumer's LDS-DMA request is one contiguous KiB.
+// Work items (one float4 = 4 channels each) are enumerated in brick order: a wave covers 8 pixels x 32 channels, i.e. it
+// reads eight whole 128-byte lines of the fp32 source and writes 512 contiguous bytes (four whole lines) of each plane.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned plane_off(unsigned f, unsigned c, unsigned CQ) {      // c % 4 == 0
+    return ((f >> 4) * CQ + (c >> 5)) * 1024u + ((f & 15u) << 6) + ((((c >> 3) ^ (0u - (f >> 2))) & 3u) << 4) + ((c & 4u) << 1);
+}
+struct BrickItem {
+    unsigned pix, c, off;      // pixel, first of its 4 channels, byte offset inside a plane
+};
+__device__ __forceinline__ BrickItem brick_item(unsigned u, unsigned CQ, bool pow2, int sh) {
+    const unsigned l = u & 63u, hb = u >> 6;
+    const unsigned ph = pow2 ? hb >> sh : hb / CQ;
+    const unsigned cq = hb - ph * CQ;
+    BrickItem it;
+    it.pix = ph * 8u + (l >> 3);
+    it.c = cq * 32u + (l & 7u) * 4u;
+    it.off = plane_off(it.pix, it.c, CQ);
+    return it;
+}
+
 __global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* x, const float* scale, const float* shift,
-                                                            int relu, char* out, long lo_off, long total4, int C4) {
-    // 32-bit index arithmetic (tensors are < 2 GiB) and a mask for power-of-two channel counts: the 64-bit
-    // division this replaces was ~100 instructions per float4 of an HBM-bound pass
-    const bool pow2 = (C4 & (C4 - 1)) == 0;
-    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < (unsigned)total4; idx += gridDim.x * 256u) {
-        const int c = (int)(pow2 ? (idx & (unsigned)(C4 - 1)) : (idx % (unsigned)C4)) * 4;
-        float4 v = reinterpret_cast<const float4*>(x)[idx];
+                                                            int relu, char* out, long lo_off, unsigned items, unsigned P,
+                                                            int C) {
+    const unsigned CQ = (unsigned)C >> 5;
+    const bool pow2 = (CQ & (CQ - 1)) == 0;
+    const int sh = 31 - __builtin_clz(CQ);
+    for (unsigned u = blockIdx.x * 256u + threadIdx.x; u < items; u += gridDim.x * 256u) {
+        const BrickItem it = brick_item(u, CQ, pow2, sh);
+        if (it.pix >= P) continue;
+        float4 v = *reinterpret_cast<const float4*>(x + (long)it.pix * C + it.c);
         if (scale) {
-            const float4 s = *reinterpret_cast<const float4*>(scale + c);
-            const float4 t = *reinterpret_cast<const float4*>(shift + c);
+            const float4 s = *reinterpret_cast<const float4*>(scale + it.c);
+            const float4 t = *reinterpret_cast<const float4*>(shift + it.c);
             v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
         }
         if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         v.x *= SPLIT3_ASCALE; v.y *= SPLIT3_ASCALE; v.z *= SPLIT3_ASCALE; v.w *= SPLIT3_ASCALE;
         uint2 hi, lo;
         split4_scaled(v, hi, lo);
-        *reinterpret_cast<uint2*>(out + (long)idx * 8) = hi;
-        *reinterpret_cast<uint2*>(out + lo_off + (long)idx * 8) = lo;
+        *reinterpret_cast<uint2*>(out + it.off) = hi;
+        *reinterpret_cast<uint2*>(out + lo_off + it.off) = lo;
     }
 }
 
@@ -956,34 +980,34 @@ __global__ __launch_bounds__(256) void bn_relu_split_kernel(const float* x, cons
 // raw fp32) or the previous unit output read back from ITS split planes (identity, optional subsampling)
 __global__ __launch_bounds__(256) void bn_add_relu_split_kernel(
     const float* a, const float* sa, const float* ta, const float* b32, const float* sb, const float* tb,
-    const char* bsp, long b_lo_off, char* out, long out_lo_off, float* out32, long total4, int OH, int OW,
-    int C4, int BH, int BW, int bstride) {
-    const bool pow2 = (C4 & (C4 - 1)) == 0;
-    const int sh = 31 - __builtin_clz((unsigned)C4);
-    for (unsigned uidx = blockIdx.x * 256u + threadIdx.x; uidx < (unsigned)total4; uidx += gridDim.x * 256u) {
-        const long idx = uidx;
-        const int c4 = (int)(pow2 ? (uidx & (unsigned)(C4 - 1)) : (uidx % (unsigned)C4));
-        const long pix = pow2 ? (uidx >> sh) : (uidx / (unsigned)C4);
-        const int c = c4 * 4;
-        const float4 va = reinterpret_cast<const float4*>(a)[idx];
-        const float4 s = *reinterpret_cast<const float4*>(sa + c);
-        const float4 t = *reinterpret_cast<const float4*>(ta + c);
-        long bpix = pix;
+    const char* bsp, long b_lo_off, char* out, long out_lo_off, float* out32, unsigned items, unsigned P, int OH, int OW,
+    int C, int BH, int BW, int bstride) {
+    const unsigned CQ = (unsigned)C >> 5;
+    const bool pow2 = (CQ & (CQ - 1)) == 0;
+    const int sh = 31 - __builtin_clz(CQ);
+    for (unsigned u = blockIdx.x * 256u + threadIdx.x; u < items; u += gridDim.x * 256u) {
+        const BrickItem it = brick_item(u, CQ, pow2, sh);
+        if (it.pix >= P) continue;
+        const long idx = (long)it.pix * C + it.c;
+        const float4 va = *reinterpret_cast<const float4*>(a + idx);
+        const float4 s = *reinterpret_cast<const float4*>(sa + it.c);
+        const float4 t = *reinterpret_cast<const float4*>(ta + it.c);
+        unsigned bpix = it.pix;
         if (bstride != 1) {
-            const int ow = (int)(pix % OW);
-            const long t2 = pix / OW;
-            const int oh = (int)(t2 % OH);
-            const long n = t2 / OH;
-            bpix = (n * BH + (long)oh * bstride) * BW + (long)ow * bstride;
+            const unsigned ow = it.pix % (unsigned)OW;
+            const unsigned t2 = it.pix / (unsigned)OW;
+            const unsigned oh = t2 % (unsigned)OH;
+            const unsigned n = t2 / (unsigned)OH;
+            bpix = (n * (unsigned)BH + oh * (unsigned)bstride) * (unsigned)BW + ow * (unsigned)bstride;
         }
         float4 vb;
         if (b32) {
-            vb = *reinterpret_cast<const float4*>(b32 + bpix * (C4 * 4) + c);
-            const float4 s2 = *reinterpret_cast<const float4*>(sb + c);
-            const float4 t2 = *reinterpret_cast<const float4*>(tb + c);
+            vb = *reinterpret_cast<const float4*>(b32 + (long)bpix * C + it.c);
+            const float4 s2 = *reinterpret_cast<const float4*>(sb + it.c);
+            const float4 t2 = *reinterpret_cast<const float4*>(tb + it.c);
             vb.x = vb.x * s2.x + t2.x; vb.y = vb.y * s2.y + t2.y; vb.z = vb.z * s2.z + t2.z; vb.w = vb.w * s2.w + t2.w;
         } else {
-            const long e = (bpix * C4 + c4) * 8;
+            const unsigned e = bstride != 1 ? plane_off(bpix, it.c, CQ) : it.off;
             vb = unsplit4(*reinterpret_cast<const uint2*>(bsp + e), *reinterpret_cast<const uint2*>(bsp + b_lo_off + e),
                           1.f / SPLIT3_ASCALE);
         }
@@ -992,28 +1016,32 @@ __global__ __launch_bounds__(256) void bn_add_relu_split_kernel(
         o.y = fmaxf(va.y * s.y + t.y + vb.y, 0.f);
         o.z = fmaxf(va.z * s.z + t.z + vb.z, 0.f);
         o.w = fmaxf(va.w * s.w + t.w + vb.w, 0.f);
-        if (out32) reinterpret_cast<float4*>(out32)[idx] = o;
+        if (out32) *reinterpret_cast<float4*>(out32 + idx) = o;
         if (out) {
             o.x *= SPLIT3_ASCALE; o.y *= SPLIT3_ASCALE; o.z *= SPLIT3_ASCALE; o.w *= SPLIT3_ASCALE;
             uint2 hi, lo;
             split4_scaled(o, hi, lo);
-            *reinterpret_cast<uint2*>(out + idx * 8) = hi;
-            *reinterpret_cast<uint2*>(out + out_lo_off + idx * 8) = lo;
+            *reinterpret_cast<uint2*>(out + it.off) = hi;
+            *reinterpret_cast<uint2*>(out + out_lo_off + it.off) = lo;
         }
     }
 }
 
 __global__ __launch_bounds__(256) void bn_relu_maxpool_split_kernel(const float* x, const float* scale,
                                                                     const float* shift, char* out, long lo_off,
-                                                                    long total4, int H, int W, int C4, int OH,
+                                                                    unsigned items, unsigned P, int H, int W, int C, int OH,
                                                                     int OW, int pad_t, int pad_l) {
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (long)gridDim.x * 256) {
-        const int c = (int)(idx % C4) * 4;
-        long t = idx / C4;
-        const int ow = (int)(t % OW);
-        t /= OW;
-        const int oh = (int)(t % OH);
-        const long n = t / OH;
+    const unsigned CQ = (unsigned)C >> 5;
+    const bool pow2 = (CQ & (CQ - 1)) == 0;
+    const int shq = 31 - __builtin_clz(CQ);
+    for (unsigned u = blockIdx.x * 256u + threadIdx.x; u < items; u += gridDim.x * 256u) {
+        const BrickItem it = brick_item(u, CQ, pow2, shq);
+        if (it.pix >= P) continue;
+        const int c = (int)it.c;
+        const int ow = (int)(it.pix % (unsigned)OW);
+        const unsigned t = it.pix / (unsigned)OW;
+        const int oh = (int)(t % (unsigned)OH);
+        const long n = t / (unsigned)OH;
         const float4 s = *reinterpret_cast<const float4*>(scale + c);
         const float4 sh = *reinterpret_cast<const float4*>(shift + c);
         float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1025,7 +1053,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_split_kernel(const float*
             for (int q = 0; q < 3; ++q) {
                 const int iw = ow * 2 - pad_l + q;
                 if ((unsigned)iw >= (unsigned)W) continue;
-                const float4 v = *reinterpret_cast<const float4*>(x + ((n * H + ih) * W + iw) * (C4 * 4) + c);
+                const float4 v = *reinterpret_cast<const float4*>(x + ((n * H + ih) * W + iw) * C + c);
                 m.x = fmaxf(m.x, v.x * s.x + sh.x);
                 m.y = fmaxf(m.y, v.y * s.y + sh.y);
                 m.z = fmaxf(m.z, v.z * s.z + sh.z);
@@ -1035,8 +1063,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_split_kernel(const float*
         m.x *= SPLIT3_ASCALE; m.y *= SPLIT3_ASCALE; m.z *= SPLIT3_ASCALE; m.w *= SPLIT3_ASCALE;
         uint2 hi, lo;
         split4_scaled(m, hi, lo);
-        *reinterpret_cast<uint2*>(out + idx * 8) = hi;
-        *reinterpret_cast<uint2*>(out + lo_off + idx * 8) = lo;
+        *reinterpret_cast<uint2*>(out + it.off) = hi;
+        *reinterpret_cast<uint2*>(out + lo_off + it.off) = lo;
     }
 }
 
@@ -1380,14 +1408,23 @@ int acimg_sqerr_channels(const float* a, const float* b, long pixels, int C, flo
     return check_launch("sqerr_channels");
 }
 
+size_t acimg_split_plane_bytes(long rows, int C) { return (size_t)((rows + 15) / 16) * 16 * (size_t)C * 2; }
+
+// items of a [rows][C] tensor in brick order (8 pixels x 32 channels per wave), or 0 if it cannot be one
+static unsigned split_items(long rows, int C) {
+    if (rows <= 0 || C <= 0 || (C & 31)) return 0;
+    const long items = (rows + 7) / 8 * 8 * (C / 4);
+    return items < (1L << 30) ? (unsigned)items : 0u;
+}
+
 int acimg_bn_relu_split(const float* x, const float* scale, const float* shift, int relu, void* out,
                         size_t lo_off, long rows, int C, void* stream) {
-    if ((C & 3) || (lo_off & 7) || !aligned16(x) || !aligned16(out))
-        return fail(ACIMG_EINVAL, "bn_relu_split: C must be a multiple of 4, buffers aligned");
-    const long total4 = rows * (C / 4);
-    if (total4 >= (1L << 30)) return fail(ACIMG_EINVAL, "bn_relu_split: tensor exceeds 2^32 elements");
-    hipLaunchKernelGGL(bn_relu_split_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, scale,
-                       shift, relu, static_cast<char*>(out), (long)lo_off, total4, C / 4);
+    const unsigned items = split_items(rows, C);
+    if (!items || (lo_off & 15) || lo_off < acimg_split_plane_bytes(rows, C) || !aligned16(x) || !aligned16(out))
+        return fail(ACIMG_EINVAL, "bn_relu_split: C must be a multiple of 32, at most 2^32 elements, buffers aligned, "
+                                  "lo_off >= acimg_split_plane_bytes(rows, C)");
+    hipLaunchKernelGGL(bn_relu_split_kernel, dim3(ew_grid(items)), dim3(256), 0, (hipStream_t)stream, x, scale,
+                       shift, relu, static_cast<char*>(out), (long)lo_off, items, (unsigned)rows, C);
     return check_launch("bn_relu_split");
 }
 
@@ -1395,18 +1432,22 @@ int acimg_bn_add_relu_split(const float* a, const float* sa, const float* ta, co
                             const float* sb, const float* tb, const void* b_planes, size_t b_lo_off,
                             void* out_planes, size_t out_lo_off, float* out32, int N, int OH, int OW, int C,
                             int BH, int BW, int bstride, void* stream) {
-    if (C & 3) return fail(ACIMG_EINVAL, "bn_add_relu_split: C must be a multiple of 4");
+    const long rows = (long)N * OH * OW;
+    const unsigned items = split_items(rows, C);
+    if (!items) return fail(ACIMG_EINVAL, "bn_add_relu_split: C must be a multiple of 32, at most 2^32 elements");
     if ((b32 == nullptr) == (b_planes == nullptr))
         return fail(ACIMG_EINVAL, "bn_add_relu_split: exactly one of b32 / b_planes");
     if (b32 && (!sb || !tb)) return fail(ACIMG_EINVAL, "bn_add_relu_split: projection shortcut needs scale/shift");
-    const long total4 = (long)N * OH * OW * (C / 4);
+    if (out_planes && out_lo_off < acimg_split_plane_bytes(rows, C))
+        return fail(ACIMG_EINVAL, "bn_add_relu_split: out_lo_off < acimg_split_plane_bytes(rows, C)");
+    if (b_planes && b_lo_off < acimg_split_plane_bytes((long)N * BH * BW, C))
+        return fail(ACIMG_EINVAL, "bn_add_relu_split: b_lo_off < acimg_split_plane_bytes of the shortcut tensor");
     // one float4 per thread (no grid-stride loop): measured 4 % faster than 4096 persistent workgroups on this
     // three-stream pass (16 M float4 at the 56x75x512 stage)
-    if (total4 >= (1L << 30)) return fail(ACIMG_EINVAL, "bn_add_relu_split: tensor exceeds 2^32 elements");
-    const long nblk = (total4 + 255) / 256;
+    const long nblk = ((long)items + 255) / 256;
     hipLaunchKernelGGL(bn_add_relu_split_kernel, dim3((unsigned)(nblk < (1L << 22) ? nblk : (1L << 22))), dim3(256), 0, (hipStream_t)stream, a, sa,
                        ta, b32, sb, tb, static_cast<const char*>(b_planes), (long)b_lo_off,
-                       static_cast<char*>(out_planes), (long)out_lo_off, out32, total4, OH, OW, C / 4, BH, BW,
+                       static_cast<char*>(out_planes), (long)out_lo_off, out32, items, (unsigned)rows, OH, OW, C, BH, BW,
                        bstride);
     return check_launch("bn_add_relu_split");
 }
@@ -1414,10 +1455,12 @@ int acimg_bn_add_relu_split(const float* a, const float* sa, const float* ta, co
 int acimg_bn_relu_maxpool_split(const float* x, const float* scale, const float* shift, void* out,
                                 size_t lo_off, int N, int H, int W, int C, int OH, int OW, int pad_t, int pad_l,
                                 void* stream) {
-    if (C & 3) return fail(ACIMG_EINVAL, "bn_relu_maxpool_split: C must be a multiple of 4");
-    const long total4 = (long)N * OH * OW * (C / 4);
-    hipLaunchKernelGGL(bn_relu_maxpool_split_kernel, dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x,
-                       scale, shift, static_cast<char*>(out), (long)lo_off, total4, H, W, C / 4, OH, OW, pad_t,
+    const long rows = (long)N * OH * OW;
+    const unsigned items = split_items(rows, C);
+    if (!items || lo_off < acimg_split_plane_bytes(rows, C))
+        return fail(ACIMG_EINVAL, "bn_relu_maxpool_split: C must be a multiple of 32, lo_off >= acimg_split_plane_bytes");
+    hipLaunchKernelGGL(bn_relu_maxpool_split_kernel, dim3(ew_grid(items)), dim3(256), 0, (hipStream_t)stream, x,
+                       scale, shift, static_cast<char*>(out), (long)lo_off, items, (unsigned)rows, H, W, C, OH, OW, pad_t,
                        pad_l);
     return check_launch("bn_relu_maxpool_split");
 }

@@ -16,7 +16,6 @@
 #include "igemm_split3d_kernel.hpp"
 #include "igemm_split3dp_kernel.hpp"
 #include "igemm_split3r_kernel.hpp"
-#include "igemm_split3r2_kernel.hpp"
 #include <cstdlib>
 #include <algorithm>
 
@@ -1190,7 +1189,7 @@ int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
 
 int acimg_config_default(AcimgConfig* c) {
     if (!c) return fail(ACIMG_EINVAL, "config_default: null");
-    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0};
+    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0};
     return ACIMG_OK;
 }
 
@@ -1201,12 +1200,11 @@ int acimg_configure(const AcimgConfig* c) {
     if (c->trunk_persistent < 0 || c->trunk_persistent > 2) return fail(ACIMG_EINVAL, "configure: trunk_persistent is 0, 1 or 2");
     if (c->trunk_dma_pos < 0 || c->trunk_dma_pos > 1) return fail(ACIMG_EINVAL, "configure: trunk_dma_pos is 0 or 1");
     if (c->trunk_stagger < 0 || c->trunk_stagger > 100) return fail(ACIMG_EINVAL, "configure: trunk_stagger is a percentage");
-    if (c->trunk_bk != 0 && c->trunk_bk != 32 && c->trunk_bk != 64)
-        return fail(ACIMG_EINVAL, "configure: trunk_bk must be 0 (per layer), 32 or 64");
-    if (c->trunk_ring < 0 || c->trunk_ring > 4) return fail(ACIMG_EINVAL, "configure: trunk_ring is 0 .. 4");
+    if (c->trunk_bk != 0 && c->trunk_bk != 32)
+        return fail(ACIMG_EINVAL, "configure: trunk_bk must be 0 or 32 (the 64-deep K step was measured slower and removed)");
+    if (c->trunk_ring < 0 || c->trunk_ring > 2) return fail(ACIMG_EINVAL, "configure: trunk_ring is 0, 1 or 2");
     if (c->trunk_ring_bm != 0 && c->trunk_ring_bm != 128 && c->trunk_ring_bm != 256)
         return fail(ACIMG_EINVAL, "configure: trunk_ring_bm must be 0 (per shape), 128 or 256");
-    if (c->trunk_b_brick < 0 || c->trunk_b_brick > 1) return fail(ACIMG_EINVAL, "configure: trunk_b_brick is 0 or 1");
     if (c->split3_tile_bm || c->split3_tile_bn) {
         const int bm = c->split3_tile_bm, bn = c->split3_tile_bn;
         if (!((bm == 128 && bn == 128) || (bm == 64 && bn == 128) || (bm == 128 && bn == 64)))
@@ -1528,21 +1526,10 @@ static int ring_rows(const AcimgConvDesc* d, int terms) {
     if (c.bm != 128 || c.bn != 128) return 0;
     const long t128 = (long)cdiv(M, 128) * cdiv(d->K, 128);
     const int kiters = d->R * d->S * (d->C / 32);
-    if (g_cfg.trunk_ring == 1 || g_cfg.trunk_ring == 4) return (t128 > 256 && t128 <= 300 && kiters >= 64) ? 128 : 0;
-    if (g_cfg.trunk_ring == 3) return 0;
+    if (g_cfg.trunk_ring == 1) return (t128 > 256 && t128 <= 300 && kiters >= 64) ? 128 : 0;
     if (g_cfg.trunk_ring_bm) return g_cfg.trunk_ring_bm;
     const long t256 = (long)cdiv(M, 256) * cdiv(d->K, 128);
     return t256 >= 500 ? 256 : 128;
-}
-
-// Two-slot ring kernel (igemm_split3r2_kernel.hpp: 128x128 tiles, two workgroups per CU): trunk_ring 3 = every 128x128
-// shape, 4 = every 128x128 shape the ring kernel's rule does not take
-static bool use_ring2(const AcimgConvDesc* d, int terms) {
-    if (g_cfg.trunk_ring < 3 || terms != 3) return false;
-    const int M = d->N * d->OH * d->OW;
-    if ((long)M * d->ldy * 4 >= (1L << 31)) return false;
-    const Split3Cfg c = pick_split3(M, d->K);
-    return c.bm == 128 && c.bn == 128;
 }
 
 int acimg_conv2d_fwd_split3p_stats_rows(const AcimgConvDesc* d) {
@@ -1561,8 +1548,6 @@ int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out) {
     if (const int rr = ring_rows(d, 3)) {      // the ring kernel: its row tile, flag 2
         out[0] = rr;
         out[2] = 2;
-    } else if (use_ring2(d, 3)) {
-        out[2] = 3;                            // the two-slot ring kernel
     }
     return ACIMG_OK;
 }
@@ -1858,9 +1843,9 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
     int rc = check_desc(d, "conv2d_fwd_split3p");
     if (rc) return rc;
     if (d->C % 32) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: C=%d must be a multiple of 32", d->C);
-    if (d->ldw < d->K || !aligned16(x_planes) || !aligned16(wsplit) || !aligned16(y) || (d->ldy & 3) || (d->ldx & 7) ||
+    if (d->ldw < d->K || !aligned16(x_planes) || !aligned16(wsplit) || !aligned16(y) || (d->ldy & 3) || d->ldx != d->C ||
         (x_lo_off & 15))
-        return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: ldw<K or unaligned operands");
+        return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: ldw<K, ldx != C (split-format tensors are dense) or unaligned operands");
     IgemmParams p{};
     p.A = static_cast<const float*>(x_planes); p.H = d->H; p.W = d->W; p.C = d->C; p.lda = d->ldx;
     p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride;
@@ -1870,13 +1855,13 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
     p.ntaps = d->R * d->S;
     p.kiters = p.ntaps * (d->C / 32);
     p.splits = 1;
-    const long plane = (((long)d->N * d->H * d->W - 1) * d->ldx + d->C) * 2;
+    const long plane = (long)acimg_split_plane_bytes((long)d->N * d->H * d->W, d->C);
     const long a_bytes = (long)x_lo_off + plane;
     const long b_bytes = (long)acimg_conv2d_split3_weight_bytes(d);
     if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31) || (long)x_lo_off < plane)
         return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: operand >= 2 GiB or overlapping planes");
     p.a_bytes = (unsigned)a_bytes; p.b_bytes = (unsigned)b_bytes; p.a_lo_off = (unsigned)x_lo_off;
-    p.b_brick = g_cfg.trunk_b_brick ? (unsigned)split3_rowmajor_bytes(d) : 0u;
+    p.b_brick = (unsigned)split3_rowmajor_bytes(d);
     EpiParams& e = p.e;
     e.Y = y; e.ldy = d->ldy; e.M = p.M; e.Nstore = d->K; e.act = d->act;
     e.stats = stats; e.stats_ld = d->ldw; e.vec = 1;
@@ -1928,38 +1913,12 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
         else hipLaunchKernelGGL((igemm_split3r_kernel<2>), dim3(nwg), dim3(512), lds_r, st, p, units, nwg);
         return check_launch("conv2d_fwd_split3p (ring)");
     }
-    if (use_ring2(d, terms)) {
-        const size_t lds_2 = (size_t)2 * 4 * 128 * 64 + 8 * 1024 + 2 * 2 * 128 * 4;
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)igemm_split3r2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_2);
-            attr2 = true;
-        }
-        const int P2 = resident_slots(7, (const void*)igemm_split3r2_kernel, 512, lds_2);
-        TailPlan t2{T, 1, 0};
-        if (ws && ws_bytes >= acimg_conv2d_fwd_split3p_workspace(d)) t2 = pick_tail(T, P2, p.kiters, TS_MAX_UNITS);
-        p.ts_whole = t2.whole; p.ts_s = t2.s;
-        p.ts_counters = static_cast<int*>(ws);
-        p.ts_partial = ws ? reinterpret_cast<float*>(static_cast<char*>(ws) + TS_COUNTER_BYTES) : nullptr;
-        const int units = t2.whole + t2.rem * t2.s;
-        const int nwg = std::min(units, P2);
-#if defined(ACIMG_STAMP) || defined(ACIMG_ABLATE)
-        p.slab = g_stamp_buf;
-        p.flip = g_stamp_nostore;
-#endif
-        hipLaunchKernelGGL(igemm_split3r2_kernel, dim3(nwg), dim3(512), lds_2, st, p, units, nwg);
-        return check_launch("conv2d_fwd_split3p (ring2)");
-    }
     const bool persistent = !big_out && split3p_persistent(c, T);
-    // K-step depth of the persistent kernel: 32 = the one-tile kernel's image (2 workgroups / CU); 64 = full 128-byte
-    // operand lines per DMA request, 1 workgroup / CU (measured slower on every trunk shape: experiments only)
-    const int bk = persistent && g_cfg.trunk_bk && terms == 3 ? g_cfg.trunk_bk : 32;
-    if (persistent && bk == 64 && d->C % 64) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: trunk_bk 64 needs C %% 64 == 0");
-    p.kiters = p.ntaps * (d->C / bk);
-    const size_t lds_p = (size_t)2 * 4 * 128 * (bk * 2) + 4 * 2 * 128 * 4;    // 2 stages + statistics scratch
+    // (a 64-deep K step - whole 128-byte operand rows, one workgroup per CU - was measured slower on every trunk shape in
+    //  round 2 and removed when the operands moved to LDS-tile order, which gives whole-line requests at two per CU)
+    const size_t lds_p = (size_t)2 * 4 * 128 * 64 + 4 * 2 * 128 * 4;    // 2 stages + statistics scratch
     TailPlan tp{T, 1, 0};
     const int P = !persistent ? resident_slots(which, fn, which == 0 ? 512 : 256, lds_bytes)
-                  : bk == 64  ? resident_slots(4, (const void*)igemm_split3dp_kernel<64, 0>, 512, lds_p)
                               : resident_slots(3, (const void*)igemm_split3dp_kernel<32, 0>, 512, lds_p);
     if (ws && ws_bytes >= acimg_conv2d_fwd_split3p_workspace(d) && which == 0)
         tp = pick_tail(T, P, p.kiters, TS_MAX_UNITS);
@@ -1973,20 +1932,12 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
     p.flip = g_stamp_nostore;
 #endif
     if (persistent) {
-        p.splits = g_cfg.trunk_stagger > 0 ? g_cfg.trunk_stagger * (p.kiters * (bk == 64 ? 3400 : 2500) + 8000) / 100 : 1;
+        p.splits = g_cfg.trunk_stagger > 0 ? g_cfg.trunk_stagger * (p.kiters * 2500 + 8000) / 100 : 1;
         // a workgroup per resident slot walks units blockIdx.x, blockIdx.x + P, ...: whole tiles first (with the
         // next tile's first operand stage and addresses prepared under the current tile's last K step and output
         // stores), then the K ranges of the tail tiles
         const int nwg = std::min(n_units, P);
-        if (bk == 64) {
-            static bool attr = false;    // > 64 KiB of dynamic LDS needs the opt-in once per process
-            if (!attr) {
-                (void)hipFuncSetAttribute((const void*)igemm_split3dp_kernel<64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds_p);
-                attr = true;
-            }
-            hipLaunchKernelGGL((igemm_split3dp_kernel<64, 0>), dim3(nwg), dim3(512), lds_p, st, p, n_units, nwg);
-        } else if (terms == 1) {
+        if (terms == 1) {
             hipLaunchKernelGGL((igemm_split3dp_kernel<32, 0, 1>), dim3(nwg), dim3(512), lds_p, st, p, n_units, nwg);
         } else if (g_cfg.trunk_dma_pos == 1) {
             hipLaunchKernelGGL((igemm_split3dp_kernel<32, 1>), dim3(nwg), dim3(512), lds_p, st, p, n_units, nwg);

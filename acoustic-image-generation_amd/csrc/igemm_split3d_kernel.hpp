@@ -1,8 +1,8 @@
 // f16x3 forward convolution on PRE-SPLIT activations with LDS-DMA operand staging (gfx950): the trunk kernel.
 //
-// A is stored in HBM as two fp16 planes [pixel][lda] (hi at p.A, lo p.a_lo_off bytes further; values already
-// carry the 2^-2 scale and any BN affine + ReLU, written by the elementwise producers in elementwise.hip), B is
-// the split + transposed weight image of `split3_prepare_kernel`.  Same GEMM core, LDS image (64-byte rows,
+// A is stored in HBM as two fp16 planes of 16-pixel x 32-channel bricks (hi at p.A, lo p.a_lo_off bytes further; values
+// already carry the 2^-2 scale and any BN affine + ReLU, written by the elementwise producers in elementwise.hip), B is
+// the tile-ordered weight image behind the row-major planes of `split3_prepare_kernel` (see "bricks" below).  Same GEMM core, LDS image (64-byte rows,
 // chunk ^ swz(row)) and epilogue as `igemm_split3_kernel`, but neither operand tile passes through VGPRs:
 // every wave copies 1-KiB pieces (16 tile rows of one fp16 plane) global -> LDS with
 // `buffer_load_dwordx4 ... lds`.  That removes the ds_write_b128 pass (13 store-path cycles per
@@ -28,6 +28,27 @@
 namespace acimg {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// ---- operands in LDS-TILE ORDER ("bricks") --------------------------------------------------------------------------
+// A request of the LDS-DMA path is 64 lanes x 16 bytes = 16 tile rows of 64 bytes.  With row-major operands those are
+// sixteen 64-byte pieces of sixteen different rows (half a cache line each, a row pitch apart), and the K loop waits at
+// the CU's texture addresser for them (profiles/r02 ablation: no weight requests -29 %, no activation requests -21 % on a
+// long-K layer; BK = 64 "whole lines" showed 1.7x less issue stall per byte but cost the second workgroup per CU).  Both
+// operands are therefore kept in HBM the way the LDS holds them:
+//   * activations: a split-format tensor [P pixels][C] (C % 32 == 0) is two planes of BRICKS; brick (pixel block
+//     f >> 4, channel chunk c >> 5) is 1 KiB at ((f >> 4) * C / 32 + (c >> 5)) * 1024: 16 rows (f & 15) of 64 bytes, logical
+//     16-byte chunk kc of a row at physical chunk kc ^ swz(f).  A 1x1 / stride-1 piece is one contiguous KiB (eight whole
+//     128-byte lines); a shifted (3x3 tap) or strided piece is still a per-lane gather, now out of one or two bricks;
+//   * weights: behind the row-major planes, for every (128-column tile n >> 7, K step q) the two 8 KiB plane images
+//     [row n & 127][64 B] with the same chunk swizzle (acimg_conv2d_split3_prepare writes both forms).
+__device__ __forceinline__ unsigned brick_a_off(unsigned f, unsigned c32, unsigned kc) {
+    // byte offset of logical chunk kc of pixel f's row in channel chunk 0; c32 = C * 32 = bytes of one pixel block
+    return (f >> 4) * c32 + ((f & 15u) << 6) + (((kc ^ (0u - (f >> 2))) & 3u) << 4);
+}
+__device__ __forceinline__ unsigned brick_b_off(unsigned n, unsigned ksteps, unsigned pch) {
+    // byte offset (hi plane, K step 0) of physical chunk pch of weight row n; + 16384 per K step, + 8192 for the lo plane
+    return (n >> 7) * ksteps * 16384u + ((n & 127u) << 6) + (pch << 4);
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -120,13 +141,14 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
 
     // ---- this lane's slot in a piece: tile row (lane>>2) of the 16-row block, physical chunk (lane&3) -------
     const int prow = lane >> 2, pch = lane & 3;
-    int a_off[RA], a_ih0[RA], a_iw0[RA];
+    const unsigned kc_sw = (unsigned)(pch ^ swz(prow));      // the logical k chunk this lane's LDS slot holds
+    const unsigned c32 = (unsigned)p.C * 32u;
+    int a_f0[RA], a_ih0[RA], a_iw0[RA];                      // pixel index / row / column of tap (0, 0)
     {
         const int ohw = p.OH * p.OW;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int row = (wid + j * NW) * 16 + prow;
-            const int kc = pch ^ swz(row);
             const int m = m0 + row;
             if (m < p.M) {
                 const int img = m / ohw;
@@ -135,11 +157,11 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
                 const int ow = r2 - oh * p.OW;
                 a_ih0[j] = oh * p.stride - p.pad_t;
                 a_iw0[j] = ow * p.stride - p.pad_l;
-                a_off[j] = ((img * p.H + a_ih0[j]) * p.W + a_iw0[j]) * p.lda * 2 + kc * 16;
+                a_f0[j] = (img * p.H + a_ih0[j]) * p.W + a_iw0[j];
             } else {
                 a_ih0[j] = -(1 << 28);
                 a_iw0[j] = -(1 << 28);
-                a_off[j] = 0;
+                a_f0[j] = 0;
             }
         }
     }
@@ -147,11 +169,9 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         const int row = (wid + j * NW) * 16 + prow;
-        const int kc = pch ^ swz(row);
-        const int n = n0 + row;
-        b_goff[j] = n < p.Nld ? (unsigned)(((long)n * Ktot + kc * 8) * 2) : OOB;
+        b_goff[j] = p.b_brick + brick_b_off((unsigned)(n0 + row), (unsigned)(Ktot / BK), (unsigned)pch);
     }
-    const unsigned b_lo_off = (unsigned)((long)p.Nld * Ktot * 2);
+    constexpr unsigned b_lo_off = 8192u;
 
     // request cursors: A walks (tap row, tap column, channel chunk); B's k offset is linear in the step
     int qa = it_begin, sa = 0, st_r = 0, st_s = 0, st_c0 = 0;     // next A tile to request, its LDS slot
@@ -166,12 +186,13 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
 
     auto issue_a = [&]() {
         char* st = lds + sa * (2 * A_BYTES);
-        const int tapoff = ((st_r * p.W + st_s) * p.lda + st_c0) * 2;
+        const int tapf = st_r * p.W + st_s;
+        const unsigned cbyte = (unsigned)st_c0 * 32u;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int ih = a_ih0[j] + st_r, iw = a_iw0[j] + st_s;
             const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const unsigned off = ok ? (unsigned)(a_off[j] + tapoff) : OOB;
+            const unsigned off = ok ? brick_a_off((unsigned)(a_f0[j] + tapf), c32, kc_sw) + cbyte : OOB;
             char* dst = st + (wid + j * NW) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)dst, 16, off, 0, 0, 0);
             if (TERMS == 3)
@@ -190,10 +211,10 @@ __global__ __launch_bounds__(NTHR) void igemm_split3d_kernel(const IgemmParams p
     };
     auto issue_b = [&]() {
         char* st = lds + B_BASE + sb * (2 * B_BYTES);
-        const unsigned kbyte = (unsigned)(qb * (BK * 2));
+        const unsigned kbyte = (unsigned)qb * 16384u;
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            const unsigned off = b_goff[j] == OOB ? OOB : b_goff[j] + kbyte;
+            const unsigned off = b_goff[j] + kbyte;
             char* dst = st + (wid + j * NW) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)dst, 16, off, 0, 0, 0);
             if (TERMS == 3)

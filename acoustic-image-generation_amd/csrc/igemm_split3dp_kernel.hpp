@@ -53,8 +53,8 @@ namespace acimg {
 template <int PP>
 struct TileAddrP {
     int mt, nt;
-    int a_off[PP], a_ih0[PP], a_iw0[PP];   // this lane's row of each of the wave's A pieces
-    unsigned b_goff[PP];                   // this lane's row of each B piece, byte offset at k = 0 (or OOB)
+    int a_f0[PP], a_ih0[PP], a_iw0[PP];    // this lane's row of each of the wave's A pieces: pixel index / row / column at tap (0, 0)
+    unsigned b_goff[PP];                   // this lane's row of each B piece, byte offset at K step 0
 };
 
 struct KCursorP {
@@ -122,11 +122,11 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
     const int kc_sw = pch ^ (BK == 32 ? swz(prow) : (prow & 7));
     const int Ktot = p.ntaps * p.C;
     const int ohw = p.OH * p.OW;
-    // weight pieces: row-major planes (a lane's 16 bytes sit in row n, 2 Ktot bytes from the next row's), or - BK = 32,
-    // p.b_brick - the image in LDS-tile order, where piece (nt, q, plane, wave) is one contiguous KiB
-    const bool brick = BK == 32 && p.b_brick != 0;
-    const unsigned b_lo_off = brick ? 8192u : (unsigned)((long)p.Nld * Ktot * 2);
-    const unsigned b_kstep = brick ? 16384u : (unsigned)(BK * 2);
+    // both operands come in LDS-tile order (igemm_split3d_kernel.hpp, "bricks"): a weight piece (nt, q, plane, wave) is one
+    // contiguous KiB, an activation piece one (1x1) or parts of two (shifted taps) KiB bricks
+    static_assert(BK == 32, "the brick layouts are the BK = 32 LDS image");
+    constexpr unsigned b_lo_off = 8192u, b_kstep = 16384u;
+    const unsigned c32 = (unsigned)p.C * 32u;
 
     const __amdgpu_buffer_rsrc_t rsA =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
@@ -151,16 +151,13 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
                 const int ow = r2 - oh * p.OW;
                 t.a_ih0[j] = oh * p.stride - p.pad_t;
                 t.a_iw0[j] = ow * p.stride - p.pad_l;
-                t.a_off[j] = ((img * p.H + t.a_ih0[j]) * p.W + t.a_iw0[j]) * p.lda * 2 + kc_sw * 16;
+                t.a_f0[j] = (img * p.H + t.a_ih0[j]) * p.W + t.a_iw0[j];
             } else {
                 t.a_ih0[j] = -(1 << 28);
                 t.a_iw0[j] = -(1 << 28);
-                t.a_off[j] = 0;
+                t.a_f0[j] = 0;
             }
-            const int n = t.nt * BN + row;
-            t.b_goff[j] = brick ? p.b_brick + (unsigned)t.nt * (unsigned)(Ktot / 32) * 16384u + (unsigned)(wid + j * NW) * 1024u +
-                                      (unsigned)lane * 16u
-                          : n < p.Nld ? (unsigned)(((long)n * Ktot + kc_sw * 8) * 2) : OOB;
+            t.b_goff[j] = p.b_brick + brick_b_off((unsigned)(t.nt * BN + row), (unsigned)(Ktot / BK), (unsigned)pch);
         }
         return t;
     };
@@ -176,7 +173,7 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
         const unsigned kbyte = (unsigned)kc.q * b_kstep;
 #pragma unroll
         for (int j = 0; j < PP; ++j) {
-            const unsigned boff = t.b_goff[j] == OOB ? OOB : t.b_goff[j] + kbyte;
+            const unsigned boff = t.b_goff[j] + kbyte;
             char* dst = st + 2 * PLANE + (wid + j * NW) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)dst, 16, boff, 0, 0, 0);
             if (TERMS == 3)
@@ -185,7 +182,8 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
     };
     auto issue_a = [&](const Tile& t, int slot) {      // ... and moves the cursor on
         char* st = lds + slot * STAGE;
-        const int tapoff = ((kc.r * p.W + kc.s) * p.lda + kc.c0) * 2;
+        const int tapf = kc.r * p.W + kc.s;
+        const unsigned cbyte = (unsigned)kc.c0 * 32u;
 #ifdef ACIMG_ABLATE
         if (p.flip & 2) {                          // ablation: no activation-tile requests
             kc = kcursor_next<BK>(kc, p.C, p.S);
@@ -196,7 +194,7 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
         for (int j = 0; j < PP; ++j) {
             const int ih = t.a_ih0[j] + kc.r, iw = t.a_iw0[j] + kc.s;
             const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const unsigned aoff = ok ? (unsigned)(t.a_off[j] + tapoff) : OOB;
+            const unsigned aoff = ok ? brick_a_off((unsigned)(t.a_f0[j] + tapf), c32, (unsigned)kc_sw) + cbyte : OOB;
             char* dst = st + (wid + j * NW) * 1024;
             // (fetching the activation tiles with the non-temporal policy, to keep the weight tiles in the XCD's L2,
             //  was measured: 25 % slower - the column tiles of an XCD share A through that L2;

@@ -33,8 +33,8 @@ namespace acimg {
 
 template <int RA>
 struct TileAddrR {
-    int a_off[RA], a_ih0[RA], a_iw0[RA];   // this lane's row of each of the wave's A pieces
-    unsigned b_goff;                       // this lane's row of the wave's B piece, byte offset at k = 0 (or OOB)
+    int a_f0[RA], a_ih0[RA], a_iw0[RA];    // this lane's row of each of the wave's A pieces: pixel index / row / column at tap (0, 0)
+    unsigned b_goff;                       // this lane's row of the wave's B piece, byte offset at K step 0
 };
 
 // s_waitcnt through the builtin, so that the compiler's own counter bookkeeping sees it (an `asm volatile` wait is opaque:
@@ -75,7 +75,8 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
     const int kc_sw = pch ^ swz(prow);               // logical k chunk it fetches (pieces start at multiples of 16 rows)
     const int Ktot = p.ntaps * p.C;
     const int ohw = p.OH * p.OW;
-    const unsigned b_lo_off = (unsigned)((long)p.Nld * Ktot * 2);
+    constexpr unsigned b_lo_off = 8192u;             // operands in LDS-tile order (igemm_split3d_kernel.hpp, "bricks")
+    const unsigned c32 = (unsigned)p.C * 32u;
     const EpiParams& e = p.e;
 
     const __amdgpu_buffer_rsrc_t rsA =
@@ -128,15 +129,14 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
                 const int ow = r2 - oh * p.OW;
                 lt.a_ih0[j] = oh * p.stride - p.pad_t;
                 lt.a_iw0[j] = ow * p.stride - p.pad_l;
-                lt.a_off[j] = ((img * p.H + lt.a_ih0[j]) * p.W + lt.a_iw0[j]) * p.lda * 2 + kc_sw * 16;
+                lt.a_f0[j] = (img * p.H + lt.a_ih0[j]) * p.W + lt.a_iw0[j];
             } else {
                 lt.a_ih0[j] = -(1 << 28);
                 lt.a_iw0[j] = -(1 << 28);
-                lt.a_off[j] = 0;
+                lt.a_f0[j] = 0;
             }
         }
-        const int n = nt_ * BN + wid * 16 + prow;
-        lt.b_goff = n < p.Nld ? (unsigned)(((long)n * Ktot + kc_sw * 8) * 2) : OOB;
+        lt.b_goff = p.b_brick + brick_b_off((unsigned)(nt_ * BN + wid * 16 + prow), (unsigned)(Ktot / BK), (unsigned)pch);
     };
     // the loader moves to a unit: `first` = this workgroup's first one, else the next of its list (the caller checked
     // that there is one); the tile's addresses are integer divisions: once per unit, between two groups of MFMAs
@@ -154,14 +154,15 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
     };
     // describe the next stage in descriptor set `ds` and move the cursor on (needs loader_more())
     auto begin_stage = [&](const int ds) __attribute__((always_inline)) {
-        const int tapoff = ((lkc.r * p.W + lkc.s) * p.lda + lkc.c0) * 2;
+        const int tapf = lkc.r * p.W + lkc.s;
+        const unsigned cbyte = (unsigned)lkc.c0 * 32u;
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int ih = lt.a_ih0[j] + lkc.r, iw = lt.a_iw0[j] + lkc.s;
             const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            st_aoff[ds][j] = ok ? (unsigned)(lt.a_off[j] + tapoff) : OOB;
+            st_aoff[ds][j] = ok ? brick_a_off((unsigned)(lt.a_f0[j] + tapf), c32, (unsigned)kc_sw) + cbyte : OOB;
         }
-        st_boff[ds] = lt.b_goff == OOB ? OOB : lt.b_goff + (unsigned)(lkc.q * (BK * 2));
+        st_boff[ds] = lt.b_goff + (unsigned)lkc.q * 16384u;
         st_base[ds] = l_slot * SLOT;
         lkc = kcursor_next<BK>(lkc, p.C, p.S);
         ++l_k;
@@ -172,11 +173,13 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
     // by its argument, right before the request that needs its result, so that these few instructions sit BETWEEN
     // matrix instructions (a wave's serial chain of scalar / vector instructions is what a K step of this kernel waits
     // for: ~125 of them in one block cost more than the 48 MFMAs)
-    int fs_tapoff = 0;
+    int fs_tapf = 0;
+    unsigned fs_cbyte = 0;
     auto begin_stage_part = [&](const int G) __attribute__((always_inline)) {
         if (G == 0) {                       // B offset, slot (requests 0, 1)
-            fs_tapoff = ((lkc.r * p.W + lkc.s) * p.lda + lkc.c0) * 2;
-            st_boff[0] = lt.b_goff == OOB ? OOB : lt.b_goff + (unsigned)(lkc.q * (BK * 2));
+            fs_tapf = lkc.r * p.W + lkc.s;
+            fs_cbyte = (unsigned)lkc.c0 * 32u;
+            st_boff[0] = lt.b_goff + (unsigned)lkc.q * 16384u;
             st_base[0] = l_slot * SLOT;
             l_slot = l_slot == 2 ? 0 : l_slot + 1;
         }
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
             if (G == GA + 4 * j) {
                 const int ih = lt.a_ih0[j] + lkc.r, iw = lt.a_iw0[j] + lkc.s;
                 const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                st_aoff[0][j] = ok ? (unsigned)(lt.a_off[j] + fs_tapoff) : OOB;
+                st_aoff[0][j] = ok ? brick_a_off((unsigned)(lt.a_f0[j] + fs_tapf), c32, (unsigned)kc_sw) + fs_cbyte : OOB;
             }
         if (G == NG - 3) {                  // the cursor moves on once every offset of this stage is formed
             lkc = kcursor_next<BK>(lkc, p.C, p.S);

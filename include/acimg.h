@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ACIMG_VERSION 202
+#define ACIMG_VERSION 203
 
 #define ACIMG_OK 0
 #define ACIMG_EINVAL (-1)     /* bad descriptor / shape / alignment */
@@ -102,8 +102,8 @@ typedef struct AcimgConfig {
     int32_t trunk_persistent;/* 128x128 trunk convs on the persistent kernel (a workgroup walks a tile list; the next tile's
                                 first loads overlap the current tile's last K step and output stores): 0 never, 1 where it
                                 was measured to pay (short-K, multi-round layers), 2 always */
-    int32_t trunk_bk;        /* K-step depth of the persistent kernel: 0 / 32 = 64-byte operand rows, 2 workgroups / CU;
-                                64 = whole 128-byte lines, 1 workgroup / CU (experiments) */
+    int32_t trunk_bk;        /* K-step depth of the persistent kernel: 0 / 32 (a 64-deep step, one workgroup per CU, was
+                                measured slower in round 2 and removed; the field keeps the record's layout) */
     int32_t trunk_stagger;   /* persistent kernel: start the second half of the grid this many percent of a tile's
                                 estimated time late (0 = together) */
     int32_t trunk_dma_pos;   /* persistent kernel: a K step's operand requests 0 = in one burst after the step barrier,
@@ -112,8 +112,6 @@ typedef struct AcimgConfig {
                                 double buffered in registers, requests spread between the MFMAs): 0 never, 1 where it was
                                 measured to pay, 2 always */
     int32_t trunk_ring_bm;   /* ring kernel's tile rows: 0 = per shape, else 128 or 256 (experiments) */
-    int32_t trunk_b_brick;   /* persistent kernel: weight tiles fetched from the image in LDS-tile order (one contiguous
-                                KiB = eight whole 128-byte lines per request instead of sixteen 64-byte row pieces) */
 } AcimgConfig;
 int acimg_config_default(AcimgConfig* cfg);
 int acimg_configure(const AcimgConfig* cfg);
@@ -126,7 +124,9 @@ size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d);
  * scaling (weights x2^10, activations x2^-2, accumulators x2^-8) keeps everything in fp16's range for
  * |w| < 63 and |x| < 2.6e5.  Needs C % 32 == 0.  `wsplit` (caller-owned,
  * acimg_conv2d_split3_weight_bytes(d) bytes) is filled by acimg_conv2d_split3_prepare from the HWIO fp32
- * kernel: [hi|lo][ldw][R*S*C] fp16.  Semantics otherwise as acimg_conv2d_fwd (deferred BN on load, raw
+ * kernel: [hi|lo][ldw][R*S*C] fp16, followed - for the pre-split entry points acimg_conv2d_fwd_split3p / _split1p - by
+ * the same weights in LDS-tile order (per 128 output channels and 32-deep K step the two 8 KiB plane images
+ * [row][64 bytes], 16-byte groups swizzled as in the activation bricks below).  Semantics otherwise as acimg_conv2d_fwd (deferred BN on load, raw
  * output + statistics partials of acimg_conv2d_fwd_split3_stats_rows(d) rows; optional bias + d->act; no
  * split-K).
  * Row-run view (this entry only): with S == 1 and pad_l == 0, ldx < C is accepted when C % ldx == 0 — the C
@@ -177,11 +177,15 @@ int acimg_conv2d_dgrad_bf16(const AcimgConvDesc* d, const float* gy, int ldgy, c
                             int lddx, const float* residual, int ldres, const float* mask, int ldmask,
                             void* stream);
 
-/* Pre-split activation format: a tensor [rows][C] is stored as TWO fp16 planes (hi at ptr, lo `lo_off`
- * bytes further), hi = f16(v/4), lo = f16(v/4 - hi): 22 mantissa bits in the same 4 bytes per element as
- * fp32.  The elementwise producers below write it (the BN affine + ReLU is already applied), and
- * acimg_conv2d_fwd_split3p consumes it: both GEMM operands are then plain 16-byte copies into LDS, so the
- * K loop of the trunk convs carries no conversion / normalisation work at all.
+/* Pre-split activation format: a tensor [rows][C] (C % 32 == 0, dense) is stored as TWO fp16 planes (hi at ptr, lo
+ * `lo_off` bytes further, lo_off >= acimg_split_plane_bytes(rows, C), 16-byte aligned), hi = f16(v/4),
+ * lo = f16(v/4 - hi): 22 mantissa bits in the same 4 bytes per element as fp32.  The elementwise producers below write
+ * it (the BN affine + ReLU is already applied), and acimg_conv2d_fwd_split3p consumes it: both GEMM operands are then
+ * plain 16-byte copies into LDS, so the K loop of the trunk convs carries no conversion / normalisation work at all.
+ * A plane is laid out in LDS-TILE ORDER: ceil(rows / 16) x C / 32 bricks of 1 KiB, brick (row >> 4, c >> 5) at
+ * ((row >> 4) * C / 32 + (c >> 5)) * 1024, inside it 16 rows (row & 15) of 64 bytes and the 16-byte group (c >> 3) & 3 of
+ * a row at group ((c >> 3) ^ -(row >> 2)) & 3 - exactly the image the kernels keep in LDS, so an LDS-DMA request of the
+ * K loop is one contiguous KiB (eight whole cache lines) instead of sixteen 64-byte pieces of sixteen rows.
  *   acimg_bn_relu_split:         planes = relu?(x*scale+shift)            (BN of a bottleneck conv, resnet50.py:109-121)
  *   acimg_bn_add_relu_split:     planes (+ optional fp32) = relu(a*sa+ta + shortcut); shortcut = b32*sb+tb
  *                                (projection) or the previous unit's planes (identity / subsample)   (resnet50.py:104-123)
@@ -202,6 +206,7 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
  * bits; everything else (arguments, tiling, statistics rows, workspace) is as for acimg_conv2d_fwd_split3p. */
 int acimg_conv2d_fwd_split1p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
                              float* y, float* stats, void* ws, size_t ws_bytes, void* stream);
+size_t acimg_split_plane_bytes(long rows, int C);
 int acimg_bn_relu_split(const float* x, const float* scale, const float* shift, int relu, void* out,
                         size_t lo_off, long rows, int C, void* stream);
 int acimg_bn_add_relu_split(const float* a, const float* sa, const float* ta, const float* b32,

@@ -287,11 +287,21 @@ def test_wgrad_split3_geometries(device, case):
     close(db, b.grad, tol=3e-5, what="bf16x3 bgrad %s" % (case,))
 
 
+def plane_bytes(rows, Cc):
+    """bytes of one split-format plane: whole 16-pixel x 32-channel bricks (include/acimg.h)"""
+    return -(-rows // 16) * 16 * Cc * 2
+
+
 def unsplit(planes, lo_off, rows, Cc):
-    """two fp16 planes (uint8 buffer) -> float64 [rows, C] (undoing the 2^-2 scale)"""
-    n = rows * Cc
-    hi = planes[: 2 * n].view(torch.float16).double()
-    lo = planes[lo_off: lo_off + 2 * n].view(torch.float16).double()
+    """two fp16 planes in LDS-tile order (uint8 buffer) -> float64 [rows, C] (undoing the 2^-2 scale): brick (row >> 4,
+    c >> 5) of 1 KiB, inside it row & 15 at 64 bytes and 16-byte group (c >> 3) & 3 at group ((c >> 3) ^ -(row >> 2)) & 3"""
+    r = torch.arange(rows).view(-1, 1)
+    c = torch.arange(Cc).view(1, -1)
+    off = ((r >> 4) * (Cc // 32) + (c >> 5)) * 1024 + (r & 15) * 64 + ((((c >> 3) ^ (-(r >> 2))) & 3) << 4) + (c & 7) * 2
+    idx = (off // 2).reshape(-1).to(planes.device)
+    n = plane_bytes(rows, Cc)
+    hi = planes[:n].view(torch.float16)[idx].double()
+    lo = planes[lo_off: lo_off + n].view(torch.float16)[idx].double()
     return ((hi + lo) * 4.0).reshape(rows, Cc).cpu()
 
 
@@ -312,7 +322,7 @@ def test_presplit_activation_path(device, case, tail):
     ref = tf_conv_ref(xa, w, stride, pads)
     d = ops.conv_desc(N, H, W, Cc, K, R, S, stride, padding)
     rows = N * H * W
-    lo_off = -(-rows * Cc * 2 // 256) * 256
+    lo_off = plane_bytes(rows, Cc)
     planes = torch.zeros(lo_off * 2, dtype=torch.uint8, device=device)
     plan = ops.Plan(device, eager=True)
     ops.bn_relu_split(plan, dev(x, device), dev(sc, device), dev(sh, device), 1, planes, lo_off, rows, Cc)
@@ -347,7 +357,7 @@ def test_presplit_unit_output_and_pool(device):
     plan = ops.Plan(device, eager=True)
     N, OH, OW, Cc = 2, 7, 9, 64
     rows = N * OH * OW
-    lo = -(-rows * Cc * 2 // 256) * 256
+    lo = plane_bytes(rows, Cc)
     a, sa, ta = rnd(g, N, OH, OW, Cc), rnd(g, Cc), rnd(g, Cc)
     # projection shortcut (raw fp32 + affine), planes + fp32 copy out
     b, sb, tb = rnd(g, N, OH, OW, Cc), rnd(g, Cc), rnd(g, Cc)
@@ -363,7 +373,7 @@ def test_presplit_unit_output_and_pool(device):
     BH, BW = 2 * OH - 1, 2 * OW
     prev = torch.relu(rnd(g, N, BH, BW, Cc))
     prow = N * BH * BW
-    plo = -(-prow * Cc * 2 // 256) * 256
+    plo = plane_bytes(prow, Cc)
     pplanes = torch.zeros(2 * plo, dtype=torch.uint8, device=device)
     ops.bn_relu_split(plan, dev(prev, device), None, None, 0, pplanes, plo, prow, Cc)
     ops.bn_add_relu_split(plan, dev(a, device), dev(sa, device), dev(ta, device), None, None, None, pplanes, plo, out,
@@ -372,14 +382,14 @@ def test_presplit_unit_output_and_pool(device):
     close(unsplit(out, lo, rows, Cc), torch.relu(a * sa + ta + prev[:, ::2, ::2]).reshape(rows, Cc), tol=1e-6,
           what="unit out (identity from planes)")
     # pool1 writing planes
-    N, H, W, Cc = 2, 112, 149, 8
+    N, H, W, Cc = 2, 112, 149, 64
     x, sc, sh = rnd(g, N, H, W, Cc), rnd(g, Cc), rnd(g, Cc)
     OHp, pt, pb = same_pads(H, 3, 2)
     OWp, pl, pr = same_pads(W, 3, 2)
     xa = torch.relu(x * sc + sh).permute(0, 3, 1, 2)
     ref = F.max_pool2d(F.pad(xa, (pl, pr, pt, pb), value=-1e30), 3, 2).permute(0, 2, 3, 1)
     rows = N * OHp * OWp
-    lo = -(-rows * Cc * 2 // 256) * 256
+    lo = plane_bytes(rows, Cc)
     out = torch.zeros(2 * lo, dtype=torch.uint8, device=device)
     ops.bn_relu_maxpool_split(plan, dev(x, device), dev(sc, device), dev(sh, device), out, lo, N, H, W, Cc, OHp, OWp,
                               pt, pl)
@@ -983,7 +993,7 @@ def test_trunk_kernel_variants_agree(device, case):
     w = torch.randn(R, S, Cc, K, generator=g) * (2.0 / (R * S * Cc)) ** 0.5
     d = ops.conv_desc(N, H, W, Cc, K, R, S, stride, padding)
     rows = N * H * W
-    lo_off = -(-rows * Cc * 2 // 256) * 256
+    lo_off = plane_bytes(rows, Cc)
     planes = torch.zeros(lo_off * 2, dtype=torch.uint8, device=device)
     plan = ops.Plan(device, eager=True)
     one, zero = torch.ones(Cc, device=device), torch.zeros(Cc, device=device)
@@ -999,15 +1009,13 @@ def test_trunk_kernel_variants_agree(device, case):
                           ("persistent", dict(trunk_persistent=2, trunk_ring=0)),
                           ("staggered", dict(trunk_persistent=2, trunk_stagger=50, trunk_ring=0)),
                           ("spread", dict(trunk_persistent=2, trunk_dma_pos=1, trunk_ring=0)),
-                          ("bk64", dict(trunk_persistent=2, trunk_bk=64, trunk_ring=0)),
                           ("auto no ring", dict(trunk_ring=0)), ("auto", dict()),
                           ("ring256 whole", dict(trunk_ring=2, trunk_ring_bm=256, tail_split=0)),
                           ("ring128 whole", dict(trunk_ring=2, trunk_ring_bm=128, tail_split=0)),
                           ("ring256", dict(trunk_ring=2, trunk_ring_bm=256)),
                           ("ring128", dict(trunk_ring=2, trunk_ring_bm=128)),
                           ("ring256 s3", dict(trunk_ring=2, trunk_ring_bm=256, tail_s=3)),
-                          ("ring", dict(trunk_ring=2)),
-                          ("ring2 whole", dict(trunk_ring=3, tail_split=0)), ("ring2", dict(trunk_ring=3))):
+                          ("ring", dict(trunk_ring=2))):
             _lib.configure(**cfg)
             srows = ops.conv2d_fwd_split3p_stats_rows(d)     # depends on the kernel the configuration picks
             y = torch.full((N, d.OH, d.OW, K), float("nan"), device=device)
@@ -1037,7 +1045,7 @@ def test_trunk_kernel_variants_agree(device, case):
         assert torch.equal(outs[name][0], outs["one-tile"][0]), name
     for name in ("staggered", "spread"):
         assert torch.equal(outs[name][1], outs["persistent"][1]), name
-    # the two-slot ring kernel sums a K step's three terms in another order (lo*hi, hi*hi, hi*lo): equal to rounding
+    # other K ranges in the tail (ring kernel under "auto", forced range counts): equal to rounding
     y0 = outs["one-tile whole"][0]
     for name in outs:
         assert float((outs[name][0] - y0).abs().max()) <= 4e-6 * float(y0.abs().max()), name
@@ -1057,7 +1065,7 @@ def test_fp16_operand_storage_conv(device, case):
     w = torch.randn(R, S, Cc, K, generator=g) * (2.0 / (R * S * Cc)) ** 0.5
     d = ops.conv_desc(N, H, W, Cc, K, R, S, stride, padding)
     rows = N * H * W
-    lo_off = -(-rows * Cc * 2 // 256) * 256
+    lo_off = plane_bytes(rows, Cc)
     planes = torch.zeros(lo_off * 2, dtype=torch.uint8, device=device)
     plan = ops.Plan(device, eager=True)
     ops.bn_relu_split(plan, x.to(device), torch.ones(Cc, device=device), torch.zeros(Cc, device=device), 1, planes,

@@ -47,7 +47,7 @@ def main():
     for (H, W, Cc, K, R) in shapes:
         d = ops.conv_desc(N, H, W, Cc, K, R, R, 1, "SAME")
         rows = N * H * W
-        lo = -(-rows * Cc * 2 // 256) * 256
+        lo = -(-rows // 16) * 16 * Cc * 2     # acimg_split_plane_bytes: whole 16-pixel bricks
         x = torch.rand(rows, Cc, generator=g).to(dev)
         planes = torch.zeros(2 * lo, dtype=torch.uint8, device=dev)
         plan = ops.Plan(dev, eager=True)

@@ -21,7 +21,7 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(1)
     d = ops.conv_desc(N, H, W, C, K, R, R, s, "SAME" if s == 1 else (1 if R == 3 else "SAME"))
     rows = N * H * W
-    lo = -(-rows * C * 2 // 256) * 256
+    lo = -(-rows // 16) * 16 * C * 2     # acimg_split_plane_bytes: whole 16-pixel bricks
     x = torch.rand(rows, C, generator=g).to(dev)
     planes = torch.zeros(2 * lo, dtype=torch.uint8, device=dev)
     plan = ops.Plan(dev, eager=True)

@@ -43,7 +43,9 @@ def main():
     for _, _, path in variants:
         if path not in handles:
             _lib._lib, _lib.LIB_PATH = None, os.path.join(ROOT, path)
+            newer = {k: _lib.PROTOTYPES.pop(k) for k in ("acimg_split_plane_bytes",)}    # entry points an older build lacks
             handles[path] = _lib.load()
+            _lib.PROTOTYPES.update(newer)
     _lib._lib = default_lib
 
     def use(cfg, path):
@@ -59,7 +61,7 @@ def main():
     for (H, W, C, K, R, s, cnt) in SHAPES:
         d = ops.conv_desc(N, H, W, C, K, R, R, s, "SAME" if s == 1 else (1 if R == 3 else "SAME"))
         rows = N * H * W
-        lo = -(-rows * C * 2 // 256) * 256
+        lo = -(-rows // 16) * 16 * C * 2     # acimg_split_plane_bytes: whole 16-pixel bricks
         x = torch.rand(rows, C, generator=g).to(dev)
         planes = torch.zeros(2 * lo, dtype=torch.uint8, device=dev)
         one, zero = torch.ones(C, device=dev), torch.zeros(C, device=dev)
