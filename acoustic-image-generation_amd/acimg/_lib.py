@@ -29,7 +29,7 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "splitk_cut", "splitk_target", "splitk_handoff", "wgrad_minpix", "wgrad_halo", "split3_tile_bm",
         "split3_tile_bn", "tail_split", "tail_s", "trunk_persistent", "trunk_bk", "trunk_stagger", "trunk_dma_pos",
-        "trunk_ring", "trunk_ring_bm")]
+        "trunk_ring", "trunk_ring_bm", "trunk_halo")]
 
 
 class SequenceDims(C.Structure):
@@ -199,7 +199,8 @@ def configure_from_env(env=None):
     for var, field in (("ACIMG_SPLITK_CUT", "splitk_cut"), ("ACIMG_SPLITK_TARGET", "splitk_target"),
                        ("ACIMG_WGRAD_MINPIX", "wgrad_minpix"), ("ACIMG_TAIL_S", "tail_s"), ("ACIMG_TRUNK_BK", "trunk_bk"),
                        ("ACIMG_TRUNK_STAGGER", "trunk_stagger"), ("ACIMG_TRUNK_DMA_POS", "trunk_dma_pos"),
-                       ("ACIMG_TRUNK_RING", "trunk_ring"), ("ACIMG_TRUNK_RING_BM", "trunk_ring_bm")):
+                       ("ACIMG_TRUNK_RING", "trunk_ring"), ("ACIMG_TRUNK_RING_BM", "trunk_ring_bm"),
+                       ("ACIMG_TRUNK_HALO", "trunk_halo")):
         if env.get(var):
             kw[field] = int(env[var])
     for var, field in (("ACIMG_NO_SPLITK_HANDOFF", "splitk_handoff"), ("ACIMG_NO_WGRAD_HALO", "wgrad_halo"),

@@ -16,6 +16,7 @@
 #include "igemm_split3d_kernel.hpp"
 #include "igemm_split3dp_kernel.hpp"
 #include "igemm_split3r_kernel.hpp"
+#include "igemm_split3h_kernel.hpp"
 #include <cstdlib>
 #include <algorithm>
 
@@ -1189,7 +1190,7 @@ int acimg_conv2d_fwd_tiling(const AcimgConvDesc* d, int* out) {
 
 int acimg_config_default(AcimgConfig* c) {
     if (!c) return fail(ACIMG_EINVAL, "config_default: null");
-    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0};
+    *c = AcimgConfig{320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0};
     return ACIMG_OK;
 }
 
@@ -1205,6 +1206,7 @@ int acimg_configure(const AcimgConfig* c) {
     if (c->trunk_ring < 0 || c->trunk_ring > 2) return fail(ACIMG_EINVAL, "configure: trunk_ring is 0, 1 or 2");
     if (c->trunk_ring_bm != 0 && c->trunk_ring_bm != 128 && c->trunk_ring_bm != 256)
         return fail(ACIMG_EINVAL, "configure: trunk_ring_bm must be 0 (per shape), 128 or 256");
+    if (c->trunk_halo < 0 || c->trunk_halo > 2) return fail(ACIMG_EINVAL, "configure: trunk_halo is 0, 1 or 2");
     if (c->split3_tile_bm || c->split3_tile_bn) {
         const int bm = c->split3_tile_bm, bn = c->split3_tile_bn;
         if (!((bm == 128 && bn == 128) || (bm == 64 && bn == 128) || (bm == 128 && bn == 64)))
@@ -1510,6 +1512,24 @@ static bool split3p_persistent(const Split3Cfg& c, long tiles) {
     return g_cfg.trunk_persistent == 2 || (g_cfg.trunk_persistent == 1 && tiles >= 512);
 }
 
+// Halo kernel (igemm_split3h_kernel.hpp) for a pre-split trunk conv: 3x3 / stride 1 / SAME on 128x128 tiles, image rows
+// short enough for an 18-brick patch.  trunk_halo = 1 takes it where it was measured to pay, 2 wherever it applies.
+static constexpr int HALO_NB = 18;
+static bool halo_applies(const AcimgConvDesc* d, int terms) {
+    if (terms != 3 || d->R != 3 || d->S != 3 || d->stride != 1 || d->pad_t != 1 || d->pad_l != 1 || d->OH != d->H ||
+        d->OW != d->W || d->C % 32)
+        return false;
+    const int M = d->N * d->OH * d->OW;
+    const Split3Cfg c = pick_split3(M, d->K);
+    if (c.bm != 128 || c.bn != 128) return false;
+    return ((d->W + 16) >> 4) + 8 + (d->W >> 4) + 1 <= HALO_NB;
+}
+static bool halo_on(const AcimgConvDesc* d, int terms) {
+    if (!g_cfg.trunk_halo || !halo_applies(d, terms)) return false;
+    if (g_cfg.trunk_halo == 2) return true;
+    return true;
+}
+
 // Ring kernel (igemm_split3r_kernel.hpp) for a pre-split trunk conv, and with how many tile rows: 0 = not on it.
 // Measured per shape at batch 32 and 30 (tools/trunk_shapes.py, profiles/r03/trunk_shapes_r03*.txt): in its steady state
 // the ring kernel's K loop is 8-14 % faster than the two-workgroups-per-CU kernels' (long-K layers whose tiles fill one
@@ -1519,7 +1539,7 @@ static bool split3p_persistent(const Split3Cfg& c, long tiles) {
 // ~1.2 rounds of 128x128 tiles over the CUs (the 14x19 stage) with at least 64 K steps, on 128-row tiles with the tail
 // cut into K ranges; trunk_ring = 2 forces it (experiments, tests).
 static int ring_rows(const AcimgConvDesc* d, int terms) {
-    if (!g_cfg.trunk_ring || terms != 3) return 0;
+    if (!g_cfg.trunk_ring || terms != 3 || halo_on(d, terms)) return 0;
     const int M = d->N * d->OH * d->OW;
     if ((long)M * d->ldy * 4 >= (1L << 31)) return 0;      // 32-bit output descriptor (see fwd_presplit)
     const Split3Cfg c = pick_split3(M, d->K);
@@ -1549,6 +1569,7 @@ int acimg_conv2d_fwd_split3_tiling(const AcimgConvDesc* d, int* out) {
         out[0] = rr;
         out[2] = 2;
     }
+    if (halo_on(d, 3)) out[2] = 3;             // the halo kernel (128x128)
     return ACIMG_OK;
 }
 
@@ -1883,6 +1904,24 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
     // the persistent and the ring kernel address the output through a 32-bit buffer descriptor; a larger output (per-GPU
     // batches around 512 on the first trunk units) falls back to the one-tile kernel's 64-bit pointer stores
     const bool big_out = (long)p.M * d->ldy * 4 >= (1L << 31);
+    if (halo_on(d, terms)) {
+        // one tile per workgroup, K walked as (channel chunk, tap) over one staged patch per chunk; tail tiles in K ranges
+        const size_t lds_h = (size_t)2 * (HALO_NB * 1024 + 64) + 2 * 2 * 128 * 64;
+        const void* fh = (const void*)igemm_split3h_kernel<HALO_NB>;
+        static bool attr_h = false;                  // > 64 KiB of dynamic LDS needs the opt-in once per process
+        if (!attr_h) {
+            (void)hipFuncSetAttribute(fh, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_h);
+            attr_h = true;
+        }
+        const int Ph = resident_slots(7, fh, 512, lds_h);
+        TailPlan th{T, 1, 0};
+        if (ws && ws_bytes >= acimg_conv2d_fwd_split3p_workspace(d)) th = pick_tail(T, Ph, p.kiters, TS_MAX_UNITS);
+        p.ts_whole = th.whole; p.ts_s = th.s;
+        p.ts_counters = static_cast<int*>(ws);
+        p.ts_partial = ws ? reinterpret_cast<float*>(static_cast<char*>(ws) + TS_COUNTER_BYTES) : nullptr;
+        hipLaunchKernelGGL((igemm_split3h_kernel<HALO_NB>), dim3(th.whole + th.rem * th.s), dim3(512), lds_h, st, p);
+        return check_launch("conv2d_fwd_split3p (halo)");
+    }
     if (const int rr = big_out ? 0 : ring_rows(d, terms)) {
 #if defined(ACIMG_STAMP) || defined(ACIMG_ABLATE)
         p.slab = g_stamp_buf;

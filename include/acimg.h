@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ACIMG_VERSION 203
+#define ACIMG_VERSION 204
 
 #define ACIMG_OK 0
 #define ACIMG_EINVAL (-1)     /* bad descriptor / shape / alignment */
@@ -112,6 +112,9 @@ typedef struct AcimgConfig {
                                 double buffered in registers, requests spread between the MFMAs): 0 never, 1 where it was
                                 measured to pay, 2 always */
     int32_t trunk_ring_bm;   /* ring kernel's tile rows: 0 = per shape, else 128 or 256 (experiments) */
+    int32_t trunk_halo;      /* 3x3 / stride-1 trunk convs on the HALO kernel (one patch of the activation planes staged per
+                                channel chunk, all nine taps formed from it in LDS): 0 never, 1 where it was measured to
+                                pay, 2 wherever it applies */
 } AcimgConfig;
 int acimg_config_default(AcimgConfig* cfg);
 int acimg_configure(const AcimgConfig* cfg);

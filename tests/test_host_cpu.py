@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (acimg_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
-    assert lib.acimg_version() == 203
+    assert lib.acimg_version() == 204
 
 
 def test_host_side_queries_need_no_gpu(lib):
@@ -308,7 +308,7 @@ def test_library_reads_no_environment_and_configure_validates(lib):
     assert lib.acimg_config_default(C.byref(cfg)) == 0
     assert (cfg.splitk_cut, cfg.splitk_target, cfg.splitk_handoff, cfg.wgrad_minpix, cfg.wgrad_halo, cfg.split3_tile_bm,
             cfg.split3_tile_bn, cfg.tail_split, cfg.tail_s, cfg.trunk_persistent, cfg.trunk_bk, cfg.trunk_stagger, cfg.trunk_dma_pos,
-            cfg.trunk_ring, cfg.trunk_ring_bm) == (320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0)
+            cfg.trunk_ring, cfg.trunk_ring_bm, cfg.trunk_halo) == (320, 768, 1, 128, 1, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0)
     # the ring kernel's row tile decides the statistics rows of a pre-split conv: 14x19 512->512 3x3 at batch 32 is on it
     d14 = ops.conv_desc(32, 14, 19, 512, 512, 3, 3)
     assert ops.conv2d_fwd_split3p_stats_rows(d14) == -(-32 * 14 * 19 // 128)

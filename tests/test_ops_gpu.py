@@ -886,11 +886,15 @@ def test_split3_prepare_multi_equals_single_launches(device):
         b = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         (ops.conv2d_split3_prepare_dgrad if mode else ops.conv2d_split3_prepare)(plan, d, w, a)
         jobs.add(d, w, b, mode)
-        singles.append((a, b))
+        # the multi launch serves the on-the-fly kernels (trainable generator kernels): the row-major planes only, not the
+        # LDS-tile-order image the single launch appends for the pre-split trunk kernels
+        rowmajor = nbytes if mode else 2 * d.ldw * R_ * R_ * C_ * 2
+        singles.append((a, b, rowmajor))
     ops.conv2d_split3_prepare_multi(plan, jobs)
     torch.cuda.synchronize()
-    for a, b in singles:
-        assert torch.equal(a, b)
+    for a, b, rowmajor in singles:
+        assert torch.equal(a[:rowmajor], b[:rowmajor])
+        assert not b[rowmajor:].any()
     empty = ops.PrepareJobs()
     ops.conv2d_split3_prepare_multi(plan, empty)            # nothing to do is not an error
 
@@ -1015,7 +1019,10 @@ def test_trunk_kernel_variants_agree(device, case):
                           ("ring256", dict(trunk_ring=2, trunk_ring_bm=256)),
                           ("ring128", dict(trunk_ring=2, trunk_ring_bm=128)),
                           ("ring256 s3", dict(trunk_ring=2, trunk_ring_bm=256, tail_s=3)),
-                          ("ring", dict(trunk_ring=2))):
+                          ("ring", dict(trunk_ring=2)),
+                          # the halo kernel takes the 3x3 cases only (the others stay on the shipped choice)
+                          ("halo whole", dict(trunk_halo=2, tail_split=0)), ("halo", dict(trunk_halo=2)),
+                          ("halo s3", dict(trunk_halo=2, tail_s=3))):
             _lib.configure(**cfg)
             srows = ops.conv2d_fwd_split3p_stats_rows(d)     # depends on the kernel the configuration picks
             y = torch.full((N, d.OH, d.OW, K), float("nan"), device=device)
@@ -1048,6 +1055,61 @@ def test_trunk_kernel_variants_agree(device, case):
     # other K ranges in the tail (ring kernel under "auto", forced range counts): equal to rounding
     y0 = outs["one-tile whole"][0]
     for name in outs:
+        assert float((outs[name][0] - y0).abs().max()) <= 4e-6 * float(y0.abs().max()), name
+
+
+@pytest.mark.parametrize("case", [(3, 14, 19, 64, 128), (2, 28, 38, 32, 160), (1, 56, 75, 32, 128), (5, 9, 79, 32, 128),
+                                  (37, 5, 3, 32, 128), (200, 3, 1, 64, 128), (1, 1, 1, 32, 128), (2, 75, 56, 96, 256)])
+def test_halo_kernel_edges(device, case):
+    """The halo form of the 3x3 trunk conv (one patch of the planes per channel chunk, taps formed in LDS, zero row for
+    taps that fall off an image, permuted fragment rows) at the sizes where its masks matter: several images inside
+    one 128-pixel tile, one-pixel-wide and one-pixel images, the widest row an 18-brick patch holds, a row tail, a
+    column tail, K ranges; against fp64 and against the per-tap kernel."""
+    from acimg import _lib, ops
+
+    N, H, W, Cc, K = case
+    g = torch.Generator().manual_seed(11 + H * W + Cc)
+    x = torch.rand(N, H, W, Cc, generator=g) - 0.3
+    w = torch.randn(3, 3, Cc, K, generator=g) * (2.0 / (9 * Cc)) ** 0.5
+    d = ops.conv_desc(N, H, W, Cc, K, 3, 3, 1, "SAME")
+    rows = N * H * W
+    lo_off = plane_bytes(rows, Cc)
+    planes = torch.zeros(lo_off * 2, dtype=torch.uint8, device=device)
+    plan = ops.Plan(device, eager=True)
+    ops.bn_relu_split(plan, x.to(device), torch.ones(Cc, device=device), torch.zeros(Cc, device=device), 0, planes, lo_off,
+                      rows, Cc)
+    wsplit = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=device)
+    ops.conv2d_split3_prepare(plan, d, w.to(device), wsplit)
+    tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=device)
+    outs = {}
+    try:
+        for name, cfg in (("per-tap", dict(split3_tile_bm=128, split3_tile_bn=128, trunk_ring=0)),
+                          ("halo", dict(split3_tile_bm=128, split3_tile_bn=128, trunk_halo=2)),
+                          ("halo whole", dict(split3_tile_bm=128, split3_tile_bn=128, trunk_halo=2, tail_split=0)),
+                          ("halo s2", dict(split3_tile_bm=128, split3_tile_bn=128, trunk_halo=2, tail_s=2)),
+                          ("halo s4", dict(split3_tile_bm=128, split3_tile_bn=128, trunk_halo=2, tail_s=4))):
+            _lib.configure(**cfg)
+            tiling = ops.conv2d_fwd_split3_tiling(d)
+            assert tiling[2] == (3 if name.startswith("halo") else tiling[2]), (name, tiling)
+            srows = ops.conv2d_fwd_split3p_stats_rows(d)
+            y = torch.full((N, H, W, K), float("nan"), device=device)
+            st = torch.full((srows, 2, K), float("nan"), device=device)
+            for _ in range(2):
+                ops.conv2d_fwd_split3p(plan, d, planes, lo_off, wsplit, y, st, tail_ws=tws)
+            torch.cuda.synchronize()
+            assert int(tws[:4096].view(torch.int32).abs().sum()) == 0, name
+            outs[name] = (y, st)
+    finally:
+        _lib.configure()
+    ref = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1),
+                                     padding=1).permute(0, 2, 3, 1)
+    flat = ref.reshape(-1, K)
+    for name, (y, st) in outs.items():
+        close(y, ref, tol=2e-6, what="halo conv %s %s" % (name, case))
+        close(st[:, 0].sum(0), flat.sum(0), tol=2e-4, what="stats sum " + name)
+        close(st[:, 1].sum(0), (flat * flat).sum(0), tol=2e-4, what="stats sumsq " + name)
+    y0 = outs["per-tap"][0]
+    for name in outs:       # (chunk, tap) order against (tap, chunk) order: equal to fp32 rounding
         assert float((outs[name][0] - y0).abs().max()) <= 4e-6 * float(y0.abs().max()), name
 
 

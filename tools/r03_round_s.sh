@@ -1,0 +1,14 @@
+# round 3, session 3: evidence at HEAD after the brick layout: GPU suite, default bench, per-shape table, op report, rocprof stats
+R=$GRAFT_REPO_ROOT
+TAG=${1:-r03s}
+cd $R
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu --durations=15 > gpurun_out/${TAG}_gputests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_gputests.log
+tail -22 gpurun_out/${TAG}_gputests.log
+python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err || { tail -5 gpurun_out/${TAG}_bench_default.err; }
+cut -c1-260 gpurun_out/${TAG}_bench_default.json
+timeout -k 10 300 python tools/trunk_shapes.py 4 "shipped=trunk_ring:1" > gpurun_out/${TAG}_shapes.txt 2> gpurun_out/${TAG}_shapes.json
+cat gpurun_out/${TAG}_shapes.txt
+python tools/op_report.py 32 > gpurun_out/${TAG}_op_report.txt 2>&1
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof1 -o run --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-pipeline --no-side-lane --no-cpu-baseline --no-secondary > $R/gpurun_out/${TAG}_prof1_bench.json 2>/dev/null
+echo done
