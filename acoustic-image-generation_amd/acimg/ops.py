@@ -513,6 +513,21 @@ def conv2d_fwd_split3p(plan, d, x_planes, x_lo_off, wsplit, y, stats=None, tail_
              wsplit, y, stats, tail_ws, int(nbytes), side=side)
 
 
+def conv2d_fwd_split3p_stats(plan, d, x_planes, x_lo_off, wsplit, stats, tail_ws=None, side=False):
+    """first pass of a two-pass conv (acimg_conv2d_fwd_split3p_stats): batch-norm partials, no output"""
+    nbytes = 0 if tail_ws is None else (tail_ws.numel() * tail_ws.element_size() if hasattr(tail_ws, "numel") else 0)
+    plan.add("conv2d_fwd_split3p_stats", _L().acimg_conv2d_fwd_split3p_stats, C.byref(d), x_planes, int(x_lo_off), wsplit,
+             stats, tail_ws, int(nbytes), side=side)
+
+
+def conv2d_fwd_split3p_tail(plan, d, x_planes, x_lo_off, wsplit, scale, shift, sc_planes, sc_lo_off, out_planes,
+                            out_lo_off, tail_ws=None, side=False):
+    """second pass (acimg_conv2d_fwd_split3p_tail): relu(conv * scale + shift + shortcut) straight into split planes"""
+    nbytes = 0 if tail_ws is None else (tail_ws.numel() * tail_ws.element_size() if hasattr(tail_ws, "numel") else 0)
+    plan.add("conv2d_fwd_split3p_tail", _L().acimg_conv2d_fwd_split3p_tail, C.byref(d), x_planes, int(x_lo_off), wsplit,
+             scale, shift, sc_planes, int(sc_lo_off), out_planes, int(out_lo_off), tail_ws, int(nbytes), side=side)
+
+
 def bn_relu_split(plan, x, scale, shift, relu, out, lo_off, rows, Cn):
     plan.add("bn_relu_split", _L().acimg_bn_relu_split, x, scale, shift, int(relu), out, int(lo_off), int(rows), Cn)
 

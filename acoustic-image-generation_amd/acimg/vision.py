@@ -33,7 +33,8 @@ PLANE_SLACK = 2 * 15 * 2048 * 2 + 512   # a split-format plane ends on a whole 1
 
 class ResNet50Model(object):
 
-    def __init__(self, input_shape=None, num_classes=None, precision="f16x3", stages=None, stage_cut=8, side_lane=True):
+    def __init__(self, input_shape=None, num_classes=None, precision="f16x3", stages=None, stage_cut=8, side_lane=True,
+                 two_pass=True):
         """precision: arithmetic of the frozen trunk convs — "f16x3" (split-fp16 MFMA, fp32-class
         results, default), "f32" (exact-f32 MFMA) or "f16" (fp16 OPERAND STORAGE: the same data path, but the 52 trunk
         convs fetch and multiply only the hi fp16 plane of activations and weights — one MFMA per product, fp32
@@ -62,6 +63,10 @@ class ResNet50Model(object):
         # (constructor arguments, not environment variables: stages, stage_cut, side_lane)
         self.STAGE_CUT = int(stage_cut)
         self.side_lane = bool(side_lane) and stages == 1
+        # two_pass: conv3 of the identity units runs twice - statistics only, then again with BN + shortcut + ReLU + split
+        # in its epilogue (ops.conv2d_fwd_split3p_stats / _tail) - instead of conv + bn_add_relu_split: the unit's widest
+        # tensor never exists in fp32 (f16x3 only; units with a subsampled shortcut and the last unit keep the pass)
+        self.two_pass = bool(two_pass) and precision == "f16x3"
         self.num_classes = num_classes
         self.height = input_shape[0]
         self.width = input_shape[1]
@@ -352,6 +357,59 @@ class ResNet50Model(object):
                         P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, BN_DECAY, BN_EPS, training, side=side)
         return d.OH, d.OW, sc, sh
 
+    def _conv3_two_pass(self, plan, scope, xplanes, hw, cin, cout, sc_planes, out_planes, training, tag=""):
+        """conv3 of an identity unit without its raw output (include/acimg.h, acimg_conv2d_fwd_split3p_stats / _tail):
+        [statistics pass ->] bn_finalize -> the conv again with relu(BN + shortcut) + split in the epilogue.  In inference
+        mode the affine comes from the moving statistics and the first pass is not needed."""
+        st = self.session.store
+        P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
+        d = ops.conv_desc(self.N, hw[0], hw[1], cin, cout, 1, 1, 1, "SAME", ldx=cin, ldy=cout, ldw=cout)
+        rows = -(-self.N * hw[0] * hw[1] // 128)
+        if tag:
+            self._lane_stats_need = getattr(self, "_lane_stats_need", {})
+            self._lane_stats_need[tag] = max(self._lane_stats_need.get(tag, 0), rows * 2 * cout)
+            stats = ops.LazyPtr(lambda lane=tag: self.lane_stats[lane])
+        else:
+            self._stats_need = max(self._stats_need, rows * 2 * cout)
+            stats = ops.LazyPtr(lambda: self.stats)
+        if scope not in self._sp3:
+            off = self._sp3_bytes
+            self._sp3[scope] = off
+            self._sp3_bytes += -(-ops.conv2d_split3_weight_bytes(d) // 256) * 256
+            ops.conv2d_split3_prepare(self.plan_prepare, d, P(scope + "/weights"),
+                                      ops.LazyPtr(lambda off=off: self.wsplit[off:]))
+        off = self._sp3[scope]
+        wsplit = ops.LazyPtr(lambda off=off: self.wsplit[off:])
+        ws_attr = "_tail_ws" + tag
+        if getattr(self, ws_attr, None) is None:
+            setattr(self, ws_attr, torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8,
+                                               device=self.session.device))
+        tail_ws = getattr(self, ws_attr)
+        lo = self._lo_off(self.N * hw[0] * hw[1], cin)
+        lo_out = self._lo_off(self.N * hw[0] * hw[1], cout)
+        if training:
+            ops.conv2d_fwd_split3p_stats(plan, d, xplanes, lo, wsplit, stats, tail_ws=tail_ws)
+        if not hasattr(self, "_aff_cache"):
+            self._aff_cache = {}
+        if scope not in self._aff_cache:
+            self._aff_cache[scope] = self._new_affine(up4(cout))
+        sc, sh = self._aff_cache[scope]
+        b = scope + "/BatchNorm/"
+        ops.bn_finalize(plan, stats if training else None, rows if training else 0, cout, up4(cout),
+                        self.N * hw[0] * hw[1] if training else 0, P(b + "gamma"), P(b + "beta"),
+                        P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, BN_DECAY, BN_EPS, training)
+        ops.conv2d_fwd_split3p_tail(plan, d, xplanes, lo, wsplit, sc, sh, sc_planes, lo_out, out_planes, lo_out,
+                                    tail_ws=tail_ws)
+
+    def _two_pass_ok(self, hw, cin, cout):
+        """measured per shape at batch 32 (profiles/r03/op_report_two_pass_all_r03u.txt): the statistics pass costs 85-95 %
+        of the conv it repeats once K >= 256 (the K loop, not the output, is its time), so the second K loop only pays
+        for the short-K / large-image units: 56x75 64->256 113 -> 84 us, 128->512 247 -> 192 us per unit, against
+        28x38 256->1024 130 -> 144 and 14x19 512->2048 94 -> 121"""
+        M = self.N * hw[0] * hw[1]
+        return (self.two_pass and self._terms == 3 and cin <= 128 and cout % 128 == 0
+                and -(-M // 128) * (cout // 128) >= 200 and M * cout * 4 < 2 ** 31)
+
     def _record_forward_split(self, plan, training):
         """f16x3 trunk: activations between convs live in split format.  Per bottleneck unit:
              conv1(X) -> raw1 -> [BN+ReLU+split] -> conv2 -> raw2 -> [BN+ReLU+split] -> conv3 -> raw3
@@ -395,12 +453,23 @@ class ResNet50Model(object):
             oh2, ow2, s2, t2 = self._conv_bn_planes(plan, scope + "/conv2", p1, (h, w), db, 3, 3, db, s,
                                                     "SAME" if s == 1 else 1, r2, training, tag=tag)
             ops.bn_relu_split(plan, r2, s2, t2, 1, p2, self._lo_off(N * oh2 * ow2, db), N * oh2 * ow2, db)
-            oh3, ow3, s3, t3 = self._conv_bn_planes(plan, scope + "/conv3", p2, (oh2, ow2), db, 1, 1, d, 1,
-                                                    "SAME", r3, training, tag=tag)
             if two and i == self.STAGE_CUT - 1:
                 nxt_out = self.planes_x          # the last unit of stage 1 writes the boundary tensor
             else:
                 nxt_out = nxt
+            if din == d and s == 1 and not last and self._two_pass_ok((oh2, ow2), db, d):
+                # identity unit: conv3 twice, the raw [N, oh, ow, d] tensor and its BN pass never exist
+                self._conv3_two_pass(plan, scope + "/conv3", p2, (oh2, ow2), db, d, cur, nxt_out, training, tag=tag)
+                h, w = oh2, ow2
+                if two and i == self.STAGE_CUT and training:
+                    self.stage_read_calls = len(plan.calls)
+                if two and i == self.STAGE_CUT:
+                    cur, nxt = self.planes_a2, self.planes_b2
+                else:
+                    cur, nxt = nxt, cur
+                continue
+            oh3, ow3, s3, t3 = self._conv_bn_planes(plan, scope + "/conv3", p2, (oh2, ow2), db, 1, 1, d, 1,
+                                                    "SAME", r3, training, tag=tag)
             out_planes = None if last else nxt_out
             out_lo = 0 if last else self._lo_off(N * oh3 * ow3, d)
             out32 = self.xfinal if last else None

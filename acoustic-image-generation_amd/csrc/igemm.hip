@@ -1800,7 +1800,7 @@ static int dgrad_split_onthefly(const AcimgConvDesc* d, const float* gy, int ldg
 // ---- tail split of the trunk kernel: which tiles to cut, and into how many K ranges ------------------------
 struct TailPlan { int whole, s, rem; };
 static int resident_slots(int which, const void* fn, int threads, size_t lds) {
-    static int cache[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static int cache[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (!cache[which]) {
         int dev = 0, ncu = 0, per = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -1808,7 +1808,7 @@ static int resident_slots(int which, const void* fn, int threads, size_t lds) {
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, fn, threads, lds) != hipSuccess || ncu <= 0 || per <= 0) {
             (void)hipGetLastError();
             ncu = 256;                    // MI355X; no device (CPU-side sizing queries): same answer
-            per = which == 7 ? 2 : which >= 4 ? 1 : (which == 0 || which == 3) ? 2 : 3;
+            per = which >= 7 ? 2 : which >= 4 ? 1 : (which == 0 || which == 3) ? 2 : 3;
         }
         cache[which] = ncu * per;
     }
@@ -1859,8 +1859,20 @@ size_t acimg_conv2d_fwd_split3p_workspace(const AcimgConvDesc* d) {
     return TS_COUNTER_BYTES + (size_t)TS_MAX_UNITS * 128 * 128 * sizeof(float);
 }
 
+// the two passes of a conv whose raw output never reaches memory (igemm_split3dp_kernel, EPI 1 / 2)
+struct Split3pTail {
+    int mode;                      // 1: statistics only; 2: relu(acc * scale + shift + shortcut) -> split planes
+    const float* scale;
+    const float* shift;
+    const void* sc_planes;
+    size_t sc_lo_off;
+    void* out_planes;
+    size_t out_lo_off;
+};
+
 static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit, float* y,
-                        float* stats, void* ws, size_t ws_bytes, void* stream, const int terms) {
+                        float* stats, void* ws, size_t ws_bytes, void* stream, const int terms,
+                        const Split3pTail* tail = nullptr) {
     int rc = check_desc(d, "conv2d_fwd_split3p");
     if (rc) return rc;
     if (d->C % 32) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p: C=%d must be a multiple of 32", d->C);
@@ -1904,6 +1916,40 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
     // the persistent and the ring kernel address the output through a 32-bit buffer descriptor; a larger output (per-GPU
     // batches around 512 on the first trunk units) falls back to the one-tile kernel's 64-bit pointer stores
     const bool big_out = (long)p.M * d->ldy * 4 >= (1L << 31);
+    if (tail) {
+        // statistics-only / fused-tail passes: always the persistent kernel (whole tiles, then K ranges of the tail tiles)
+        if (terms != 3 || c.bm != 128 || c.bn != 128 || big_out || d->K % 128 || d->ldy != d->K || d->ldw != d->K)
+            return fail(ACIMG_EINVAL, "conv2d_fwd_split3p (two-pass): needs 128x128 tiles, K %% 128 == 0, dense output < 2 GiB");
+        const size_t lds_t = (size_t)2 * 4 * 128 * 64 + 4 * 2 * 128 * 4;
+        const void* ft = tail->mode == 1 ? (const void*)igemm_split3dp_kernel<32, 0, 3, 1>
+                                         : (const void*)igemm_split3dp_kernel<32, 0, 3, 2>;
+        const int Pt = resident_slots(tail->mode == 1 ? 8 : 9, ft, 512, lds_t);
+        TailPlan tt{T, 1, 0};
+        if (ws && ws_bytes >= acimg_conv2d_fwd_split3p_workspace(d)) tt = pick_tail(T, Pt, p.kiters, TS_MAX_UNITS);
+        p.ts_whole = tt.whole; p.ts_s = tt.s;
+        p.ts_counters = static_cast<int*>(ws);
+        p.ts_partial = ws ? reinterpret_cast<float*>(static_cast<char*>(ws) + TS_COUNTER_BYTES) : nullptr;
+        const int units = tt.whole + tt.rem * tt.s;
+        const int nwg = std::min(units, Pt);
+        if (tail->mode == 1) {
+            e.Y = nullptr;
+            hipLaunchKernelGGL((igemm_split3dp_kernel<32, 0, 3, 1>), dim3(nwg), dim3(512), lds_t, st, p, units, nwg);
+            return check_launch("conv2d_fwd_split3p_stats");
+        }
+        const long oplane = (long)acimg_split_plane_bytes((long)p.M, d->K);
+        if (!aligned16(tail->sc_planes) || !aligned16(tail->out_planes) || (tail->sc_lo_off & 15) || (tail->out_lo_off & 15) ||
+            (long)tail->sc_lo_off < oplane || (long)tail->out_lo_off < oplane ||
+            (long)tail->sc_lo_off + oplane >= (1L << 31) || (long)tail->out_lo_off + oplane >= (1L << 31))
+            return fail(ACIMG_EINVAL, "conv2d_fwd_split3p_tail: unaligned / overlapping / >= 2 GiB split-format operands");
+        e.Y = nullptr; e.stats = nullptr;
+        e.f_scale = tail->scale; e.f_shift = tail->shift;
+        e.f_sc = static_cast<const char*>(tail->sc_planes); e.f_sc_lo = (unsigned)tail->sc_lo_off;
+        e.f_sc_bytes = (unsigned)(tail->sc_lo_off + oplane);
+        e.f_out = static_cast<char*>(tail->out_planes); e.f_out_lo = (unsigned)tail->out_lo_off;
+        e.f_out_bytes = (unsigned)(tail->out_lo_off + oplane);
+        hipLaunchKernelGGL((igemm_split3dp_kernel<32, 0, 3, 2>), dim3(nwg), dim3(512), lds_t, st, p, units, nwg);
+        return check_launch("conv2d_fwd_split3p_tail");
+    }
     if (halo_on(d, terms)) {
         // one tile per workgroup, K walked as (channel chunk, tap) over one staged patch per chunk; tail tiles in K ranges
         const size_t lds_h = (size_t)2 * (HALO_NB * 1024 + 64) + 2 * 2 * 128 * 64;
@@ -2007,6 +2053,22 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
 int acimg_conv2d_fwd_split1p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
                              float* y, float* stats, void* ws, size_t ws_bytes, void* stream) {
     return fwd_presplit(d, x_planes, x_lo_off, wsplit, y, stats, ws, ws_bytes, stream, 1);
+}
+
+int acimg_conv2d_fwd_split3p_stats(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
+                                   float* stats, void* ws, size_t ws_bytes, void* stream) {
+    if (!stats) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p_stats: null statistics buffer");
+    const Split3pTail t{1, nullptr, nullptr, nullptr, 0, nullptr, 0};
+    return fwd_presplit(d, x_planes, x_lo_off, wsplit, nullptr, stats, ws, ws_bytes, stream, 3, &t);
+}
+
+int acimg_conv2d_fwd_split3p_tail(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
+                                  const float* scale, const float* shift, const void* sc_planes, size_t sc_lo_off,
+                                  void* out_planes, size_t out_lo_off, void* ws, size_t ws_bytes, void* stream) {
+    if (!scale || !shift || !sc_planes || !out_planes || !aligned16(scale) || !aligned16(shift))
+        return fail(ACIMG_EINVAL, "conv2d_fwd_split3p_tail: null / unaligned scale, shift, shortcut or output");
+    const Split3pTail t{2, scale, shift, sc_planes, sc_lo_off, out_planes, out_lo_off};
+    return fwd_presplit(d, x_planes, x_lo_off, wsplit, nullptr, nullptr, ws, ws_bytes, stream, 3, &t);
 }
 
 /* ---- tap-GEMM helpers (see the kernels above) ---- */

@@ -24,6 +24,13 @@ struct EpiParams {
     float* stats;
     int stats_ld;
     int vec;  // every pointer / stride of the epilogue allows 16-byte accesses
+    // fused tail of an identity bottleneck unit (igemm_split3dp_kernel, EPI 2): relu(acc * f_scale + f_shift + shortcut)
+    // -> hi / lo fp16 planes in brick order; shortcut and output are split-format tensors of the output's shape
+    const float* f_scale;
+    const float* f_shift;
+    const char* f_sc;
+    char* f_out;
+    unsigned f_sc_bytes, f_sc_lo, f_out_bytes, f_out_lo;
 };
 
 // C[m][n] = sum_k A(m,k) * B(k,n);  A gathered from an NHWC tensor (im2col on the fly).

@@ -89,7 +89,16 @@ __device__ __forceinline__ KCursorP kcursor_next(KCursorP k, int C, int S) {
 // under the MFMA block - the B pieces after the first of the three MFMA sweeps, the A pieces after the second - so a
 // wave that waits at the addresser has already queued matrix work and the others keep the pipe busy.
 // TERMS: 3 = split product, 1 = fp16 operand storage (hi planes only), as in igemm_split3d_kernel.
-template <int BK, int DPOS, int TERMS = 3>
+// EPI: what leaves a tile.  0: the raw fp32 tile + batch-norm partials (a BN pass reads it back).  The expanding 1x1
+// conv of an identity bottleneck unit (conv3: short K, 4x wide output) can instead run TWICE (slim bottleneck,
+// models/resnet50.py:104-125: out = relu(BN(conv3) + shortcut)):
+//   1: statistics only - the K loop and the partials, no output at all (its 4 B / element never reach HBM);
+//   2: the same tiles again, now with the layer's (scale, shift) known: relu(acc * scale + shift + shortcut), split into
+//      the hi / lo fp16 planes and written straight in brick order (the next unit's operand format) - the shortcut comes
+//      from the previous unit's planes.  Per wide element 4 B read + 4 B written instead of 4 written + (4 + 4 read,
+//      4 written) by conv + bn_add_relu_split; the price is the conv's K loop twice.
+//      Both passes run the same units in the same order: the statistics are those of exactly the values normalised.
+template <int BK, int DPOS, int TERMS = 3, int EPI = 0>
 __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(const IgemmParams p, const int n_units,
                                                                                const int stride_units) {
     constexpr int BM = 128, BN = 128, WGN = 4, NTHR = 512, NW = 8, ROWB = BK * 2;
@@ -104,8 +113,10 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
     constexpr int HALVES = BM * BN * 4 / STAGE;      // the output tile leaves through one stage: in 2 / 1 passes
     constexpr int RH = BM / HALVES;                  // tile rows per pass
     constexpr int WH = WTM / HALVES;                 // ... of which per wave row
-    constexpr int NST = HALVES * (RH * CH / NTHR) + 1;  // vector-memory stores a wave issues per tile epilogue (8 + 1)
-    static_assert(RH * CH % NTHR == 0 && NST == 9, "output store mapping");
+    // vector-memory instructions a wave issues per tile epilogue AFTER its last wait (8 + 1; statistics only: 1)
+    constexpr int NST = EPI == 1 ? 1 : HALVES * (RH * CH / NTHR) + 1;
+    static_assert(RH * CH % NTHR == 0 && (EPI == 1 || NST == 9), "output store mapping");
+    static_assert(EPI == 0 || (BK == 32 && TERMS == 3), "the fused epilogues belong to the split-product BK = 32 form");
     typedef TileAddrP<PP> Tile;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -313,7 +324,34 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] *= SPLIT3_OUTSCALE;
-        if (e.stats) {
+        // EPI 2: the shortcut chunks of this thread's items (2 passes x 2 bricks per wave x hi / lo), requested before
+        // anything else of the epilogue; item (h, q): brick q of the wave in pass h = pixel group (wave >> 1) of the pass,
+        // channel group 2 (wave & 1) + q; lane l = pixel row l >> 2, physical 16-byte chunk l & 3 of the brick
+        u32x4 sc_hi[EPI == 2 ? 4 : 1], sc_lo[EPI == 2 ? 4 : 1];
+        unsigned f_off[EPI == 2 ? 4 : 1];
+        if constexpr (EPI == 2) {
+            const __amdgpu_buffer_rsrc_t rsC =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(e.f_sc), 0, e.f_sc_bytes, 0x00020000);
+            const unsigned CQ = (unsigned)e.Nstore >> 5;
+            const int pg = e_wid >> 1;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int trow = (pg >> 1) * WTM + h * WH + (pg & 1) * 16;        // first tile row of the pixel group
+                    const int m = m0 + trow + (e_lane >> 2);
+                    const unsigned cg = (unsigned)(n0 >> 5) + 2u * (unsigned)(e_wid & 1) + (unsigned)q;
+                    const unsigned off = (((unsigned)(m0 + trow) >> 4) * CQ + cg) * 1024u + (unsigned)e_lane * 16u;
+                    f_off[h * 2 + q] = m < e.M ? off : OOB;
+                    sc_hi[h * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rsC, f_off[h * 2 + q], 0, 0);
+                    sc_lo[h * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rsC, f_off[h * 2 + q], (int)e.f_sc_lo, 0);
+                }
+            if (te < 64) {      // this column tile's scale | shift -> red[0 .. 255] (read after the staging barrier)
+                const float* src = (te < 32 ? e.f_scale : e.f_shift) + n0 + (te & 31) * 4;
+                *reinterpret_cast<f32x4*>(red + te * 4) = *reinterpret_cast<const f32x4*>(src);
+            }
+        }
+        if (EPI != 2 && e.stats) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 f32x4 s1 = acc[0][j], s2 = acc[0][j] * acc[0][j];
@@ -335,8 +373,13 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
             }
         }
         ACIMG_STAMP_AT(12);                         // statistics from the accumulators
+        if constexpr (EPI == 1) {                   // no output: the partials meet, nothing else leaves the tile
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
-        for (int h = 0; h < HALVES; ++h) {
+        for (int h = 0; h < (EPI == 1 ? 0 : HALVES); ++h) {
 #pragma unroll
             for (int ii = 0; ii < TM / HALVES; ++ii) {
                 const int lr = e_wm * WH + ii * 16 + e_li;
@@ -352,6 +395,42 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             ACIMG_STAMP_AT(10);                     // barrier
+            if constexpr (EPI == 2) {
+                // a wave turns two bricks of the pass (16 pixels x 32 channels each) into their hi / lo KiB: lane l takes
+                // the 8 channels of physical chunk l & 3 of pixel row l >> 2 (two 16-byte fp32 chunks of the staged
+                // tile), normalises, adds the shortcut, ReLU, 2^-2, splits; 64 lanes x 16 bytes = one contiguous KiB
+                const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(e.f_out, 0, e.f_out_bytes, 0x00020000);
+                const unsigned lr = (unsigned)(e_wid >> 1) * 16u + ((unsigned)e_lane >> 2);
+                const unsigned kc = (((unsigned)e_lane & 3u) ^ (0u - ((unsigned)e_lane >> 4))) & 3u;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned cl = (2u * (unsigned)(e_wid & 1) + (unsigned)q) * 32u + kc * 8u;
+                    const unsigned c4 = cl >> 2;
+                    const f32x4 v0 = tile[lr * CH + (c4 ^ (lr & (CH - 1)))];
+                    const f32x4 v1 = tile[lr * CH + ((c4 + 1u) ^ (lr & (CH - 1)))];
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(red + cl);
+                    const f32x4 s1 = *reinterpret_cast<const f32x4*>(red + cl + 4);
+                    const f32x4 t0 = *reinterpret_cast<const f32x4*>(red + BN + cl);
+                    const f32x4 t1 = *reinterpret_cast<const f32x4*>(red + BN + cl + 4);
+                    const h16x8 bh = __builtin_bit_cast(h16x8, sc_hi[h * 2 + q]);
+                    const h16x8 bl = __builtin_bit_cast(h16x8, sc_lo[h * 2 + q]);
+                    h16x8 oh, ol;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float raw = k < 4 ? v0[k & 3] : v1[k & 3];
+                        const float sk = k < 4 ? s0[k & 3] : s1[k & 3];
+                        const float tk = k < 4 ? t0[k & 3] : t1[k & 3];
+                        const float scv = ((float)bh[k] + (float)bl[k]) * (1.f / SPLIT3_ASCALE);
+                        const float o = fmaxf(__builtin_fmaf(raw, sk, tk) + scv, 0.f) * SPLIT3_ASCALE;
+                        const _Float16 hh = (_Float16)o;
+                        oh[k] = hh;
+                        ol[k] = (_Float16)(o - (float)hh);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh), rsO, f_off[h * 2 + q], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), rsO, f_off[h * 2 + q],
+                                                           (int)e.f_out_lo, 0);
+                }
+            } else {
             f32x4 v[RH * CH / NTHR];
             unsigned off[RH * CH / NTHR];
             // thread te reads 16-byte chunk c = te % CH of local rows lr0 + RSTEP k, lr0 = te / CH < RSTEP: the row of
@@ -378,6 +457,7 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
 #pragma unroll
             for (int k = 0; k < RH * CH / NTHR; ++k)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[k]), rsY, off[k], 0, 0);
+            }
             ACIMG_STAMP_AT(11);                     // row reads + output stores issued
             if (h + 1 < HALVES) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -389,10 +469,10 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
         // the two wave rows' partials (written before the first barrier above) -> this row block's statistics row
         const int which = (int)(((unsigned)te / BN) & 1u), col = (int)((unsigned)te % BN);
         float sum = 0.f;
-        if (e.stats) sum = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col];
+        if (EPI != 2 && e.stats) sum = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col];
         {
             const int n = n0 + col;
-            const unsigned soff = (e.stats && te < 2 * BN && n < e.stats_ld)
+            const unsigned soff = (EPI != 2 && e.stats && te < 2 * BN && n < e.stats_ld)
                                       ? (unsigned)((((long)mt * 2 + which) * e.stats_ld + n) * 4) : OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), rsS, soff, 0, 0);
         }

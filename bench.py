@@ -242,7 +242,7 @@ def dominant_trunk_kernel(g, f16):
     elif len(tile) > 2 and tile[2] == 2:
         kernel_name = "igemm_split3r_kernel<%d>" % (tile[0] // 64)    # the ring kernel (TM = rows / 64)
     elif len(tile) > 2 and tile[2]:
-        kernel_name = "igemm_split3dp_kernel<32, 0, 3>"    # the persistent form of the 128x128 trunk kernel
+        kernel_name = "igemm_split3dp_kernel<32, 0, 3, 0>"    # the persistent form of the 128x128 trunk kernel
     else:
         kernel_name = "igemm_split3d_kernel<%d,%d,%s,2,2,3>" % (tile[0], tile[1], TILE_THREADS[tile[:2]])
     return probe_idx, flops, alg_bytes, kernel_name

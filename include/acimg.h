@@ -107,7 +107,9 @@ typedef struct AcimgConfig {
     int32_t trunk_stagger;   /* persistent kernel: start the second half of the grid this many percent of a tile's
                                 estimated time late (0 = together) */
     int32_t trunk_dma_pos;   /* persistent kernel: a K step's operand requests 0 = in one burst after the step barrier,
-                                1 = spread under the MFMA block (B after the first sweep, A after the second) */
+                                1 = spread under the MFMA block (B after the first sweep, A after the second)
+                                (requests TWO steps ahead - a second barrier after the fragment reads frees the stage
+                                early - were measured in round 3: 2.5 % slower over the trunk, removed) */
     int32_t trunk_ring;      /* 128-column trunk convs on the RING kernel (one workgroup per CU, three LDS slots, fragments
                                 double buffered in registers, requests spread between the MFMAs): 0 never, 1 where it was
                                 measured to pay, 2 always */
@@ -209,6 +211,22 @@ int acimg_conv2d_fwd_split3p(const AcimgConvDesc* d, const void* x_planes, size_
  * bits; everything else (arguments, tiling, statistics rows, workspace) is as for acimg_conv2d_fwd_split3p. */
 int acimg_conv2d_fwd_split1p(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
                              float* y, float* stats, void* ws, size_t ws_bytes, void* stream);
+/* The expanding 1x1 conv of an identity bottleneck unit in TWO PASSES, its raw output never stored (slim bottleneck,
+ * models/resnet50.py:104-125: out = relu(BN(conv3(x)) + shortcut), batch statistics): the conv is short-K and 4x wide,
+ * so its MFMA work is cheap and its output bytes are not.
+ *   acimg_conv2d_fwd_split3p_stats: the K loop and the batch-norm partials only (rows as acimg_conv2d_fwd_split3p's);
+ *   acimg_conv2d_fwd_split3p_tail:  the same tiles again with the layer's (scale, shift) from acimg_bn_finalize:
+ *                                   relu(acc * scale + shift + shortcut) split into hi / lo planes in brick order;
+ *                                   `sc_planes` is a split-format tensor of the output's shape (the unit's input),
+ *                                   `out_planes` must not alias it.
+ * Both need 128x128 tiles (>= 200 of them), K % 128 == 0, ldy == ldw == K, outputs < 2 GiB; same units in the same
+ * order in both passes, so the statistics are those of exactly the values the second pass normalises.  Per output
+ * element 4 B read + 4 B written instead of 4 written + 8 read + 4 written by conv + acimg_bn_add_relu_split. */
+int acimg_conv2d_fwd_split3p_stats(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
+                                   float* stats, void* ws, size_t ws_bytes, void* stream);
+int acimg_conv2d_fwd_split3p_tail(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
+                                  const float* scale, const float* shift, const void* sc_planes, size_t sc_lo_off,
+                                  void* out_planes, size_t out_lo_off, void* ws, size_t ws_bytes, void* stream);
 size_t acimg_split_plane_bytes(long rows, int C);
 int acimg_bn_relu_split(const float* x, const float* scale, const float* shift, int relu, void* out,
                         size_t lo_off, long rows, int C, void* stream);

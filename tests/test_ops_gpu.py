@@ -1058,6 +1058,68 @@ def test_trunk_kernel_variants_agree(device, case):
         assert float((outs[name][0] - y0).abs().max()) <= 4e-6 * float(y0.abs().max()), name
 
 
+@pytest.mark.parametrize("case", [(32, 28, 38, 256, 1024), (8, 56, 75, 64, 256), (7, 28, 38, 128, 512), (32, 14, 19, 512, 2048)])
+def test_two_pass_conv3_equals_conv_then_bn_pass(device, case):
+    """conv3 of an identity unit in two passes (acimg_conv2d_fwd_split3p_stats: K loop + batch-norm partials, no output;
+    acimg_conv2d_fwd_split3p_tail: the same tiles with relu(acc * scale + shift + shortcut) + split in the epilogue)
+    against conv -> raw fp32 -> acimg_bn_add_relu_split on the same kernel form: the same partials and the same plane
+    bytes (same K order, same fma / add / max / split sequence); a row tail inside the last row tile; tickets at zero"""
+    from acimg import _lib, ops
+
+    N, H, W, Cc, K = case
+    g = torch.Generator().manual_seed(3 + Cc + K)
+    x = torch.rand(N, H, W, Cc, generator=g)
+    w = torch.randn(1, 1, Cc, K, generator=g) * (2.0 / Cc) ** 0.5
+    short = torch.rand(N, H, W, K, generator=g) * 2.0
+    scale = (torch.rand(K, generator=g) + 0.5).to(device)
+    shift = (torch.rand(K, generator=g) - 0.7).to(device)
+    d = ops.conv_desc(N, H, W, Cc, K, 1, 1, 1, "SAME")
+    rows = N * H * W
+    lo_x, lo_y = plane_bytes(rows, Cc), plane_bytes(rows, K)
+    plan = ops.Plan(device, eager=True)
+    xp = torch.zeros(lo_x * 2, dtype=torch.uint8, device=device)
+    ops.bn_relu_split(plan, x.to(device), torch.ones(Cc, device=device), torch.zeros(Cc, device=device), 1, xp, lo_x, rows, Cc)
+    sp = torch.zeros(lo_y * 2, dtype=torch.uint8, device=device)
+    ops.bn_relu_split(plan, short.to(device), torch.ones(K, device=device), torch.zeros(K, device=device), 1, sp, lo_y, rows, K)
+    wsplit = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=device)
+    ops.conv2d_split3_prepare(plan, d, w.to(device), wsplit)
+    tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=device)
+    try:
+        _lib.configure(trunk_persistent=2)          # the reference path on the same kernel form as the two passes
+        srows = ops.conv2d_fwd_split3p_stats_rows(d)
+        assert srows == -(-rows // 128)
+        y = torch.full((N, H, W, K), float("nan"), device=device)
+        st_ref = torch.full((srows, 2, K), float("nan"), device=device)
+        ops.conv2d_fwd_split3p(plan, d, xp, lo_x, wsplit, y, st_ref, tail_ws=tws)
+        ref = torch.zeros(lo_y * 2, dtype=torch.uint8, device=device)
+        ops.bn_add_relu_split(plan, y, scale, shift, None, None, None, sp, lo_y, ref, lo_y, None, N, H, W, K, H, W, 1)
+        st = torch.full((srows, 2, K), float("nan"), device=device)
+        out = torch.zeros(lo_y * 2, dtype=torch.uint8, device=device)
+        for _ in range(2):
+            ops.conv2d_fwd_split3p_stats(plan, d, xp, lo_x, wsplit, st, tail_ws=tws)
+            ops.conv2d_fwd_split3p_tail(plan, d, xp, lo_x, wsplit, scale, shift, sp, lo_y, out, lo_y, tail_ws=tws)
+        torch.cuda.synchronize()
+    finally:
+        _lib.configure()
+    assert int(tws[:4096].view(torch.int32).abs().sum()) == 0
+    assert torch.equal(st, st_ref)
+    # compare as values first (a clearer message than a byte mismatch), then the bytes
+    full = -(-rows // 16) * 16
+
+    def values(buf):
+        h = buf[:full * K * 2].view(torch.float16).float()
+        lo = buf[lo_y:lo_y + full * K * 2].view(torch.float16).float()
+        return (h + lo) * 4.0
+    va, vb = values(out), values(ref)
+    assert float((va - vb).abs().max()) <= 1e-6 * float(vb.abs().max()), float((va - vb).abs().max())
+    assert torch.equal(out[:full * K * 2], ref[:full * K * 2]) and torch.equal(out[lo_y:], ref[lo_y:])
+    # and against fp64
+    r64 = torch.relu(torch.einsum("nhwc,ck->nhwk", x.double(), w[0, 0].double()) * scale.cpu().double() + shift.cpu().double()
+                     + short.double())
+    got = unsplit(out, lo_y, rows, K)
+    close(got, r64.reshape(rows, K), tol=2e-6, what="two-pass conv3 vs fp64 %s" % (case,))
+
+
 @pytest.mark.parametrize("case", [(3, 14, 19, 64, 128), (2, 28, 38, 32, 160), (1, 56, 75, 32, 128), (5, 9, 79, 32, 128),
                                   (37, 5, 3, 32, 128), (200, 3, 1, 64, 128), (1, 1, 1, 32, 128), (2, 75, 56, 96, 256)])
 def test_halo_kernel_edges(device, case):
