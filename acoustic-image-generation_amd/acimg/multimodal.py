@@ -186,8 +186,10 @@ class _JointMLP(object):
             assert t.shape[:-1] == src.shape[:-1] and t.stride() == src.stride()
             assert t.storage_offset() == src.storage_offset() + off, "inputs must be consecutive channel slices"
             off += t.shape[-1]
-        assert off == ctot and ctot % 4 == 0, "the slices must cover the buffer; channels a multiple of 4"
-        self.cin, self.src = ctot, src
+        # (the joint step's 133 + 512 + 128 = 773 channels sit in a 776-wide buffer: the three pad channels are zeros and
+        #  meet zero rows of the padded first kernel)
+        assert up4(off) == ctot, "the slices must cover the buffer up to its padding to a multiple of 4 channels"
+        self.cin, self.src = off, src
         self._register(sess.store)
         rows = src.numel() // ctot
         self.rows = rows

@@ -107,9 +107,7 @@ class UNetAcNoConc(object):
         return ops.LazyPtr(lambda: st.g(self.scope + "/" + name))
 
     # ---- graph ------------------------------------------------------------------------------------------------
-    def _build_model(self, acoustic_images, mean2=None, std2=None, session=None, eps=None):
-        """acoustic_images: device buffer [N,36,48,12]; eps: device buffer [N,150].  UNetAcZ: mean2 / std2 are
-        views of ONE device buffer `ext` [N, 2*150] = [mean2 | std2] (pass the same tensor's halves)."""
+    def _alloc(self, acoustic_images, mean2=None, std2=None, session=None, eps=None):
         sess = session or get_default_session()
         self.session = sess
         self._register(sess.store)
@@ -144,8 +142,17 @@ class UNetAcNoConc(object):
         self.c51 = Act(z(N, H, W, 128), N, H, W, 128)
         self.conv5 = Act(z(N, H, W, 128), N, H, W, 128)
         self.yhat = Act(z(N, H, W, 12), N, H, W, 12)
-        self.plan_fwd = sess.new_plan()
+
+    def _build_model(self, acoustic_images, mean2=None, std2=None, session=None, eps=None):
+        """acoustic_images: device buffer [N,36,48,12]; eps: device buffer [N,150].  UNetAcZ: mean2 / std2 are
+        views of ONE device buffer `ext` [N, 2*150] = [mean2 | std2] (pass the same tensor's halves)."""
+        self._alloc(acoustic_images, mean2, std2, session, eps)
+        self.plan_fwd = self.session.new_plan()
         self._record_forward(self.plan_fwd)
+        self._publish()
+
+    def _publish(self):
+        sess, acoustic_images = self.session, self.images
         self.mean = self.heads_out[:, :Z]
         self.std = self.sigma
         self.output = self.yhat.t
@@ -177,17 +184,27 @@ class UNetAcNoConc(object):
             ops.conv2d_fwd(plan, d, x.ptr, self._P(name + "/kernel"), self._P(name + "/bias"), y.ptr)
 
     def _record_forward(self, plan):
-        N = self.N
         self._descs = {}
-        h, w = self.pool1.H, self.pool1.W
+        self._record_encoder(plan)
+        self._record_decoder(plan, self.conv2.t)
+
+    def _record_encoder(self, plan):
+        """models/unet_noconc2.py:48-64 (`_build_network`): acoustic image -> the 12x16x133 feature map `conv2`"""
         self._conv(plan, "layer1/conv_1", self.xpad, self.c11)
         self._conv(plan, "layer1/conv_2", self.c11, self.conv1)
         self._conv(plan, "layer1/pool_2", self.conv1, self.pool1, stride=3)
         self._conv(plan, "layer3/conv_1", self.pool1, self.c31)
         self._conv(plan, "layer3/conv_2", self.c31, self.conv2)
+
+    def _record_decoder(self, plan, feat):
+        """heads + latent + decoder from a feature map `feat` [N,12,16,136] (133 channels valid): the model's own `conv2`, or
+        - models/unet_noconc2.py:66-96, `_build_network2(f)` - the joint MLP's acoustic head"""
+        N = self.N
+        h, w = self.pool1.H, self.pool1.W
+        self.feat = feat
         kin = h * w * 136
         self.d_heads = ops.conv_desc(N, 1, 1, kin, 2 * Z, 1, 1, 1, "VALID", ldx=kin, ldy=2 * Z, ldw=2 * Z)
-        ops.conv2d_fwd(plan, self.d_heads, self.conv2.t, self._P("heads/kernel"), self._P("heads/bias"), self.heads_out)
+        ops.conv2d_fwd(plan, self.d_heads, feat, self._P("heads/kernel"), self._P("heads/bias"), self.heads_out)
         if self.EXTERNAL_Z:
             # own statistics are still produced (the associator trainers read them); z comes from outside
             self.own_kl = self.session.zeros(N)
@@ -208,10 +225,11 @@ class UNetAcNoConc(object):
         self._conv(plan, "final", self.conv5, self.yhat, act=ACT_SIGMOID)
 
     # ---- backward ---------------------------------------------------------------------------------------------
-    def record_backward(self, plan, g_logit, kl_weight):
+    def record_backward(self, plan, g_logit, kl_weight, stop_at_features=False):
         """g_logit: gradient w.r.t. the pre-sigmoid output; kl_weight: d loss / d kl[n].  UNetAcZ: the gradient
         w.r.t. the external statistics is left in `self.g_ext` [N, 300] (KL term of (mean2, std2) included) and the
-        encoder receives no gradient."""
+        encoder receives no gradient.  stop_at_features: the decoder was fed an outside feature map (`_record_decoder`):
+        d loss / d feat is left in `self.g_feat` [N,12,16,136], unmasked, and the encoder receives no gradient."""
         N = self.N
         z = self.session.zeros
         H, W, h, w = self.height, self.width, self.pool1.H, self.pool1.W
@@ -259,7 +277,12 @@ class UNetAcNoConc(object):
         g_heads = z(N, 2 * Z)
         ops.latent_bwd(plan, self.heads_out, self.eps, self.sigma, g_z, 152, kl_weight, g_heads, N, Z)
         g_conv2 = gbuf(self.conv2)
-        ops.conv2d_wgrad(plan, self.d_heads, self.conv2.t, g_heads, 2 * Z, self._G("heads/kernel"), self._G("heads/bias"))
+        ops.conv2d_wgrad(plan, self.d_heads, self.feat, g_heads, 2 * Z, self._G("heads/kernel"), self._G("heads/bias"))
+        if stop_at_features:
+            ops.conv2d_dgrad(plan, self.d_heads, g_heads, 2 * Z, self._P("heads/kernel"), g_conv2.t)
+            self.g_feat = g_conv2.t
+            self._grad_bufs.update(g_heads=g_heads)
+            return
         ops.conv2d_dgrad(plan, self.d_heads, g_heads, 2 * Z, self._P("heads/kernel"), g_conv2.t, None, 0,
                          self.conv2.t, h * w * 136)        # ReLU mask of conv2, viewed as one 12*16*136-channel pixel
         g_c31, g_pool1, g_conv1, g_c11 = gbuf(self.c31), gbuf(self.pool1), gbuf(self.conv1), gbuf(self.c11)

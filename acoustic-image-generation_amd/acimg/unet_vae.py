@@ -163,7 +163,7 @@ class UNetVAE(object):
                     state["%s/%s/moving_variance" % (s, bn)] = torch.ones(cout)
                 elif kind == "heads":
                     kh, kw, cin, cout = shape
-                    for h in ("mean", "variance"):
+                    for h in self.HEAD_NAMES:
                         state["%s/%s/kernel" % (s, h)] = xav(shape, kh * kw * cin, kh * kw * cout)
                         state["%s/%s/bias" % (s, h)] = torch.zeros(cout)
                 elif kind == "dense":

@@ -371,3 +371,32 @@ def test_plan_side_lane_bookkeeping():
     e.add_hook(lambda: None, "join")
     e.add("z", lambda *args: 0, 1)
     assert e.shared_calls() == {2, 3}
+
+
+def test_joint_oracle_tables_reduce_to_the_12x16_feature_map():
+    """oracle/joint.py: the three split VAEs of trainermulti.py — parameter inventories (UNetSound22 14.7 M, UNetAc2 9.32 M =
+    SURVEY A.3's unet_noconc, Unet2's heads 2 x 12*16*512*1024) and, for the two small models, one forward pass: the
+    encoders reduce their inputs to 12x16, the decoders return to the input size, losses compose as trainermulti.py:58-81"""
+    import torch
+    from oracle import joint
+
+    n = {m: sum(int(torch.tensor(s).prod()) for s in joint.param_shapes(m).values()) for m in joint.MODELS}
+    assert n["UNetAc2"] == 9317700 and n["UNetSound22"] == 14716449 and n["Unet2"] == 221621699
+    assert joint.param_shapes("Unet2")["UNet/mean/kernel"] == (12, 16, 512, 1024)
+    assert joint.is_encoder_var("UNetSound22", "UNetAudio/layer4/pool_2/kernel")
+    assert not joint.is_encoder_var("UNetSound22", "UNetAudio/layer6/conv_1/kernel")
+    g = torch.Generator().manual_seed(3)
+    for model in ("UNetAc2", "UNetSound22"):
+        cfg = joint.MODELS[model]
+        p = joint.init_params(model, seed=5)
+        net = joint._Net(model, p, True)
+        x = torch.rand(1, cfg["input_hw"][0], cfg["input_hw"][1], cfg["cin"], generator=g)
+        f = net.encoder(x)
+        assert tuple(f.shape) == (1, 12, 16, joint.feature_channels(model))
+        out = net.decoder(f, torch.randn(1, cfg["Z"], generator=g))
+        assert tuple(out["output"].shape) == tuple(x.shape) and float(out["std"].min()) > 0
+        if cfg["bn"]:
+            assert len(net.new_stats) == 2 * sum(1 for k in p if k.endswith("gamma"))
+            assert float(joint.regulariser(model, p)) > 0
+        else:
+            assert not net.new_stats and joint.regulariser(model, p) == 0.0

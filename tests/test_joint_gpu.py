@@ -1,0 +1,92 @@
+"""The joint-latent step of trainer/trainermulti.py:32-96: `Unet2`, `UNetSound22`, `UNetAc2` encoders ->
+`Jointmvae` -> the three decoders; losses, reconstructions, features, every gradient of the fusion MLP, the batch-norm
+moving averages and the Adam step against the CPU oracle (oracle/joint.py), through the C ABI; only `Jointmvae/` moves."""
+import os
+import sys
+from collections import OrderedDict
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "acoustic-image-generation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _device_masks(tr):
+    """ReLU on / off patterns of the device step, by oracle layer name (both sides then differentiate the same
+    piecewise-linear function; see oracle/unet_vae.py `forward`)"""
+    g = tr.primary
+    masks = OrderedDict()
+    for key, (m, _, _) in g.mods.items():
+        mm = OrderedDict()
+        if hasattr(m, "layers"):                       # conv-BN-ReLU models: every layer's output buffer
+            for name, L in m.layers.items():
+                mm[name] = (L.y.t.view(L.y.N, L.y.H, L.y.W, -1)[..., L.y.off:L.y.off + L.y.C] > 0).cpu()
+            mm["dense"] = (m.dns1 > 0).cpu()
+            mm["conv2d"] = (m.c2d.t > 0).cpu()
+        else:                                          # the acoustic model: plain conv + ReLU
+            for name, a in (("layer1/conv_1", m.c11), ("layer1/conv_2", m.conv1), ("layer1/pool_2", m.pool1),
+                            ("layer3/conv_1", m.c31), ("layer3/conv_2", m.conv2), ("conv2d", m.net),
+                            ("layer4/conv_1", m.c41), ("layer4/conv_2", m.conv4), ("layer5/conv_1", m.c51),
+                            ("layer5/conv_2", m.conv5)):
+                mm[name] = (a.t.view(a.N, a.H, a.W, -1)[..., :a.C] > 0).cpu()
+            mm["dense"] = (m.dns.t > 0).cpu().reshape(m.N, -1)
+        masks[key] = mm
+    ma = tr.modelassociator
+    masks["joint"] = OrderedDict((name, (y[:, :d.K] > 0).cpu().view(g.N, 12, 16, d.K)) for name, d, x, ldx, y, attr in ma.layers)
+    return masks
+
+
+def test_joint_step_matches_oracle():
+    from acimg.multimodal import Jointmvae
+    from acimg.session import Session
+    from acimg.trainer_multi import TrainerMulti
+    from acimg.unet_joint import UNetAc2, UNetSound22, Unet2
+    from oracle import joint
+
+    dev = torch.device("cuda:0")
+    N = 2
+    orc = joint.Oracle(learning_rate=1e-3)
+    sess = Session(dev)
+    tr = TrainerMulti(UNetAc2([36, 48, 12]), UNetSound22([193, 257, 1]), Unet2([224, 298, 3]), Jointmvae(),
+                      learning_rate=1e-3, session=sess)
+    g = tr._build_functions(batch_size=N)
+    sess.store.load_state(orc.state_dict(), strict=True)
+    before = {k: v.clone() for k, v in sess.store.state_dict().items()}
+    batch, eps = joint.synthetic_batch(N)
+    got = tr.train_step((batch["ac"], batch["audio"], batch["video"]), eps=eps, apply=False)
+    torch.cuda.synchronize()
+    masks = _device_masks(tr)
+    ref = orc.train_step(batch, eps, apply=True, relu_masks=masks)
+    for k in ("mse_ac", "huber_ac", "mse_video", "huber_video", "mse_audio", "huber_audio", "latent", "reg", "loss"):
+        assert abs(got[k] - ref["losses"][k]) <= 1e-3 * abs(ref["losses"][k]) + 1e-12, (k, got[k], ref["losses"][k])
+    for key, (m, _, attr) in g.mods.items():
+        assert rel(m.features, ref["feats"][key]) < 1e-3, key
+        assert rel(getattr(tr.modelassociator, attr), ref["heads"][attr]) < 1e-3, attr
+        assert rel(m.output[..., :m.channels], ref["outs"][key]["output"]) < 1e-3, key
+        assert rel(m.mean, ref["outs"][key]["mean"]) < 1e-3 and rel(m.std, ref["outs"][key]["std"]) < 1e-3, key
+    grads = sess.store.grad_dict()
+    worst = max((rel(grads[k], v), k) for k, v in ref["grads"].items())
+    print("worst Jointmvae gradient %s %.2e" % (worst[1], worst[0]))
+    assert worst[0] < 1e-3, worst
+    # batch-norm moving averages follow the step (update_ops); now the Adam step: only Jointmvae/ moves
+    now = sess.store.state_dict()
+    for k, v in ref["new_stats"].items():
+        assert rel(now[k], v) < 1e-3, k
+    tr.train_step(None, eps=eps, apply=True)
+    torch.cuda.synchronize()
+    after = sess.store.state_dict()
+    oracle_after = orc.state_dict()
+    moved = [k for k in after if not torch.equal(after[k], before[k]) and not k.endswith(("moving_mean", "moving_variance"))]
+    assert moved and all(k.startswith("Jointmvae/") for k in moved), moved[:5]
+    for k in moved:
+        assert rel(after[k], oracle_after[k]) < 2e-3, k
