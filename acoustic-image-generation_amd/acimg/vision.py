@@ -407,8 +407,12 @@ class ResNet50Model(object):
         for the short-K / large-image units: 56x75 64->256 113 -> 84 us, 128->512 247 -> 192 us per unit, against
         28x38 256->1024 130 -> 144 and 14x19 512->2048 94 -> 121"""
         M = self.N * hw[0] * hw[1]
-        return (self.two_pass and self._terms == 3 and cin <= 128 and cout % 128 == 0
-                and -(-M // 128) * (cout // 128) >= 200 and M * cout * 4 < 2 ** 31)
+        if not (self.two_pass and self._terms == 3 and cin <= 128 and cout % 128 == 0 and M * cout * 4 < 2 ** 31):
+            return False
+        # the library's own tile choice for this shape under the current configuration (a forced experiment tile, or
+        # fewer than 200 tiles, takes the unit back to conv + bn_add_relu_split)
+        d = ops.conv_desc(self.N, hw[0], hw[1], cin, cout, 1, 1, 1, "SAME", ldx=cin, ldy=cout, ldw=cout)
+        return tuple(ops.conv2d_fwd_split3_tiling(d)[:2]) == (128, 128)
 
     def _record_forward_split(self, plan, training):
         """f16x3 trunk: activations between convs live in split format.  Per bottleneck unit:
