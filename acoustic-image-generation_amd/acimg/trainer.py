@@ -297,7 +297,8 @@ class Trainer(object):
         stages = []
         if g.stage_calls is not None:
             sc, src = g.head_calls + g.stage_calls, g.head_calls + g.stage_read_calls
-            assert full.calls[sc - 1][0] == "bn_add_relu_split"                          # ... the boundary tensor
+            # ... the boundary tensor (a two-pass unit writes it from conv3's second pass)
+            assert full.calls[sc - 1][0] in ("bn_add_relu_split", "conv2d_fwd_split3p_tail")
             stages.append(dict(parts=[(full.slice(lo, sc - 1), lo, None, None), (full.slice(sc - 1, sc), sc - 1, "x", None)],
                                stream=cur))
             stages.append(dict(parts=[(full.slice(sc, src), sc, None, "x"), (full.slice(src, cut - 1), src, None, None),

@@ -34,7 +34,7 @@ PLANE_SLACK = 2 * 15 * 2048 * 2 + 512   # a split-format plane ends on a whole 1
 class ResNet50Model(object):
 
     def __init__(self, input_shape=None, num_classes=None, precision="f16x3", stages=None, stage_cut=8, side_lane=True,
-                 two_pass=True):
+                 two_pass=True, two_pass_max_cin=128):
         """precision: arithmetic of the frozen trunk convs — "f16x3" (split-fp16 MFMA, fp32-class
         results, default), "f32" (exact-f32 MFMA) or "f16" (fp16 OPERAND STORAGE: the same data path, but the 52 trunk
         convs fetch and multiply only the hi fp16 plane of activations and weights — one MFMA per product, fp32
@@ -67,6 +67,7 @@ class ResNet50Model(object):
         # in its epilogue (ops.conv2d_fwd_split3p_stats / _tail) - instead of conv + bn_add_relu_split: the unit's widest
         # tensor never exists in fp32 (f16x3 only; units with a subsampled shortcut and the last unit keep the pass)
         self.two_pass = bool(two_pass) and precision == "f16x3"
+        self.two_pass_max_cin = int(two_pass_max_cin)       # widest conv3 INPUT that takes the two passes (measured: 128)
         self.num_classes = num_classes
         self.height = input_shape[0]
         self.width = input_shape[1]
@@ -407,7 +408,8 @@ class ResNet50Model(object):
         for the short-K / large-image units: 56x75 64->256 113 -> 84 us, 128->512 247 -> 192 us per unit, against
         28x38 256->1024 130 -> 144 and 14x19 512->2048 94 -> 121"""
         M = self.N * hw[0] * hw[1]
-        if not (self.two_pass and self._terms == 3 and cin <= 128 and cout % 128 == 0 and M * cout * 4 < 2 ** 31):
+        if not (self.two_pass and self._terms == 3 and cin <= self.two_pass_max_cin and cout % 128 == 0 and
+                M * cout * 4 < 2 ** 31):
             return False
         # the library's own tile choice for this shape under the current configuration (a forced experiment tile, or
         # fewer than 200 tiles, takes the unit back to conv + bn_add_relu_split)

@@ -82,6 +82,8 @@ def parse():
     ap.add_argument("--trunk-stages", type=int, default=0, choices=[0, 1, 2],
                     help="pipeline stages of the frozen trunk (0 = the model's default: 2 for the split-MFMA trunk)")
     ap.add_argument("--stage-cut", type=int, default=8, help="bottleneck units in trunk stage 1 (of 16)")
+    ap.add_argument("--two-pass-cin", type=int, default=128,
+                    help="conv3 of the identity units in two passes up to this many input channels (0 = never; 128 = measured)")
     ap.add_argument("--no-side-lane", action="store_true",
                     help="record the plans without the second HIP stream for weight gradients / projection shortcuts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -445,7 +447,8 @@ def main():
     sess = Session(dev)
     tr = Trainer(UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=args.num_skip, side_lane=side_lane),
                  ResNet50Model(input_shape=[224, 298, 3], num_classes=None, precision=args.precision,
-                               stages=args.trunk_stages or None, stage_cut=args.stage_cut, side_lane=side_lane),
+                               stages=args.trunk_stages or None, stage_cut=args.stage_cut, side_lane=side_lane,
+                               two_pass=args.two_pass_cin > 0, two_pass_max_cin=args.two_pass_cin),
                  learning_rate=1e-4, session=sess)
     g = tr._build_functions(batch_size=B)
     tr.modelimages.initialize(seed=1238)
