@@ -165,7 +165,8 @@ def load_traffic_profile(kernel_name):
     if not files:
         return None
     f = files[-1]
-    out = {"file": os.path.relpath(f, ROOT), "commit": None, "step_bytes": None, "kernel_bytes_per_launch": None}
+    out = {"file": os.path.relpath(f, ROOT), "commit": None, "step_bytes": None, "steady_bytes": None,
+           "kernel_bytes_per_launch": None}
     want = kernel_name.replace(" ", "")
     for ln in open(f):
         m = re.match(r"commit (\S+)", ln)
@@ -174,6 +175,9 @@ def load_traffic_profile(kernel_name):
         m = re.match(r"total ([0-9.]+) GB/step", ln)
         if m:
             out["step_bytes"] = float(m.group(1)) * 1e9
+        m = re.search(r"steady-state step ([0-9.]+) GB", ln)
+        if m:
+            out["steady_bytes"] = float(m.group(1)) * 1e9
         m = re.match(r"(.+?)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", ln)
         if m and m.group(1).replace(" ", "") == want:
             out["kernel_bytes_per_launch"] = (float(m.group(3)) + float(m.group(4))) * 1e6
@@ -601,6 +605,8 @@ def main():
                        # 0.45 GB algorithmic per image with fp32 trunk activations
                        "alg_bytes": 0.45e9 * B,
                        "hbm_bytes": sb, "traffic_ratio": (sb / (0.45e9 * B)) if sb else None,
+                       # without the profiled process's one-time dispatches (torch fills of the arenas, trunk weight images)
+                       "hbm_bytes_steady": prof["steady_bytes"] if sb else None,
                        "hbm_GBps": (sb / (dt / args.steps) / 1e9) if sb else None,
                        "hbm_frac": (sb / (dt / args.steps) / 8.0e12) if sb else None,
                        "hbm_source": prof["file"] if sb else None, "hbm_commit": prof["commit"] if sb else None,
