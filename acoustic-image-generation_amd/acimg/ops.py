@@ -528,6 +528,14 @@ def conv2d_fwd_split3p_tail(plan, d, x_planes, x_lo_off, wsplit, scale, shift, s
              scale, shift, sc_planes, int(sc_lo_off), out_planes, int(out_lo_off), tail_ws, int(nbytes), side=side)
 
 
+def conv2d_fwd_split3p_tail_proj(plan, d, x_planes, x_lo_off, wsplit, scale, shift, sc32, sc_scale, sc_shift, out_planes,
+                                 out_lo_off, tail_ws=None, side=False):
+    """second pass of a unit with a projection shortcut (acimg_conv2d_fwd_split3p_tail_proj)"""
+    nbytes = 0 if tail_ws is None else (tail_ws.numel() * tail_ws.element_size() if hasattr(tail_ws, "numel") else 0)
+    plan.add("conv2d_fwd_split3p_tail_proj", _L().acimg_conv2d_fwd_split3p_tail_proj, C.byref(d), x_planes, int(x_lo_off),
+             wsplit, scale, shift, sc32, sc_scale, sc_shift, out_planes, int(out_lo_off), tail_ws, int(nbytes), side=side)
+
+
 def bn_relu_split(plan, x, scale, shift, relu, out, lo_off, rows, Cn):
     plan.add("bn_relu_split", _L().acimg_bn_relu_split, x, scale, shift, int(relu), out, int(lo_off), int(rows), Cn)
 

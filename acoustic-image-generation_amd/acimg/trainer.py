@@ -298,7 +298,7 @@ class Trainer(object):
         if g.stage_calls is not None:
             sc, src = g.head_calls + g.stage_calls, g.head_calls + g.stage_read_calls
             # ... the boundary tensor (a two-pass unit writes it from conv3's second pass)
-            assert full.calls[sc - 1][0] in ("bn_add_relu_split", "conv2d_fwd_split3p_tail")
+            assert full.calls[sc - 1][0] in ("bn_add_relu_split", "conv2d_fwd_split3p_tail", "conv2d_fwd_split3p_tail_proj")
             stages.append(dict(parts=[(full.slice(lo, sc - 1), lo, None, None), (full.slice(sc - 1, sc), sc - 1, "x", None)],
                                stream=cur))
             stages.append(dict(parts=[(full.slice(sc, src), sc, None, "x"), (full.slice(src, cut - 1), src, None, None),

@@ -358,10 +358,12 @@ class ResNet50Model(object):
                         P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, BN_DECAY, BN_EPS, training, side=side)
         return d.OH, d.OW, sc, sh
 
-    def _conv3_two_pass(self, plan, scope, xplanes, hw, cin, cout, sc_planes, out_planes, training, tag=""):
-        """conv3 of an identity unit without its raw output (include/acimg.h, acimg_conv2d_fwd_split3p_stats / _tail):
+    def _conv3_two_pass(self, plan, scope, xplanes, hw, cin, cout, sc_planes, out_planes, training, tag="", proj=None):
+        """conv3 of a unit without its raw output (include/acimg.h, acimg_conv2d_fwd_split3p_stats / _tail / _tail_proj):
         [statistics pass ->] bn_finalize -> the conv again with relu(BN + shortcut) + split in the epilogue.  In inference
-        mode the affine comes from the moving statistics and the first pass is not needed."""
+        mode the affine comes from the moving statistics and the first pass is not needed.  proj = (raw fp32 output of the
+        unit's shortcut conv, its scale, its shift) for a unit with a projection shortcut, else the identity shortcut is
+        read from `sc_planes`."""
         st = self.session.store
         P = lambda n: ops.LazyPtr(lambda n=n: st.p(n))  # noqa: E731
         d = ops.conv_desc(self.N, hw[0], hw[1], cin, cout, 1, 1, 1, "SAME", ldx=cin, ldy=cout, ldw=cout)
@@ -399,8 +401,12 @@ class ResNet50Model(object):
         ops.bn_finalize(plan, stats if training else None, rows if training else 0, cout, up4(cout),
                         self.N * hw[0] * hw[1] if training else 0, P(b + "gamma"), P(b + "beta"),
                         P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, BN_DECAY, BN_EPS, training)
-        ops.conv2d_fwd_split3p_tail(plan, d, xplanes, lo, wsplit, sc, sh, sc_planes, lo_out, out_planes, lo_out,
-                                    tail_ws=tail_ws)
+        if proj is not None:
+            ops.conv2d_fwd_split3p_tail_proj(plan, d, xplanes, lo, wsplit, sc, sh, proj[0], proj[1], proj[2], out_planes,
+                                             lo_out, tail_ws=tail_ws)
+        else:
+            ops.conv2d_fwd_split3p_tail(plan, d, xplanes, lo, wsplit, sc, sh, sc_planes, lo_out, out_planes, lo_out,
+                                        tail_ws=tail_ws)
 
     def _two_pass_ok(self, hw, cin, cout):
         """measured per shape at batch 32 (profiles/r03/op_report_two_pass_all_r03u.txt): the statistics pass costs 85-95 %
@@ -463,9 +469,18 @@ class ResNet50Model(object):
                 nxt_out = self.planes_x          # the last unit of stage 1 writes the boundary tensor
             else:
                 nxt_out = nxt
-            if din == d and s == 1 and not last and self._two_pass_ok((oh2, ow2), db, d):
-                # identity unit: conv3 twice, the raw [N, oh, ow, d] tensor and its BN pass never exist
-                self._conv3_two_pass(plan, scope + "/conv3", p2, (oh2, ow2), db, d, cur, nxt_out, training, tag=tag)
+            if s == 1 and not last and self._two_pass_ok((oh2, ow2), db, d):
+                # conv3 twice: the raw [N, oh, ow, d] tensor and its BN pass never exist
+                proj = None
+                if din != d:
+                    if beside:
+                        plan.join()
+                    else:
+                        _, _, ssc, tsc = self._conv_bn_planes(plan, scope + "/shortcut", cur, (h, w), din, 1, 1, d, s,
+                                                              "SAME", asc, training, tag=tag)
+                    proj = (asc, ssc, tsc)
+                self._conv3_two_pass(plan, scope + "/conv3", p2, (oh2, ow2), db, d, cur, nxt_out, training, tag=tag,
+                                     proj=proj)
                 h, w = oh2, ow2
                 if two and i == self.STAGE_CUT and training:
                     self.stage_read_calls = len(plan.calls)

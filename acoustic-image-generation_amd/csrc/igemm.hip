@@ -1861,13 +1861,16 @@ size_t acimg_conv2d_fwd_split3p_workspace(const AcimgConvDesc* d) {
 
 // the two passes of a conv whose raw output never reaches memory (igemm_split3dp_kernel, EPI 1 / 2)
 struct Split3pTail {
-    int mode;                      // 1: statistics only; 2: relu(acc * scale + shift + shortcut) -> split planes
+    int mode;                      // 1: statistics only; 2: relu(acc * scale + shift + shortcut) -> split planes;
+                                   // 3: the same with a projection shortcut (raw fp32 + its own scale / shift)
     const float* scale;
     const float* shift;
-    const void* sc_planes;
+    const void* sc_planes;         // mode 3: the fp32 [M][K] output of the shortcut conv
     size_t sc_lo_off;
     void* out_planes;
     size_t out_lo_off;
+    const float* scale2;
+    const float* shift2;
 };
 
 static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit, float* y,
@@ -1922,8 +1925,9 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
             return fail(ACIMG_EINVAL, "conv2d_fwd_split3p (two-pass): needs 128x128 tiles, K %% 128 == 0, dense output < 2 GiB");
         const size_t lds_t = (size_t)2 * 4 * 128 * 64 + 4 * 2 * 128 * 4;
         const void* ft = tail->mode == 1 ? (const void*)igemm_split3dp_kernel<32, 0, 3, 1>
-                                         : (const void*)igemm_split3dp_kernel<32, 0, 3, 2>;
-        const int Pt = resident_slots(tail->mode == 1 ? 8 : 9, ft, 512, lds_t);
+                       : tail->mode == 2 ? (const void*)igemm_split3dp_kernel<32, 0, 3, 2>
+                                         : (const void*)igemm_split3dp_kernel<32, 0, 3, 3>;
+        const int Pt = resident_slots(7 + tail->mode, ft, 512, lds_t);
         TailPlan tt{T, 1, 0};
         if (ws && ws_bytes >= acimg_conv2d_fwd_split3p_workspace(d)) tt = pick_tail(T, Pt, p.kiters, TS_MAX_UNITS);
         p.ts_whole = tt.whole; p.ts_s = tt.s;
@@ -1937,16 +1941,24 @@ static int fwd_presplit(const AcimgConvDesc* d, const void* x_planes, size_t x_l
             return check_launch("conv2d_fwd_split3p_stats");
         }
         const long oplane = (long)acimg_split_plane_bytes((long)p.M, d->K);
-        if (!aligned16(tail->sc_planes) || !aligned16(tail->out_planes) || (tail->sc_lo_off & 15) || (tail->out_lo_off & 15) ||
-            (long)tail->sc_lo_off < oplane || (long)tail->out_lo_off < oplane ||
-            (long)tail->sc_lo_off + oplane >= (1L << 31) || (long)tail->out_lo_off + oplane >= (1L << 31))
+        if (!aligned16(tail->sc_planes) || !aligned16(tail->out_planes) || (tail->out_lo_off & 15) ||
+            (long)tail->out_lo_off < oplane || (long)tail->out_lo_off + oplane >= (1L << 31))
             return fail(ACIMG_EINVAL, "conv2d_fwd_split3p_tail: unaligned / overlapping / >= 2 GiB split-format operands");
         e.Y = nullptr; e.stats = nullptr;
         e.f_scale = tail->scale; e.f_shift = tail->shift;
-        e.f_sc = static_cast<const char*>(tail->sc_planes); e.f_sc_lo = (unsigned)tail->sc_lo_off;
-        e.f_sc_bytes = (unsigned)(tail->sc_lo_off + oplane);
+        e.f_sc = static_cast<const char*>(tail->sc_planes);
         e.f_out = static_cast<char*>(tail->out_planes); e.f_out_lo = (unsigned)tail->out_lo_off;
         e.f_out_bytes = (unsigned)(tail->out_lo_off + oplane);
+        if (tail->mode == 3) {
+            e.f_scale2 = tail->scale2; e.f_shift2 = tail->shift2;
+            e.f_sc_lo = 0; e.f_sc_bytes = (unsigned)((long)p.M * d->K * 4);      // < 2 GiB: big_out was refused above
+            hipLaunchKernelGGL((igemm_split3dp_kernel<32, 0, 3, 3>), dim3(nwg), dim3(512), lds_t, st, p, units, nwg);
+            return check_launch("conv2d_fwd_split3p_tail_proj");
+        }
+        if ((tail->sc_lo_off & 15) || (long)tail->sc_lo_off < oplane || (long)tail->sc_lo_off + oplane >= (1L << 31))
+            return fail(ACIMG_EINVAL, "conv2d_fwd_split3p_tail: unaligned / overlapping / >= 2 GiB shortcut planes");
+        e.f_sc_lo = (unsigned)tail->sc_lo_off;
+        e.f_sc_bytes = (unsigned)(tail->sc_lo_off + oplane);
         hipLaunchKernelGGL((igemm_split3dp_kernel<32, 0, 3, 2>), dim3(nwg), dim3(512), lds_t, st, p, units, nwg);
         return check_launch("conv2d_fwd_split3p_tail");
     }
@@ -2058,7 +2070,7 @@ int acimg_conv2d_fwd_split1p(const AcimgConvDesc* d, const void* x_planes, size_
 int acimg_conv2d_fwd_split3p_stats(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
                                    float* stats, void* ws, size_t ws_bytes, void* stream) {
     if (!stats) return fail(ACIMG_EINVAL, "conv2d_fwd_split3p_stats: null statistics buffer");
-    const Split3pTail t{1, nullptr, nullptr, nullptr, 0, nullptr, 0};
+    const Split3pTail t{1, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr};
     return fwd_presplit(d, x_planes, x_lo_off, wsplit, nullptr, stats, ws, ws_bytes, stream, 3, &t);
 }
 
@@ -2067,7 +2079,18 @@ int acimg_conv2d_fwd_split3p_tail(const AcimgConvDesc* d, const void* x_planes, 
                                   void* out_planes, size_t out_lo_off, void* ws, size_t ws_bytes, void* stream) {
     if (!scale || !shift || !sc_planes || !out_planes || !aligned16(scale) || !aligned16(shift))
         return fail(ACIMG_EINVAL, "conv2d_fwd_split3p_tail: null / unaligned scale, shift, shortcut or output");
-    const Split3pTail t{2, scale, shift, sc_planes, sc_lo_off, out_planes, out_lo_off};
+    const Split3pTail t{2, scale, shift, sc_planes, sc_lo_off, out_planes, out_lo_off, nullptr, nullptr};
+    return fwd_presplit(d, x_planes, x_lo_off, wsplit, nullptr, nullptr, ws, ws_bytes, stream, 3, &t);
+}
+
+int acimg_conv2d_fwd_split3p_tail_proj(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
+                                       const float* scale, const float* shift, const float* sc32, const float* sc_scale,
+                                       const float* sc_shift, void* out_planes, size_t out_lo_off, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    if (!scale || !shift || !sc32 || !sc_scale || !sc_shift || !out_planes || !aligned16(scale) || !aligned16(shift) ||
+        !aligned16(sc_scale) || !aligned16(sc_shift))
+        return fail(ACIMG_EINVAL, "conv2d_fwd_split3p_tail_proj: null / unaligned scale, shift, shortcut or output");
+    const Split3pTail t{3, scale, shift, sc32, 0, out_planes, out_lo_off, sc_scale, sc_shift};
     return fwd_presplit(d, x_planes, x_lo_off, wsplit, nullptr, nullptr, ws, ws_bytes, stream, 3, &t);
 }
 

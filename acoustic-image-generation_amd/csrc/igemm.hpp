@@ -31,6 +31,9 @@ struct EpiParams {
     const char* f_sc;
     char* f_out;
     unsigned f_sc_bytes, f_sc_lo, f_out_bytes, f_out_lo;
+    // EPI 3 (projection shortcut): f_sc is the raw fp32 [M][Nstore] output of the shortcut conv, normalised by these
+    const float* f_scale2;
+    const float* f_shift2;
 };
 
 // C[m][n] = sum_k A(m,k) * B(k,n);  A gathered from an NHWC tensor (im2col on the fly).

@@ -98,6 +98,8 @@ __device__ __forceinline__ KCursorP kcursor_next(KCursorP k, int C, int S) {
 //      from the previous unit's planes.  Per wide element 4 B read + 4 B written instead of 4 written + (4 + 4 read,
 //      4 written) by conv + bn_add_relu_split; the price is the conv's K loop twice.
 //      Both passes run the same units in the same order: the statistics are those of exactly the values normalised.
+//   3: as 2 for a unit with a PROJECTION shortcut: the shortcut is the raw fp32 output of the unit's 1x1 shortcut conv
+//      with a batch norm of its own: relu(acc * scale + shift + (sc32 * scale2 + shift2)).
 template <int BK, int DPOS, int TERMS = 3, int EPI = 0>
 __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(const IgemmParams p, const int n_units,
                                                                                const int stride_units) {
@@ -327,31 +329,44 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
         // EPI 2: the shortcut chunks of this thread's items (2 passes x 2 bricks per wave x hi / lo), requested before
         // anything else of the epilogue; item (h, q): brick q of the wave in pass h = pixel group (wave >> 1) of the pass,
         // channel group 2 (wave & 1) + q; lane l = pixel row l >> 2, physical 16-byte chunk l & 3 of the brick
-        u32x4 sc_hi[EPI == 2 ? 4 : 1], sc_lo[EPI == 2 ? 4 : 1];
-        unsigned f_off[EPI == 2 ? 4 : 1];
-        if constexpr (EPI == 2) {
+        constexpr bool FUSED = EPI == 2 || EPI == 3;
+        u32x4 sc_hi[FUSED ? 4 : 1], sc_lo[FUSED ? 4 : 1];      // EPI 2: hi / lo chunks; EPI 3: the two fp32 chunks
+        unsigned f_off[FUSED ? 4 : 1];
+        if constexpr (FUSED) {
             const __amdgpu_buffer_rsrc_t rsC =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(e.f_sc), 0, e.f_sc_bytes, 0x00020000);
             const unsigned CQ = (unsigned)e.Nstore >> 5;
             const int pg = e_wid >> 1;
+            const unsigned kc_e = (((unsigned)e_lane & 3u) ^ (0u - ((unsigned)e_lane >> 4))) & 3u;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int trow = (pg >> 1) * WTM + h * WH + (pg & 1) * 16;        // first tile row of the pixel group
                     const int m = m0 + trow + (e_lane >> 2);
-                    const unsigned cg = (unsigned)(n0 >> 5) + 2u * (unsigned)(e_wid & 1) + (unsigned)q;
+                    const unsigned cgl = 2u * (unsigned)(e_wid & 1) + (unsigned)q;   // channel group inside the tile
+                    const unsigned cg = (unsigned)(n0 >> 5) + cgl;
                     const unsigned off = (((unsigned)(m0 + trow) >> 4) * CQ + cg) * 1024u + (unsigned)e_lane * 16u;
                     f_off[h * 2 + q] = m < e.M ? off : OOB;
-                    sc_hi[h * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rsC, f_off[h * 2 + q], 0, 0);
-                    sc_lo[h * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rsC, f_off[h * 2 + q], (int)e.f_sc_lo, 0);
+                    if constexpr (EPI == 2) {
+                        sc_hi[h * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rsC, f_off[h * 2 + q], 0, 0);
+                        sc_lo[h * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rsC, f_off[h * 2 + q], (int)e.f_sc_lo, 0);
+                    } else {    // row-major fp32 [M][Nstore]: this lane's 8 channels n0 + cgl 32 + kc 8 .. + 7 of pixel m
+                        const unsigned o32 = m < e.M ? ((unsigned)m * (unsigned)e.Nstore + (unsigned)n0 + cgl * 32u + kc_e * 8u) * 4u
+                                                     : OOB;
+                        sc_hi[h * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rsC, o32, 0, 0);
+                        sc_lo[h * 2 + q] = __builtin_amdgcn_raw_buffer_load_b128(rsC, o32 + 16u, 0, 0);
+                    }
                 }
             if (te < 64) {      // this column tile's scale | shift -> red[0 .. 255] (read after the staging barrier)
                 const float* src = (te < 32 ? e.f_scale : e.f_shift) + n0 + (te & 31) * 4;
                 *reinterpret_cast<f32x4*>(red + te * 4) = *reinterpret_cast<const f32x4*>(src);
+            } else if (EPI == 3 && te < 128) {      // ... and the shortcut's -> red[256 .. 511]
+                const float* src = (te < 96 ? e.f_scale2 : e.f_shift2) + n0 + (te & 31) * 4;
+                *reinterpret_cast<f32x4*>(red + 2 * BN + (te - 64) * 4) = *reinterpret_cast<const f32x4*>(src);
             }
         }
-        if (EPI != 2 && e.stats) {
+        if (!FUSED && e.stats) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 f32x4 s1 = acc[0][j], s2 = acc[0][j] * acc[0][j];
@@ -395,7 +410,7 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             ACIMG_STAMP_AT(10);                     // barrier
-            if constexpr (EPI == 2) {
+            if constexpr (FUSED) {
                 // a wave turns two bricks of the pass (16 pixels x 32 channels each) into their hi / lo KiB: lane l takes
                 // the 8 channels of physical chunk l & 3 of pixel row l >> 2 (two 16-byte fp32 chunks of the staged
                 // tile), normalises, adds the shortcut, ReLU, 2^-2, splits; 64 lanes x 16 bytes = one contiguous KiB
@@ -414,21 +429,35 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
                     const f32x4 t1 = *reinterpret_cast<const f32x4*>(red + BN + cl + 4);
                     const h16x8 bh = __builtin_bit_cast(h16x8, sc_hi[h * 2 + q]);
                     const h16x8 bl = __builtin_bit_cast(h16x8, sc_lo[h * 2 + q]);
+                    const f32x4 r0 = __builtin_bit_cast(f32x4, sc_hi[h * 2 + q]);      // EPI 3: the same registers as fp32
+                    const f32x4 r1 = __builtin_bit_cast(f32x4, sc_lo[h * 2 + q]);
+                    f32x4 u0 = s0, u1 = s1, w0 = t0, w1 = t1;
+                    if constexpr (EPI == 3) {
+                        u0 = *reinterpret_cast<const f32x4*>(red + 2 * BN + cl);
+                        u1 = *reinterpret_cast<const f32x4*>(red + 2 * BN + cl + 4);
+                        w0 = *reinterpret_cast<const f32x4*>(red + 3 * BN + cl);
+                        w1 = *reinterpret_cast<const f32x4*>(red + 3 * BN + cl + 4);
+                    }
                     h16x8 oh, ol;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const float raw = k < 4 ? v0[k & 3] : v1[k & 3];
                         const float sk = k < 4 ? s0[k & 3] : s1[k & 3];
                         const float tk = k < 4 ? t0[k & 3] : t1[k & 3];
-                        const float scv = ((float)bh[k] + (float)bl[k]) * (1.f / SPLIT3_ASCALE);
+                        const float scv = EPI == 3 ? __builtin_fmaf(k < 4 ? r0[k & 3] : r1[k & 3], k < 4 ? u0[k & 3] : u1[k & 3],
+                                                                    k < 4 ? w0[k & 3] : w1[k & 3])
+                                                   : ((float)bh[k] + (float)bl[k]) * (1.f / SPLIT3_ASCALE);
                         const float o = fmaxf(__builtin_fmaf(raw, sk, tk) + scv, 0.f) * SPLIT3_ASCALE;
                         const _Float16 hh = (_Float16)o;
                         oh[k] = hh;
                         ol[k] = (_Float16)(o - (float)hh);
                     }
+                    // (the lo plane's distance goes into the VECTOR offset, not the scalar one: with a register in soffset the
+                    //  compiler's hazard recognizer - following the ISA manual - leaves no wait state between a 16-byte store
+                    //  and a VALU write of its data registers, and gfx950 was seen taking a register written one instruction
+                    //  after `buffer_store_dwordx4 v[a:a+3], v, s[..], sN offen` for the lanes it reads last)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh), rsO, f_off[h * 2 + q], 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), rsO, f_off[h * 2 + q],
-                                                           (int)e.f_out_lo, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol), rsO, f_off[h * 2 + q] + e.f_out_lo, 0, 0);
                 }
             } else {
             f32x4 v[RH * CH / NTHR];
@@ -469,10 +498,10 @@ __global__ __launch_bounds__(512, BK == 32 ? 4 : 2) void igemm_split3dp_kernel(c
         // the two wave rows' partials (written before the first barrier above) -> this row block's statistics row
         const int which = (int)(((unsigned)te / BN) & 1u), col = (int)((unsigned)te % BN);
         float sum = 0.f;
-        if (EPI != 2 && e.stats) sum = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col];
+        if (!FUSED && e.stats) sum = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col];
         {
             const int n = n0 + col;
-            const unsigned soff = (EPI != 2 && e.stats && te < 2 * BN && n < e.stats_ld)
+            const unsigned soff = (!FUSED && e.stats && te < 2 * BN && n < e.stats_ld)
                                       ? (unsigned)((((long)mt * 2 + which) * e.stats_ld + n) * 4) : OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), rsS, soff, 0, 0);
         }

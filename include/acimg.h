@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ACIMG_VERSION 204
+#define ACIMG_VERSION 205
 
 #define ACIMG_OK 0
 #define ACIMG_EINVAL (-1)     /* bad descriptor / shape / alignment */
@@ -227,6 +227,13 @@ int acimg_conv2d_fwd_split3p_stats(const AcimgConvDesc* d, const void* x_planes,
 int acimg_conv2d_fwd_split3p_tail(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
                                   const float* scale, const float* shift, const void* sc_planes, size_t sc_lo_off,
                                   void* out_planes, size_t out_lo_off, void* ws, size_t ws_bytes, void* stream);
+/* ... and of a unit with a PROJECTION shortcut (models/resnet50.py:112-118: shortcut = batch_norm(conv1x1(x))): `sc32` is the
+ * raw fp32 [rows][K] output of the shortcut conv, (sc_scale, sc_shift) its affine from acimg_bn_finalize:
+ * relu(acc * scale + shift + (sc32 * sc_scale + sc_shift)) -> split planes.  Same requirements as _tail. */
+int acimg_conv2d_fwd_split3p_tail_proj(const AcimgConvDesc* d, const void* x_planes, size_t x_lo_off, const void* wsplit,
+                                       const float* scale, const float* shift, const float* sc32, const float* sc_scale,
+                                       const float* sc_shift, void* out_planes, size_t out_lo_off, void* ws, size_t ws_bytes,
+                                       void* stream);
 size_t acimg_split_plane_bytes(long rows, int C);
 int acimg_bn_relu_split(const float* x, const float* scale, const float* shift, int relu, void* out,
                         size_t lo_off, long rows, int C, void* stream);

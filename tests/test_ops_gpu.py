@@ -1058,15 +1058,18 @@ def test_trunk_kernel_variants_agree(device, case):
         assert float((outs[name][0] - y0).abs().max()) <= 4e-6 * float(y0.abs().max()), name
 
 
-@pytest.mark.parametrize("case", [(32, 28, 38, 256, 1024), (8, 56, 75, 64, 256), (7, 28, 38, 128, 512), (32, 14, 19, 512, 2048)])
+@pytest.mark.parametrize("case", [(32, 28, 38, 256, 1024, 0), (8, 56, 75, 64, 256, 0), (7, 28, 38, 128, 512, 0),
+                                  (32, 14, 19, 512, 2048, 0), (8, 56, 75, 64, 256, 1), (7, 28, 38, 128, 512, 1)])
 def test_two_pass_conv3_equals_conv_then_bn_pass(device, case):
     """conv3 of an identity unit in two passes (acimg_conv2d_fwd_split3p_stats: K loop + batch-norm partials, no output;
     acimg_conv2d_fwd_split3p_tail: the same tiles with relu(acc * scale + shift + shortcut) + split in the epilogue)
     against conv -> raw fp32 -> acimg_bn_add_relu_split on the same kernel form: the same partials and the same plane
-    bytes (same K order, same fma / add / max / split sequence); a row tail inside the last row tile; tickets at zero"""
+    bytes (same K order, same fma / add / max / split sequence); a row tail inside the last row tile; tickets at zero.
+    Last case field 1: a PROJECTION shortcut (acimg_conv2d_fwd_split3p_tail_proj: raw fp32 shortcut conv output with its own
+    scale / shift) against the projection form of acimg_bn_add_relu_split"""
     from acimg import _lib, ops
 
-    N, H, W, Cc, K = case
+    N, H, W, Cc, K, proj = case
     g = torch.Generator().manual_seed(3 + Cc + K)
     x = torch.rand(N, H, W, Cc, generator=g)
     w = torch.randn(1, 1, Cc, K, generator=g) * (2.0 / Cc) ** 0.5
@@ -1092,12 +1095,20 @@ def test_two_pass_conv3_equals_conv_then_bn_pass(device, case):
         st_ref = torch.full((srows, 2, K), float("nan"), device=device)
         ops.conv2d_fwd_split3p(plan, d, xp, lo_x, wsplit, y, st_ref, tail_ws=tws)
         ref = torch.zeros(lo_y * 2, dtype=torch.uint8, device=device)
-        ops.bn_add_relu_split(plan, y, scale, shift, None, None, None, sp, lo_y, ref, lo_y, None, N, H, W, K, H, W, 1)
+        sc32 = (short - 1.0).to(device)
+        sb, tb = (torch.rand(K, generator=g) + 0.5).to(device), (torch.rand(K, generator=g) - 0.5).to(device)
+        if proj:
+            ops.bn_add_relu_split(plan, y, scale, shift, sc32, sb, tb, None, 0, ref, lo_y, None, N, H, W, K, H, W, 1)
+        else:
+            ops.bn_add_relu_split(plan, y, scale, shift, None, None, None, sp, lo_y, ref, lo_y, None, N, H, W, K, H, W, 1)
         st = torch.full((srows, 2, K), float("nan"), device=device)
         out = torch.zeros(lo_y * 2, dtype=torch.uint8, device=device)
         for _ in range(2):
             ops.conv2d_fwd_split3p_stats(plan, d, xp, lo_x, wsplit, st, tail_ws=tws)
-            ops.conv2d_fwd_split3p_tail(plan, d, xp, lo_x, wsplit, scale, shift, sp, lo_y, out, lo_y, tail_ws=tws)
+            if proj:
+                ops.conv2d_fwd_split3p_tail_proj(plan, d, xp, lo_x, wsplit, scale, shift, sc32, sb, tb, out, lo_y, tail_ws=tws)
+            else:
+                ops.conv2d_fwd_split3p_tail(plan, d, xp, lo_x, wsplit, scale, shift, sp, lo_y, out, lo_y, tail_ws=tws)
         torch.cuda.synchronize()
     finally:
         _lib.configure()
@@ -1114,8 +1125,9 @@ def test_two_pass_conv3_equals_conv_then_bn_pass(device, case):
     assert float((va - vb).abs().max()) <= 1e-6 * float(vb.abs().max()), float((va - vb).abs().max())
     assert torch.equal(out[:full * K * 2], ref[:full * K * 2]) and torch.equal(out[lo_y:], ref[lo_y:])
     # and against fp64
+    shortcut = ((short.double() - 1.0) * sb.cpu().double() + tb.cpu().double()) if proj else short.double()
     r64 = torch.relu(torch.einsum("nhwc,ck->nhwk", x.double(), w[0, 0].double()) * scale.cpu().double() + shift.cpu().double()
-                     + short.double())
+                     + shortcut)
     got = unsplit(out, lo_y, rows, K)
     close(got, r64.reshape(rows, K), tol=2e-6, what="two-pass conv3 vs fp64 %s" % (case,))
 
