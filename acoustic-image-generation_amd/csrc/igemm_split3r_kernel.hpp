@@ -351,8 +351,8 @@ __global__ __launch_bounds__(512, 2) void igemm_split3r_kernel(const IgemmParams
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsP, tid * 16,
-                                                       (i * TN + j) * NTHR * 16, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsP,
+                                                       ((i * TN + j) * NTHR + tid) * 16, 0, 16);     // (soffset 0: DESIGN 7d)
         // (`red` carries the flag below: a tail unit has at least two steps, so the statistics partials of the unit
         //  before it were flushed at the top of its first step)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
