@@ -1525,9 +1525,9 @@ static bool halo_applies(const AcimgConvDesc* d, int terms) {
     return ((d->W + 16) >> 4) + 8 + (d->W >> 4) + 1 <= HALO_NB;
 }
 static bool halo_on(const AcimgConvDesc* d, int terms) {
-    if (!g_cfg.trunk_halo || !halo_applies(d, terms)) return false;
-    if (g_cfg.trunk_halo == 2) return true;
-    return true;
+    // trunk_halo = 1 ("where it was measured to pay") selects nothing yet: at batch 32 the halo form is at parity with the
+    // per-tap kernels on the 56x75 / 28x38 layers and behind the ring kernel on 14x19; 2 = wherever it applies
+    return g_cfg.trunk_halo == 2 && halo_applies(d, terms);
 }
 
 // Ring kernel (igemm_split3r_kernel.hpp) for a pre-split trunk conv, and with how many tile rows: 0 = not on it.
