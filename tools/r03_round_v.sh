@@ -1,3 +1,4 @@
+# (historical: trunk_dma_pos 2 was measured with this script and then removed from the library - DESIGN 7d (3); configure now refuses it)
 # round 3: operand requests two steps ahead (trunk_dma_pos 2): parity, per-shape table, stats / tail passes
 set -e
 R=$GRAFT_REPO_ROOT
