@@ -17,6 +17,7 @@
 #include "igemm_split3dp_kernel.hpp"
 #include "igemm_split3r_kernel.hpp"
 #include "igemm_split3h_kernel.hpp"
+#include "skinny_kernel.hpp"
 #include <cstdlib>
 #include <algorithm>
 
@@ -1216,10 +1217,21 @@ int acimg_configure(const AcimgConfig* c) {
     return ACIMG_OK;
 }
 
+// a dense layer over at most 64 batch rows with a large weight matrix (csrc/skinny_kernel.hpp)
+static bool skinny_shape(const AcimgConvDesc* d) {
+    return d->R == 1 && d->S == 1 && d->H == 1 && d->W == 1 && d->OH == 1 && d->OW == 1 && d->stride == 1 &&
+           d->pad_t == 0 && d->pad_l == 0 && d->N <= 64 && d->C >= 4096 && (d->C & 3) == 0 && (d->K & 3) == 0 &&
+           (long)d->C * d->ldw * 4 < (1L << 31) && (long)d->N * d->ldx * 4 < (1L << 31);
+}
+static size_t skinny_fwd_ws_bytes(const AcimgConvDesc* d) {
+    return skinny_shape(d) ? (size_t)cdiv(d->C, SKINNY_KS) * d->N * d->K * 4 : 0;
+}
+
 size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d) {
     const size_t a = igemm_ws_bytes(d->N * d->OH * d->OW, d->K, fwd_kiters(d));
     const size_t b = d->C <= 16 && d->K <= 32 ? direct_ws_bytes(d->R, d->S, d->C, (d->K + 7) & ~7) : 0;
-    return a > b ? a : b;
+    const size_t c = skinny_fwd_ws_bytes(d);
+    return std::max(a, std::max(b, c));
 }
 
 int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
@@ -1228,6 +1240,25 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
     int rc = check_desc(d, "conv2d_fwd");
     if (rc) return rc;
     if (d->ldw < d->K) return fail(ACIMG_EINVAL, "conv2d_fwd: ldw < K");
+    if (skinny_shape(d) && !in_scale && !in_shift && !stats && ws && ws_bytes >= skinny_fwd_ws_bytes(d) && aligned16(x) &&
+        aligned16(w) && aligned16(y) && aligned16(ws) && (!bias || aligned16(bias)) && (d->ldw & 3) == 0 && (d->ldx & 3) == 0 &&
+        (d->ldy & 3) == 0) {
+        // the VAE heads' dense layer: weight rows read once in whole lines, K slabs combined in slab order
+        SkinnyParams q{};
+        q.W = w; q.X = x; q.out = y; q.bias = bias; q.act = d->act; q.part = static_cast<float*>(ws);
+        q.M = d->N; q.C = d->C; q.N = d->K; q.ldw = d->ldw; q.ldx = d->ldx; q.ldo = d->ldy;
+        q.slabs = cdiv(d->C, SKINNY_KS);
+        const dim3 grid(q.slabs, cdiv(d->K, 64));
+        const int mb = cdiv(d->N, 16);
+        if (mb == 1) hipLaunchKernelGGL(skinny_fwd_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, q);
+        else if (mb == 2) hipLaunchKernelGGL(skinny_fwd_kernel<2>, grid, dim3(64), 0, (hipStream_t)stream, q);
+        else if (mb == 3) hipLaunchKernelGGL(skinny_fwd_kernel<3>, grid, dim3(64), 0, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL(skinny_fwd_kernel<4>, grid, dim3(64), 0, (hipStream_t)stream, q);
+        rc = check_launch("conv2d_fwd (skinny)");
+        if (rc) return rc;
+        hipLaunchKernelGGL(skinny_fwd_reduce_kernel, dim3(cdiv(d->N * (d->K / 4), 256)), dim3(256), 0, (hipStream_t)stream, q);
+        return check_launch("conv2d_fwd (skinny reduce)");
+    }
     if (direct_ok(d->C, d->K, d->ldy, 0, y, bias, nullptr, in_scale != nullptr, nullptr) &&
         (long)d->N * d->OH * d->OW >= 65536) {
         DirectParams q{};
@@ -1288,6 +1319,21 @@ int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
     if (rc) return rc;
     const int ca = up4(d->K);
     if (ca > ldgy || ca > d->ldw || (ldgy & 3)) return fail(ACIMG_EINVAL, "conv2d_dgrad: padded K=%d exceeds ldgy=%d/ldw=%d", ca, ldgy, d->ldw);
+    if (skinny_shape(d) && aligned16(gy) && aligned16(w) && (d->ldw & 3) == 0) {
+        // a dense layer over a few batch rows (the 28 416 -> 300 VAE heads): the weight matrix is read once, in rows
+        SkinnyParams q{};
+        q.W = w; q.G = gy; q.out = dx; q.res = residual; q.mask = mask;
+        q.M = d->N; q.C = d->C; q.N = ca;
+        q.ldw = d->ldw; q.ldg = ldgy; q.ldo = lddx > 0 ? lddx : d->ldx; q.ldres = ldres; q.ldmask = ldmask;
+        if (q.ldo < d->C) return fail(ACIMG_EINVAL, "conv2d_dgrad: lddx < C");
+        const dim3 grid(cdiv(cdiv(d->C, 16), 4));
+        const int mb = cdiv(d->N, 16);
+        if (mb == 1) hipLaunchKernelGGL(skinny_dgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, q);
+        else if (mb == 2) hipLaunchKernelGGL(skinny_dgrad_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, q);
+        else if (mb == 3) hipLaunchKernelGGL(skinny_dgrad_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, q);
+        else hipLaunchKernelGGL(skinny_dgrad_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, q);
+        return check_launch("conv2d_dgrad (skinny)");
+    }
     IgemmParams p{};
     p.A = gy; p.C = ca; p.lda = ldgy;
     p.B = w; p.ldb = d->ldw;
@@ -1357,6 +1403,18 @@ int acimg_conv2d_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, 
     if (rc) return rc;
     const int kp = up4(d->K);
     if (kp > ldgy || kp > d->ldw) return fail(ACIMG_EINVAL, "conv2d_wgrad: padded K exceeds ldgy/ldw");
+    if (skinny_shape(d) && aligned16(x) && aligned16(gy) && aligned16(dw) && (d->ldw & 3) == 0 && (ldgy & 3) == 0 &&
+        (d->ldx & 3) == 0) {
+        // the same dense layer's weight gradient: every weight row is written once, 256 contiguous bytes per wave
+        SkinnyParams q{};
+        q.X = x; q.G = gy; q.out = dw; q.db = db;
+        q.M = d->N; q.C = d->C; q.N = kp;
+        q.ldw = d->ldw; q.ldg = ldgy; q.ldx = d->ldx;
+        const int ngroups = cdiv(kp, 64);
+        const int tasks = cdiv(d->C, 64) * ngroups;
+        hipLaunchKernelGGL(skinny_wgrad_kernel, dim3(cdiv(tasks, 4)), dim3(256), 0, (hipStream_t)stream, q, ngroups);
+        return check_launch("conv2d_wgrad (skinny)");
+    }
     WgradParams p{};
     p.X = x; p.H = d->H; p.W = d->W; p.C = d->C; p.ldx = d->ldx;
     p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;

@@ -1245,3 +1245,38 @@ def test_pipeline_lanes_are_measured(device):
     ops.set_side_lane(device, lanes[0], lanes[0])          # "no second lane" is a valid side lane
     with torch.cuda.stream(lanes[0]):
         assert ops.side_lane(device) == lanes[0]
+
+
+@pytest.mark.parametrize("case", [(32, 28416, 300), (5, 4096, 152), (64, 8192, 300), (17, 4100, 16)])
+def test_skinny_dense_gradients(device, case):
+    """the dense layers over a few batch rows (the 28 416 -> 300 VAE heads, models/unet_acresnet.py:73-76) take the
+    skinny kernels inside acimg_conv2d_fwd / _dgrad / _wgrad (csrc/skinny_kernel.hpp: the weight matrix read / written
+    once, exact-f32 MFMA): forward with bias (K slabs combined in slab order), data gradient with residual and ReLU mask,
+    weight and bias gradient vs fp64"""
+    from acimg import ops
+
+    M, Cc, K = case
+    g = torch.Generator().manual_seed(9 + M + K)
+    x = torch.rand(M, Cc, generator=g) - 0.3
+    w = torch.randn(Cc, K, generator=g) * 0.05
+    gy = torch.randn(M, K, generator=g)
+    res = torch.randn(M, Cc, generator=g)
+    d = ops.conv_desc(M, 1, 1, Cc, K, 1, 1, 1, "VALID", ldx=Cc, ldy=K, ldw=K)
+    plan = ops.Plan(device, eager=True)
+    dx = torch.full((M, Cc), float("nan"), device=device)
+    ops.conv2d_dgrad(plan, d, gy.to(device), K, w.to(device), dx, res.to(device), Cc, x.to(device), Cc)
+    dw = torch.full((Cc, K), float("nan"), device=device)
+    db = torch.full((K,), float("nan"), device=device)
+    ops.conv2d_wgrad(plan, d, x.to(device), gy.to(device), K, dw, db)
+    dx2 = torch.full((M, Cc), float("nan"), device=device)
+    ops.conv2d_dgrad(plan, d, gy.to(device), K, w.to(device), dx2)          # no residual, no mask
+    bias = torch.randn(K, generator=g)
+    y = torch.full((M, K), float("nan"), device=device)
+    ops.conv2d_fwd(plan, d, x.to(device), w.to(device), bias.to(device), y)
+    torch.cuda.synchronize()
+    close(y, x.double() @ w.double() + bias.double(), tol=2e-6, what="skinny forward %s" % (case,))
+    ref_dx = gy.double() @ w.double().t()
+    close(dx2, ref_dx, tol=2e-6, what="skinny dgrad %s" % (case,))
+    close(dx, (ref_dx + res.double()) * (x > 0).double(), tol=2e-6, what="skinny dgrad + residual + mask %s" % (case,))
+    close(dw, x.double().t() @ gy.double(), tol=2e-6, what="skinny wgrad %s" % (case,))
+    close(db, gy.double().sum(0), tol=2e-6, what="skinny bias gradient %s" % (case,))
