@@ -1240,7 +1240,7 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
     int rc = check_desc(d, "conv2d_fwd");
     if (rc) return rc;
     if (d->ldw < d->K) return fail(ACIMG_EINVAL, "conv2d_fwd: ldw < K");
-    if (skinny_shape(d) && !in_scale && !in_shift && !stats && ws && ws_bytes >= skinny_fwd_ws_bytes(d) && aligned16(x) &&
+    if (skinny_shape(d) && !in_scale && !in_shift && !in_relu && !stats && ws && ws_bytes >= skinny_fwd_ws_bytes(d) && aligned16(x) &&
         aligned16(w) && aligned16(y) && aligned16(ws) && (!bias || aligned16(bias)) && (d->ldw & 3) == 0 && (d->ldx & 3) == 0 &&
         (d->ldy & 3) == 0) {
         // the VAE heads' dense layer: weight rows read once in whole lines, K slabs combined in slab order
