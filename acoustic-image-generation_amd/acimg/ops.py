@@ -207,11 +207,12 @@ def _runs_beside(a, b, work):
     return beside
 
 
-def concurrent_streams(device, base, want, pool=8):
+def concurrent_streams(device, base, want, pool=8, priority=0):
     """up to `want` new streams that really run beside `base` and beside each other (measured, a few ms each); fewer if
-    the runtime has fewer free hardware queues — the caller then shares lanes, which costs time, never correctness"""
+    the runtime has fewer free hardware queues — the caller then shares lanes, which costs time, never correctness.
+    priority: HIP stream priority of the new streams (0 normal, -1 high): a scheduling hint only"""
     work = torch.zeros(64, device=device)
-    chosen, cands = [base], [torch.cuda.Stream(device=device) for _ in range(pool)]
+    chosen, cands = [base], [torch.cuda.Stream(device=device, priority=int(priority)) for _ in range(pool)]
     for c in cands:
         if len(chosen) > want:
             break

@@ -289,7 +289,9 @@ class Trainer(object):
         want = (2 if g.stage_calls is not None else 1) + 1
         key = (cur.cuda_stream, want)
         if getattr(self, "_lane_cache", None) is None or self._lane_cache[0] != key:
-            self._lane_cache = (key, ops.concurrent_streams(dev, cur, want))     # measured once per trainer
+            # (lane_priority: attribute, 0 by default - the lanes beside the caller's stream as high-priority streams was
+            #  measured in round 3, profiles/r03/pipeline_lane_priority_r03al.txt)
+            self._lane_cache = (key, ops.concurrent_streams(dev, cur, want, priority=getattr(self, "lane_priority", 0)))
         lanes = list(self._lane_cache[1])
         side_b = lanes.pop() if len(lanes) == want else None
         while len(lanes) < want - 1:

@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--stage-cut", type=int, default=8, help="bottleneck units in trunk stage 1 (of 16)")
     ap.add_argument("--two-pass-cin", type=int, default=128,
                     help="conv3 of the identity units in two passes up to this many input channels (0 = never; 128 = measured)")
+    ap.add_argument("--lane-priority", type=int, default=0,
+                    help="HIP priority of the pipeline's extra streams (0 normal, -1 high): experiment")
     ap.add_argument("--no-side-lane", action="store_true",
                     help="record the plans without the second HIP stream for weight gradients / projection shortcuts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -454,6 +456,7 @@ def main():
                                stages=args.trunk_stages or None, stage_cut=args.stage_cut, side_lane=side_lane,
                                two_pass=args.two_pass_cin > 0, two_pass_max_cin=args.two_pass_cin),
                  learning_rate=1e-4, session=sess)
+    tr.lane_priority = args.lane_priority
     g = tr._build_functions(batch_size=B)
     tr.modelimages.initialize(seed=1238)
     tr.modelac.initialize(seed=1239)
