@@ -34,7 +34,7 @@ PLANE_SLACK = 2 * 15 * 2048 * 2 + 512   # a split-format plane ends on a whole 1
 class ResNet50Model(object):
 
     def __init__(self, input_shape=None, num_classes=None, precision="f16x3", stages=None, stage_cut=8, side_lane=True,
-                 two_pass=True, two_pass_max_cin=128):
+                 two_pass=True, two_pass_max_cin=256):
         """precision: arithmetic of the frozen trunk convs — "f16x3" (split-fp16 MFMA, fp32-class
         results, default), "f32" (exact-f32 MFMA) or "f16" (fp16 OPERAND STORAGE: the same data path, but the 52 trunk
         convs fetch and multiply only the hi fp16 plane of activations and weights — one MFMA per product, fp32
@@ -67,7 +67,10 @@ class ResNet50Model(object):
         # in its epilogue (ops.conv2d_fwd_split3p_stats / _tail) - instead of conv + bn_add_relu_split: the unit's widest
         # tensor never exists in fp32 (f16x3 only; units with a subsampled shortcut and the last unit keep the pass)
         self.two_pass = bool(two_pass) and precision == "f16x3"
-        self.two_pass_max_cin = int(two_pass_max_cin)       # widest conv3 INPUT that takes the two passes (measured: 128)
+        # widest conv3 INPUT that takes the two passes: with the chip to itself the second K loop pays up to 128 channels; in
+        # the pipelined step, where three lanes share HBM, 256 is as fast (6.617 vs 6.632 ms, three alternating runs each:
+        # profiles/r03/pipeline_two_pass_rule_r03ao.txt) and moves 1.4 GB less per step; 512 is slower (6.656 ms)
+        self.two_pass_max_cin = int(two_pass_max_cin)
         self.num_classes = num_classes
         self.height = input_shape[0]
         self.width = input_shape[1]

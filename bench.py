@@ -82,8 +82,8 @@ def parse():
     ap.add_argument("--trunk-stages", type=int, default=0, choices=[0, 1, 2],
                     help="pipeline stages of the frozen trunk (0 = the model's default: 2 for the split-MFMA trunk)")
     ap.add_argument("--stage-cut", type=int, default=8, help="bottleneck units in trunk stage 1 (of 16)")
-    ap.add_argument("--two-pass-cin", type=int, default=128,
-                    help="conv3 of the identity units in two passes up to this many input channels (0 = never; 128 = measured)")
+    ap.add_argument("--two-pass-cin", type=int, default=256,
+                    help="conv3 of the stride-1 units in two passes up to this many input channels (0 = never; 256 = shipped)")
     ap.add_argument("--lane-priority", type=int, default=0,
                     help="HIP priority of the pipeline's extra streams (0 normal, -1 high): experiment")
     ap.add_argument("--no-side-lane", action="store_true",
