@@ -1,6 +1,6 @@
 # final evidence of round 3 at HEAD: full GPU suite (durations), default bench line (pipelined, CPU baseline, secondaries),
 # rocprof kernel stats of the default and of the one-stream command, per-op report.  (PMC traffic: tools/r03_round_w.sh ran
-# it on the same kernel tree - profiles/r03/hbm_traffic_r03w.txt.)
+# it on the same kernel tree - profiles/r03/hbm_traffic_r03a_9674477.txt.)
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r03z}
 cd $R
