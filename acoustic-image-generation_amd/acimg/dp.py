@@ -99,10 +99,22 @@ class GradComm(object):
         self.stream = torch.cuda.Stream(device=flat_grad.device) if (self.cuda and self.enabled) else None
         self.events = [torch.cuda.Event() for _ in self.buckets] if self.stream is not None else []
         self._works = []
+        # measurement only (bench.py): `timing` = list of (event, event) pairs bracketing every collective on the stream
+        # it is issued from; `muted` = skip the collectives (the no-exchange leg that tells whether the exchange is
+        # hidden - the ranks' weights diverge, so never outside a benchmark)
+        self.timing = None
+        self.muted = False
+
+    def start_timing(self):
+        self.timing = []
+
+    def exchange_ms(self):
+        """total device time between the bracketing events of the collectives timed so far (call after a synchronize)"""
+        return sum(e0.elapsed_time(e1) for e0, e1 in (self.timing or []))
 
     def bucket_ready(self, i):
         """call (from the host, in launch order) right after the last kernel writing bucket i"""
-        if not self.enabled:
+        if not self.enabled or self.muted:
             return
         a, b = self.buckets[i]
         view = self.flat[a:b]
@@ -112,7 +124,15 @@ class GradComm(object):
         self.events[i].record(torch.cuda.current_stream(self.flat.device))
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(self.events[i])
-            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
+            w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._works.append(w)
+            if self.timing is not None:
+                w.wait()             # orders the exchange stream behind the collective (no host block)
+                e1.record(self.stream)
+                self.timing.append((e0, e1))
 
     def hook(self, i):
         return lambda: self.bucket_ready(i)
@@ -120,9 +140,18 @@ class GradComm(object):
     def allreduce_all(self):
         """the whole flat gradient in one exchange (gradient-accumulation steps: the buckets of the individual
         micro-batches are not final, so nothing can be overlapped before the last one has been added)"""
+        if self.muted:
+            return
         if self.world > 1 or self.enabled:
             if dist.is_available() and dist.is_initialized():
+                if self.timing is not None and self.cuda:
+                    cur = torch.cuda.current_stream(self.flat.device)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(cur)
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                if self.timing is not None and self.cuda:
+                    e1.record(cur)
+                    self.timing.append((e0, e1))
 
     def wait(self):
         """make the compute stream wait for every outstanding bucket (before the optimiser)"""

@@ -151,10 +151,9 @@ class Trainer(object):
         if N in self.graphs:
             return self.graphs[N]
         # a different batch size (last partial batch): same variables, new buffers + plans
-        mi = type(self.modelimages)(input_shape=[224, 298, 3], num_classes=None, precision=self.modelimages.precision,
-                                    stages=getattr(self.modelimages, "stages", 1),
-                                    stage_cut=getattr(self.modelimages, "STAGE_CUT", 8),
-                                    side_lane=getattr(self.modelimages, "side_lane", True))
+        # (every constructor argument that shapes the recorded plan comes from the model's own record of them, so the
+        #  partial batch runs the same kernel path - two-pass rule included - as the primary graph)
+        mi = type(self.modelimages)(**self.modelimages.clone_kwargs())
         ma = type(self.modelac)(input_shape=[36, 48, 12], embedding=self.modelac.embedding,
                                 num_skip=self.modelac.num_skip, precision=self.modelac.precision,
                                 side_lane=self.modelac.side_lane)
@@ -460,14 +459,21 @@ class Trainer(object):
         # in this call (trunk stage 1 runs in it)
         targets = None
         if batch is not None:
-            dev = self.session.device
-            targets = (torch.as_tensor(batch[0]).to(dev, torch.float32, copy=True),
-                       torch.as_tensor(batch[1]).to(dev, torch.float32, copy=True))
+            targets = (self._stage_for_lane_b(pipe, batch[0]), self._stage_for_lane_b(pipe, batch[1]))
             if eps is not None:
-                eps = torch.as_tensor(eps).to(dev, torch.float32, copy=True)
+                eps = self._stage_for_lane_b(pipe, eps)
         item = dict(video=None if batch is None else batch[2], targets=targets, eps=eps, tag=tag)
         res = self._advance(pipe, item, probe)
         return res if res is not None else out
+
+    def _stage_for_lane_b(self, pipe, x):
+        """device copy of a host / device tensor made NOW on the caller's stream and read two ticks later by the trained
+        part's stream: `record_stream` tells the caching allocator about that second stream, so the block is not handed
+        to a later staging copy (on the caller's stream) before the trained part's D2D copy of it has run"""
+        t = torch.as_tensor(x).to(self.session.device, torch.float32, copy=True)
+        if pipe["sb"] != torch.cuda.current_stream(self.session.device):
+            t.record_stream(pipe["sb"])
+        return t
 
     def _lane_b_scalars(self, losses):
         """python floats of a loss tensor produced on lane B (read behind that lane, not behind the trunk in flight)"""
@@ -508,11 +514,9 @@ class Trainer(object):
             pipe = self._pipeline(g)
             if self._acc is None:
                 self._acc = torch.zeros_like(self.session.store.grad)
-            dev = self.session.device
             for i, b in enumerate(shards):
-                e = None if eps is None else torch.as_tensor(eps[i]).to(dev, torch.float32, copy=True)
-                item = dict(video=b[2], targets=(torch.as_tensor(b[0]).to(dev, torch.float32, copy=True),
-                                                 torch.as_tensor(b[1]).to(dev, torch.float32, copy=True)),
+                e = None if eps is None else self._stage_for_lane_b(pipe, eps[i])
+                item = dict(video=b[2], targets=(self._stage_for_lane_b(pipe, b[0]), self._stage_for_lane_b(pipe, b[1])),
                             eps=e, tag=tag, accum=(i, len(shards)))
                 self._advance(pipe, item, probe)
             return None

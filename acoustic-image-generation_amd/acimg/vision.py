@@ -6,13 +6,16 @@ checkpoint_file)`, `_build_model(visual_images)` which sets `output`, `network`,
 (bottleneck), :205-209 (7x7/2 stem, 3x3/2 pool, conv_map 3x4 VALID 2048->12 + BN + ReLU), :261-266
 (block strides 1,2,2,1 placed in each block's last unit).
 
-MI355X design: every conv is one implicit-GEMM launch that writes the RAW conv output once and
-leaves per-row-block (sum, sum^2) partials; `bn_finalize` turns them into per-channel scale/shift
-(and advances the moving averages); the *consumer* conv applies scale/shift/ReLU while staging its
-A tile, so normalised activations are never written to HBM.  Only the unit outputs
-(relu(bn(conv3) + shortcut)) are materialised.  Activations live in six reusable arenas (about
-0.8 GB at batch 32), so consecutive layers hit the 256 MiB Infinity Cache instead of streaming
-6.5 GB of distinct tensors.
+MI355X design (f16x3, the default): every trunk conv is one implicit-GEMM launch on PRE-SPLIT operands (two fp16
+planes per tensor in LDS-tile order, "bricks": csrc/igemm_split3d_kernel.hpp) that writes the RAW fp32 conv output
+once and leaves per-row-block (sum, sum^2) partials; `bn_finalize` turns them into per-channel scale/shift (and
+advances the moving averages); ONE elementwise pass per tensor (`bn_relu_split`, `bn_relu_maxpool_split`,
+`bn_add_relu_split`) applies scale/shift (+ shortcut) + ReLU and writes the consumer's operand planes, so a normalised
+activation is written exactly once, in the format the next K loop copies into LDS.  conv3 of a bottleneck never writes
+its fp32 output when its batch statistics are known beforehand (the statistics pass of round 3, the input-side Gram
+statistics of round 4): BN + shortcut + ReLU + split then run in the conv's own epilogue (`*_tail`, `*_tail_proj`).
+Activations live in a few reusable arenas (about 1.2 GB at batch 32), so consecutive layers hit the 256 MiB Infinity
+Cache instead of streaming 6.5 GB of distinct tensors.
 """
 import os
 from collections import OrderedDict
@@ -71,6 +74,9 @@ class ResNet50Model(object):
         # the pipelined step, where three lanes share HBM, 256 is as fast (6.617 vs 6.632 ms, three alternating runs each:
         # profiles/r03/pipeline_two_pass_rule_r03ao.txt) and moves 1.4 GB less per step; 512 is slower (6.656 ms)
         self.two_pass_max_cin = int(two_pass_max_cin)
+        self._ctor = dict(input_shape=list(input_shape), num_classes=num_classes, precision=precision, stages=stages,
+                          stage_cut=int(stage_cut), side_lane=bool(side_lane), two_pass=bool(two_pass),
+                          two_pass_max_cin=int(two_pass_max_cin))
         self.num_classes = num_classes
         self.height = input_shape[0]
         self.width = input_shape[1]
@@ -80,6 +86,11 @@ class ResNet50Model(object):
         self.session = None
         self.output = None
         self.network = None
+
+    def clone_kwargs(self):
+        """constructor arguments of a second instance that records the same plan shape (Trainer._graph_for: another
+        batch size over the same variables)"""
+        return dict(self._ctor)
 
     # ---- variable inventory (TF names) --------------------------------------------------------------
     def _units(self):

@@ -1403,8 +1403,8 @@ int acimg_conv2d_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, 
     if (rc) return rc;
     const int kp = up4(d->K);
     if (kp > ldgy || kp > d->ldw) return fail(ACIMG_EINVAL, "conv2d_wgrad: padded K exceeds ldgy/ldw");
-    if (skinny_shape(d) && aligned16(x) && aligned16(gy) && aligned16(dw) && (d->ldw & 3) == 0 && (ldgy & 3) == 0 &&
-        (d->ldx & 3) == 0) {
+    if (skinny_shape(d) && aligned16(x) && aligned16(gy) && aligned16(dw) && (!db || aligned16(db)) && (d->ldw & 3) == 0 &&
+        (ldgy & 3) == 0 && (d->ldx & 3) == 0) {
         // the same dense layer's weight gradient: every weight row is written once, 256 contiguous bytes per wave
         SkinnyParams q{};
         q.X = x; q.G = gy; q.out = dw; q.db = db;

@@ -19,6 +19,16 @@ stages); `--no-pipeline`: bucketed, overlapped with backward.  `--scaling strong
 --global-batch 256`: the SAME 256 images per step at every N, as shards of 32 (the batch-norm group) run one after
 the other on each rank with accumulated gradients — the arithmetic of a step does not depend on N.
 
+The two documented 8-GPU commands (the driver runs the weak one; the >= 6x target of BASELINE.json is the strong one):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps K --warmup W                                      # weak: 8 x 32 = configs[3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps K --warmup W --scaling strong --global-batch 256  # strong: the same 256 images at every N
+At N > 1 (or `--dp-force` under torch.distributed.run at N = 1) the line verifies itself: `config.rccl_ranks`,
+`config.dp` = lanes obtained beside RCCL (min over ranks), the measured exchange time per step (events around the
+collectives, max over ranks), the same loop with the collectives muted, `exchange_hidden`, and the fallback taken if
+fewer than three streams run side by side (one-stream step, bucketed exchange overlapped with backward).
+
 One JSON line on rank 0.  `roofline` is for the dominant kernel (the 128x128-tile implicit-GEMM
 forward conv that runs the ResNet trunk (LDS-DMA staged, XCD-aware tile order): split-fp16 "f16x3" MFMA by default, exact-f32 MFMA with
 --precision f32): ALGORITHMIC FLOPs (2*M*N*K per conv) of its launches divided by their
@@ -93,7 +103,7 @@ def parse():
                     help="skip the configs[1] (UNet RGB VAE) and configs[2] (2-skip, batch 64) side measurements")
     ap.add_argument("--cpu-batch", type=int, default=32, help="BASELINE.md §3: the CPU leg runs the GPU leg's batch")
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed CPU steps (BASELINE.md §3: >= 10) after --cpu-warmup")
-    ap.add_argument("--cpu-warmup", type=int, default=2)
+    ap.add_argument("--cpu-warmup", type=int, default=3, help="BASELINE.md §3: >= 3")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every host core this process may run on")
     ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds of timed CPU work after which no further "
                                                                      "timed step starts")
@@ -121,7 +131,7 @@ def host_cores():
 
 def cpu_baseline(args):
     """CPU oracle train step: the SAME step as the GPU leg — same generator variant (--num-skip), same
-    batch (32) — on a BOUNDED sample: --cpu-warmup (2) warm-up steps, then up to --cpu-steps (10) timed steps (about
+    batch (32) — on a BOUNDED sample: --cpu-warmup (3) warm-up steps, then up to --cpu-steps (10) timed steps (about
     6 s each on the GPU box's 16-core share: ~75 s), stopping early once --cpu-budget seconds (default 150) of timed
     work are spent (at least one timed step), so the default bench.py run stays within a few minutes.  `cores` = the
     thread count actually set with torch.set_num_threads (affinity mask capped by the cgroup CPU quota).  Progress
@@ -478,6 +488,23 @@ def main():
     probe_idx, flops, alg_bytes, kernel_name = dominant_trunk_kernel(g, f16)
     shared = g.plan_train.shared_calls()
     pipelined = not args.no_pipeline and f16
+    dp_on = world > 1 or force_dp
+    lanes_min, dp_fallback = None, None
+    if dp_on and pipelined:
+        # SELF-VERIFICATION of the multi-GPU schedule: the pipelined step needs three streams that
+        # really run side by side WITH the RCCL communicator up (the runtime exposes ~4 hardware queues and RCCL takes
+        # some).  The lanes are measured now, on every rank; if any rank got fewer than three, every rank falls back to
+        # the one-stream step with the bucketed exchange overlapped with backward, and the line says so.
+        lanes_here = tr._pipeline(g)["lanes"]
+        t = torch.tensor([lanes_here], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        lanes_min = int(t.item())
+        if lanes_min < 3:
+            dp_fallback = ("only %d concurrent HIP streams beside RCCL on at least one rank: one-stream step with the "
+                           "bucketed exchange instead of the three-lane pipeline" % lanes_min)
+            pipelined = False
+            tr._pipe = None
+            tr.exchange = "bucketed"
 
     def one_step(probe=None):
         if strong:
@@ -502,6 +529,8 @@ def main():
             torch.cuda.synchronize()
 
     barrier()
+    if dp_on:
+        tr.comm.start_timing()    # event pairs around every collective of the timed region, on the stream it is issued from
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(probe=(probe_idx, events))
@@ -511,6 +540,35 @@ def main():
         tr.flush_pipeline()       # the batch whose trunk ran in the last timed call (the first timed call finished one
         torch.cuda.synchronize()  # whose trunk ran during warm-up): outside the timed region on both ends
     last = tr._scalars(g)
+    dp_report = None
+    if dp_on:
+        # what the exchange costs and whether the schedule hides it: (a) device time between the events that bracket the
+        # collectives of the timed region, per step, max over ranks; (b) the SAME timed loop once more with the collectives
+        # muted (weights diverge between ranks from here on: nothing after this point is a result) - `exchange_hidden` =
+        # the step with the exchange took at most 2 % longer than the step without it
+        n_coll = len(tr.comm.timing)
+        ex_ms = tr.comm.exchange_ms() / max(args.steps, 1)
+        tr.comm.timing = None
+        tr.comm.muted = True
+        for _ in range(min(args.warmup, 3)):
+            one_step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        barrier()
+        dt_mute = time.perf_counter() - t1
+        if pipelined:
+            tr.flush_pipeline()
+            torch.cuda.synchronize()
+        t = torch.tensor([ex_ms, dt_mute], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ex_ms, dt_mute = float(t[0]), float(t[1])
+        dp_report = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                     "lanes_min_over_ranks": lanes_min, "fallback": dp_fallback,
+                     "collectives_per_step": n_coll / max(args.steps, 1),
+                     "exchange_ms_per_step": ex_ms, "no_exchange_ms_per_step": dt_mute / args.steps * 1e3}
     seq_events = []
     if pipelined and events:
         # kernel quality without a second lane on the chip: a few one-stream steps after the timed region
@@ -521,6 +579,8 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if dp_report is not None:
+        dp_report["exchange_hidden"] = bool(dt / args.steps * 1e3 <= 1.02 * dp_report["no_exchange_ms_per_step"])
 
     roof = None
     prof = load_traffic_profile(kernel_name) if f16 else None
@@ -590,10 +650,15 @@ def main():
                        "per_gpu_batch": images_per_step // world, "global_batch": images_per_step,
                        "bn_group": B, "shards_per_gpu_per_step": len(shards) if strong else 1,
                        "parallelism": "dp%d" % world, "launches_per_step": len(g.plan_train) + 2,
-                       "exchange": (None if not (world > 1 or force_dp) else
+                       "exchange": (None if not dp_on else
                                     "whole flat gradient, one all-reduce behind the backward pass"
-                                    if (args.exchange == "whole" or strong or (args.exchange == "auto" and pipelined)) else
+                                    if (strong or ((args.exchange == "whole" or (args.exchange == "auto" and pipelined))
+                                                   and dp_fallback is None)) else
                                     "5 buckets fired from hooks in the backward plan on an exchange stream (overlapped)"),
+                       # multi-GPU self-verification (None on a plain one-GPU run): ranks RCCL really has, lanes obtained
+                       # (min over ranks), measured exchange time and whether the schedule hid it
+                       "rccl_ranks": dp_report["rccl_ranks"] if dp_report else None,
+                       "dp": dp_report,
                        "lanes": ("%d HIP streams measured to run side by side: trunk units 1-8 of batch n | trunk units 9-16 "
                                  "of batch n-1 | conv_map + generator + backward + exchange + Adam of batch n-2; every batch's "
                                  "arithmetic is the one-stream step's" % tr._pipe["lanes"]) if pipelined else "1"},
@@ -631,7 +696,7 @@ def main():
     quiet.release()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1 or force_dp:
+    if dp_on:
         dist.barrier()
         dist.destroy_process_group()
 

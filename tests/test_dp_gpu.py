@@ -223,3 +223,32 @@ def test_rccl_exchange_at_world_size_one(tmp_path):
     out = p.stdout.decode()
     assert p.returncode == 0, out[-3000:]
     assert "rccl ok" in out and out.count("== plain step") == 4
+
+
+def test_bench_line_verifies_the_multi_gpu_schedule_at_world_size_one(tmp_path):
+    """bench.py under torch.distributed.run with --dp-force (a fresh process: RCCL comes up before anything touches the
+    GPU): the one JSON line carries the self-verification fields of VERDICT r3 item 6 - ranks RCCL really has, lanes
+    obtained beside the communicator, measured exchange time per step, the no-exchange step, `exchange_hidden`, and the
+    fallback (taken or not)"""
+    import json
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 90),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3", "--dp-force",
+                        "--no-cpu-baseline", "--no-secondary"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert cfg["rccl_ranks"] == 1 and cfg["dp"]["backend"] == "nccl"
+    d = cfg["dp"]
+    assert d["lanes_min_over_ranks"] >= 1
+    assert (d["fallback"] is None) == (d["lanes_min_over_ranks"] >= 3)
+    assert d["collectives_per_step"] in (1.0, 5.0), d                  # whole-buffer form, or the bucketed fallback
+    assert d["exchange_ms_per_step"] > 0 and d["no_exchange_ms_per_step"] > 0
+    assert isinstance(d["exchange_hidden"], bool)
+    assert cfg["exchange"] is not None and out["n_gpus"] == 1 and out["value"] > 0
+

@@ -1280,3 +1280,11 @@ def test_skinny_dense_gradients(device, case):
     close(dx, (ref_dx + res.double()) * (x > 0).double(), tol=2e-6, what="skinny dgrad + residual + mask %s" % (case,))
     close(dw, x.double().t() @ gy.double(), tol=2e-6, what="skinny wgrad %s" % (case,))
     close(db, gy.double().sum(0), tol=2e-6, what="skinny bias gradient %s" % (case,))
+    # a bias-gradient buffer that is 4- but not 16-byte aligned (C ABI: any float*): the dispatch must fall back to
+    # the general kernel instead of issuing misaligned 16-byte stores
+    dbb = torch.full((K + 1,), float("nan"), device=device)
+    dw3 = torch.full((Cc, K), float("nan"), device=device)
+    ops.conv2d_wgrad(plan, d, x.to(device), gy.to(device), K, dw3, dbb[1:])
+    torch.cuda.synchronize()
+    close(dw3, x.double().t() @ gy.double(), tol=2e-6, what="wgrad, offset db %s" % (case,))
+    close(dbb[1:], gy.double().sum(0), tol=2e-6, what="bias gradient at a 4-byte offset %s" % (case,))

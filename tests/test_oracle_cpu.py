@@ -135,6 +135,71 @@ def test_parameter_inventory():
     assert unet_acresnet.param_shapes(0)["UNetAcRes/layer6/conv_1/kernel"] == (3, 3, 128, 128)
 
 
+# The trunk geometry WRITTEN OUT from /root/reference/models/resnet50.py:229-250 (`resnet_v1_block`: units 1 .. n-1 have
+# stride 1, the LAST unit carries the block's stride) and :261-266 (block1: 64 x 3 stride 1; block2: 128 x 4 stride 2;
+# block3: 256 x 6 stride 2; block4: 512 x 3 stride 1), with :104-125 (shortcut = 1x1 conv only where the depth changes,
+# else subsample) and :205-209 (7x7/2 root conv + 3x3/2 SAME pool: 224x298 -> 112x149 -> 56x75).  One literal row per
+# unit, independent of the generators `oracle.resnet50.units()` / `acimg.vision.ResNet50Model._units()` (which share an
+# author): (block, unit, depth_in, depth_bottleneck, depth_out, stride, projection shortcut?, H x W in, H x W out).
+TRUNK_UNITS = [
+    ("block1", 1,   64,  64,  256, 1, True,  (56, 75), (56, 75)),
+    ("block1", 2,  256,  64,  256, 1, False, (56, 75), (56, 75)),
+    ("block1", 3,  256,  64,  256, 1, False, (56, 75), (56, 75)),
+    ("block2", 1,  256, 128,  512, 1, True,  (56, 75), (56, 75)),
+    ("block2", 2,  512, 128,  512, 1, False, (56, 75), (56, 75)),
+    ("block2", 3,  512, 128,  512, 1, False, (56, 75), (56, 75)),
+    ("block2", 4,  512, 128,  512, 2, False, (56, 75), (28, 38)),
+    ("block3", 1,  512, 256, 1024, 1, True,  (28, 38), (28, 38)),
+    ("block3", 2, 1024, 256, 1024, 1, False, (28, 38), (28, 38)),
+    ("block3", 3, 1024, 256, 1024, 1, False, (28, 38), (28, 38)),
+    ("block3", 4, 1024, 256, 1024, 1, False, (28, 38), (28, 38)),
+    ("block3", 5, 1024, 256, 1024, 1, False, (28, 38), (28, 38)),
+    ("block3", 6, 1024, 256, 1024, 2, False, (28, 38), (14, 19)),
+    ("block4", 1, 1024, 512, 2048, 1, True,  (14, 19), (14, 19)),
+    ("block4", 2, 2048, 512, 2048, 1, False, (14, 19), (14, 19)),
+    ("block4", 3, 2048, 512, 2048, 1, False, (14, 19), (14, 19)),
+]
+
+
+def test_trunk_geometry_against_the_written_out_table():
+    """per-unit depths, strides, shortcut kinds and spatial sizes of BOTH generators (oracle and product host) against
+    the literal table above, and the oracle's forward pass against the table's spatial sizes (product and
+    oracle shared one author-written table; this pins it independently)"""
+    from acimg.vision import ResNet50Model
+
+    ou = list(resnet50.units())
+    pu = list(ResNet50Model(input_shape=[224, 298, 3], num_classes=None)._units())
+    assert len(ou) == len(pu) == len(TRUNK_UNITS) == 16
+    convs_o = dict((sc, (kh, kw, ci, co)) for sc, kh, kw, ci, co in resnet50.conv_layers())
+    for (blk, u, din, db, d, s, proj, hw_in, hw_out), o, q in zip(TRUNK_UNITS, ou, pu):
+        scope = "resnet_v1_50/%s/unit_%d/bottleneck_v1" % (blk, u)
+        assert tuple(o) == (scope, din, d, db, s), (o, scope)
+        assert (q[0].split("resnet_v1_50/")[1], q[1], q[2], q[3], q[4]) == (scope.split("resnet_v1_50/")[1], din, d, db, s), q
+        assert ((scope + "/shortcut") in convs_o) == proj
+        if proj:
+            assert convs_o[scope + "/shortcut"] == (1, 1, din, d)
+        assert convs_o[scope + "/conv1"] == (1, 1, din, db)
+        assert convs_o[scope + "/conv2"] == (3, 3, db, db)
+        assert convs_o[scope + "/conv3"] == (1, 1, db, d)
+        # TF SAME / conv2d_same output size at stride s: ceil(in / s)
+        assert tuple(-(-x // s) for x in hw_in) == hw_out
+    # spatial chain of the table is consistent and ends where conv_map (3x4 VALID) gives 12 x 16
+    for a, b in zip(TRUNK_UNITS[:-1], TRUNK_UNITS[1:]):
+        assert a[8] == b[7] and a[4] == b[2]
+    assert (TRUNK_UNITS[-1][8][0] - 3 + 1, TRUNK_UNITS[-1][8][1] - 4 + 1) == (12, 16)
+    # the oracle's forward pass produces exactly these maps (batch 1, inference statistics: cheap)
+    p = resnet50.init_params(seed=3)
+    ep = {}
+    torch.manual_seed(0)
+    feat, _ = resnet50.forward(p, torch.rand(1, 224, 298, 3), False, end_points=ep)
+    assert tuple(ep["resnet_v1_50/conv1"].shape) == (1, 112, 149, 64)
+    assert tuple(ep["resnet_v1_50/pool1"].shape) == (1, 56, 75, 64)
+    for blk, u, din, db, d, s, proj, hw_in, hw_out in TRUNK_UNITS:
+        t = ep["resnet_v1_50/%s/unit_%d/bottleneck_v1" % (blk, u)]
+        assert tuple(t.shape) == (1, hw_out[0], hw_out[1], d), (blk, u, t.shape)
+    assert tuple(feat.shape) == (1, 12, 16, 12)
+
+
 @pytest.mark.parametrize("num_skip,embedding", [(1, False), (2, False), (0, True)])
 def test_oracle_step_shapes_and_learning(num_skip, embedding):
     o = trainer.Oracle(num_skip=num_skip, embedding=embedding, randomize=True, learning_rate=1e-3)
