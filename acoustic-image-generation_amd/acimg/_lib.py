@@ -75,6 +75,8 @@ PROTOTYPES = {
     "acimg_conv2d_fwd_split3p": (_I, [_DP, _P, _SZ, _P, _P, _P, _P, _SZ, _P]),
     "acimg_conv2d_fwd_split1p": (_I, [_DP, _P, _SZ, _P, _P, _P, _P, _SZ, _P]),
     "acimg_conv2d_fwd_split3p_stats": (_I, [_DP, _P, _SZ, _P, _P, _P, _SZ, _P]),
+    "acimg_gram_stats_workspace": (_SZ, [_L, _I]),
+    "acimg_gram_stats": (_I, [_P, _SZ, _L, _I, _P, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _SZ, _P]),
     "acimg_conv2d_fwd_split3p_tail": (_I, [_DP, _P, _SZ, _P, _P, _P, _P, _SZ, _P, _SZ, _P, _SZ, _P]),
     "acimg_conv2d_fwd_split3p_tail_proj": (_I, [_DP, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _SZ, _P, _SZ, _P]),
     "acimg_split_plane_bytes": (_SZ, [_L, _I]),

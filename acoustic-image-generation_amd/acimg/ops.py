@@ -521,6 +521,20 @@ def conv2d_fwd_split3p_stats(plan, d, x_planes, x_lo_off, wsplit, stats, tail_ws
              stats, tail_ws, int(nbytes), side=side)
 
 
+def gram_stats_workspace(rows, Cn):
+    return int(_L().acimg_gram_stats_workspace(int(rows), int(Cn)))
+
+
+def gram_stats(plan, x_planes, x_lo_off, rows, Cn, w, ldw, K, gamma, beta, moving_mean, moving_var, scale, shift, ws,
+               decay=0.997, eps=1e-5, side=False):
+    """batch-norm statistics of y = x w (a 1x1 conv) from the Gram matrix of its INPUT, finalised into scale / shift and the
+    moving averages (acimg_gram_stats: replaces conv2d_fwd_split3p_stats + bn_finalize in front of a fused tail).  ws: a
+    uint8 buffer of gram_stats_workspace(rows, Cn) bytes, dedicated to the lane the call runs on."""
+    plan.add("gram_stats", _L().acimg_gram_stats, x_planes, int(x_lo_off), int(rows), int(Cn), w, int(ldw), int(K), gamma,
+             beta, moving_mean, moving_var, float(decay), float(eps), scale, shift, ws,
+             int(ws.numel() * ws.element_size()), side=side)
+
+
 def conv2d_fwd_split3p_tail(plan, d, x_planes, x_lo_off, wsplit, scale, shift, sc_planes, sc_lo_off, out_planes,
                             out_lo_off, tail_ws=None, side=False):
     """second pass (acimg_conv2d_fwd_split3p_tail): relu(conv * scale + shift + shortcut) straight into split planes"""

@@ -37,7 +37,7 @@ PLANE_SLACK = 2 * 15 * 2048 * 2 + 512   # a split-format plane ends on a whole 1
 class ResNet50Model(object):
 
     def __init__(self, input_shape=None, num_classes=None, precision="f16x3", stages=None, stage_cut=8, side_lane=True,
-                 two_pass=True, two_pass_max_cin=256):
+                 two_pass=True, two_pass_max_cin=256, gram=True):
         """precision: arithmetic of the frozen trunk convs — "f16x3" (split-fp16 MFMA, fp32-class
         results, default), "f32" (exact-f32 MFMA) or "f16" (fp16 OPERAND STORAGE: the same data path, but the 52 trunk
         convs fetch and multiply only the hi fp16 plane of activations and weights — one MFMA per product, fp32
@@ -74,9 +74,14 @@ class ResNet50Model(object):
         # the pipelined step, where three lanes share HBM, 256 is as fast (6.617 vs 6.632 ms, three alternating runs each:
         # profiles/r03/pipeline_two_pass_rule_r03ao.txt) and moves 1.4 GB less per step; 512 is slower (6.656 ms)
         self.two_pass_max_cin = int(two_pass_max_cin)
+        # gram (round 4): the statistics of those conv3 layers come from the Gram matrix of the conv's INPUT
+        # (ops.gram_stats: P C^2 MACs at two MFMAs per product + two small launches) instead of a statistics pass that
+        # repeats the conv's K loop (4 P C^2 MACs at three): the conv then runs ONCE, with the fused tail.  False = round
+        # 3's two K loops (kept for the A/B tables and the bit-exactness tests of the pass form).
+        self.gram = bool(gram) and self.two_pass
         self._ctor = dict(input_shape=list(input_shape), num_classes=num_classes, precision=precision, stages=stages,
                           stage_cut=int(stage_cut), side_lane=bool(side_lane), two_pass=bool(two_pass),
-                          two_pass_max_cin=int(two_pass_max_cin))
+                          two_pass_max_cin=int(two_pass_max_cin), gram=bool(gram))
         self.num_classes = num_classes
         self.height = input_shape[0]
         self.width = input_shape[1]
@@ -404,17 +409,28 @@ class ResNet50Model(object):
         tail_ws = getattr(self, ws_attr)
         lo = self._lo_off(self.N * hw[0] * hw[1], cin)
         lo_out = self._lo_off(self.N * hw[0] * hw[1], cout)
-        if training:
-            ops.conv2d_fwd_split3p_stats(plan, d, xplanes, lo, wsplit, stats, tail_ws=tail_ws)
         if not hasattr(self, "_aff_cache"):
             self._aff_cache = {}
         if scope not in self._aff_cache:
             self._aff_cache[scope] = self._new_affine(up4(cout))
         sc, sh = self._aff_cache[scope]
         b = scope + "/BatchNorm/"
-        ops.bn_finalize(plan, stats if training else None, rows if training else 0, cout, up4(cout),
-                        self.N * hw[0] * hw[1] if training else 0, P(b + "gamma"), P(b + "beta"),
-                        P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, BN_DECAY, BN_EPS, training)
+        M = self.N * hw[0] * hw[1]
+        if training and self.gram and ops.gram_stats_workspace(M, cin) > 0:
+            # statistics from the conv's input (one workspace per pipeline stage: the stages run side by side)
+            need = ops.gram_stats_workspace(M, cin)
+            gw_attr = "_gram_ws" + tag
+            if getattr(self, gw_attr, None) is None or getattr(self, gw_attr).numel() < need:
+                setattr(self, gw_attr, torch.zeros(need, dtype=torch.uint8, device=self.session.device))
+            gws = getattr(self, gw_attr)     # (a unit that needed a smaller one keeps the buffer it was recorded with)
+            ops.gram_stats(plan, xplanes, lo, M, cin, P(scope + "/weights"), cout, cout, P(b + "gamma"), P(b + "beta"),
+                           P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, gws, BN_DECAY, BN_EPS)
+        else:
+            if training:
+                ops.conv2d_fwd_split3p_stats(plan, d, xplanes, lo, wsplit, stats, tail_ws=tail_ws)
+            ops.bn_finalize(plan, stats if training else None, rows if training else 0, cout, up4(cout),
+                            M if training else 0, P(b + "gamma"), P(b + "beta"),
+                            P(b + "moving_mean"), P(b + "moving_variance"), sc, sh, BN_DECAY, BN_EPS, training)
         if proj is not None:
             ops.conv2d_fwd_split3p_tail_proj(plan, d, xplanes, lo, wsplit, sc, sh, proj[0], proj[1], proj[2], out_planes,
                                              lo_out, tail_ws=tail_ws)

@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--stage-cut", type=int, default=8, help="bottleneck units in trunk stage 1 (of 16)")
     ap.add_argument("--two-pass-cin", type=int, default=256,
                     help="conv3 of the stride-1 units in two passes up to this many input channels (0 = never; 256 = shipped)")
+    ap.add_argument("--no-gram", action="store_true",
+                    help="statistics of the fused-tail conv3 layers from a second K loop (round 3) instead of the Gram matrix "
+                         "of the conv's input (round 4): A/B switch")
     ap.add_argument("--lane-priority", type=int, default=0,
                     help="HIP priority of the pipeline's extra streams (0 normal, -1 high): experiment")
     ap.add_argument("--no-side-lane", action="store_true",
@@ -464,7 +467,7 @@ def main():
     tr = Trainer(UNetAc(input_shape=[36, 48, 12], embedding=False, num_skip=args.num_skip, side_lane=side_lane),
                  ResNet50Model(input_shape=[224, 298, 3], num_classes=None, precision=args.precision,
                                stages=args.trunk_stages or None, stage_cut=args.stage_cut, side_lane=side_lane,
-                               two_pass=args.two_pass_cin > 0, two_pass_max_cin=args.two_pass_cin),
+                               two_pass=args.two_pass_cin > 0, two_pass_max_cin=args.two_pass_cin, gram=not args.no_gram),
                  learning_rate=1e-4, session=sess)
     tr.lane_priority = args.lane_priority
     g = tr._build_functions(batch_size=B)
@@ -536,6 +539,12 @@ def main():
         one_step(probe=(probe_idx, events))
     barrier()
     dt = time.perf_counter() - t0
+    n_coll, ex_ms = 0, 0.0
+    if dp_on:
+        # the collectives of the K timed calls (the pipeline's flush below issues those of the batches still in flight)
+        n_coll = len(tr.comm.timing)
+        ex_ms = tr.comm.exchange_ms() / max(args.steps, 1)
+        tr.comm.timing = None
     if pipelined:
         tr.flush_pipeline()       # the batch whose trunk ran in the last timed call (the first timed call finished one
         torch.cuda.synchronize()  # whose trunk ran during warm-up): outside the timed region on both ends
@@ -546,9 +555,6 @@ def main():
         # collectives of the timed region, per step, max over ranks; (b) the SAME timed loop once more with the collectives
         # muted (weights diverge between ranks from here on: nothing after this point is a result) - `exchange_hidden` =
         # the step with the exchange took at most 2 % longer than the step without it
-        n_coll = len(tr.comm.timing)
-        ex_ms = tr.comm.exchange_ms() / max(args.steps, 1)
-        tr.comm.timing = None
         tr.comm.muted = True
         for _ in range(min(args.warmup, 3)):
             one_step()

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ACIMG_VERSION 205
+#define ACIMG_VERSION 206
 
 #define ACIMG_OK 0
 #define ACIMG_EINVAL (-1)     /* bad descriptor / shape / alignment */
@@ -234,6 +234,21 @@ int acimg_conv2d_fwd_split3p_tail_proj(const AcimgConvDesc* d, const void* x_pla
                                        const float* scale, const float* shift, const float* sc32, const float* sc_scale,
                                        const float* sc_shift, void* out_planes, size_t out_lo_off, void* ws, size_t ws_bytes,
                                        void* stream);
+/* INPUT-SIDE batch-norm statistics of a 1x1 conv (round 4; replaces acimg_conv2d_fwd_split3p_stats + acimg_bn_finalize in
+ * front of the fused tails above): for y = x w over `rows` pixels, sum_p y_n = w_n^T sum_p x and
+ * sum_p y_n^2 = w_n^T (sum_p x x^T) w_n - the column sums and the C x C Gram matrix of the conv's INPUT (P C^2 MACs, a
+ * quarter of the conv's, two fp16 MFMAs per product: a quadratic form only sees the symmetric part, hi hi^T + 2 hi lo^T).
+ * Three launches on `stream` (csrc/gram.hip): Gram partials per pixel range (brick planes -> LDS by LDS-DMA, transposing
+ * fragment reads), a deterministic reduce in double, and per 16 output channels the two forms by exact-f32 MFMA followed by
+ * acimg_bn_finalize's arithmetic: `scale` / `shift` [K] for the conv's fused tail, the moving averages advanced (training
+ * mode only; inference keeps acimg_bn_finalize with training = 0).
+ *   x_planes / x_lo_off: the conv's input in split format [rows][C]; C = 64 or a multiple of 128 up to 512
+ *   w: the conv's fp32 kernel [C][ldw] (TF layout [1, 1, C, K]); ws: acimg_gram_stats_workspace(rows, C) bytes, 16-byte aligned
+ * Replaces: the moments slim batch_norm takes of conv3's output, models/resnet50.py:121-123 (is_training=True). */
+size_t acimg_gram_stats_workspace(long rows, int C);
+int acimg_gram_stats(const void* x_planes, size_t x_lo_off, long rows, int C, const float* w, int ldw, int K,
+                     const float* gamma, const float* beta, float* moving_mean, float* moving_var, float decay, float eps,
+                     float* scale, float* shift, void* ws, size_t ws_bytes, void* stream);
 size_t acimg_split_plane_bytes(long rows, int C);
 int acimg_bn_relu_split(const float* x, const float* scale, const float* shift, int relu, void* out,
                         size_t lo_off, long rows, int C, void* stream);

@@ -17,6 +17,7 @@ import os, sys
 ROOT = %(root)r
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "acoustic-image-generation_amd"))
 import torch, torch.distributed as dist
+torch.set_num_threads(%(threads)d)      # two ranks share the box's core quota (gloo collectives and CPU tensor work)
 from acimg.flags import FLAGS
 from acimg.session import Session
 from acimg.trainer import Trainer
@@ -146,7 +147,9 @@ print("rank", rank, "ok", out["loss"])
 
 def test_two_ranks_share_averaged_gradients(tmp_path):
     script = tmp_path / "dp_gpu_worker.py"
-    script.write_text(WORKER % {"root": ROOT, "port": 29600 + os.getpid() % 2000, "ckpt": str(tmp_path / "ckpt")})
+    import torch
+    script.write_text(WORKER % {"root": ROOT, "port": 29600 + os.getpid() % 2000, "ckpt": str(tmp_path / "ckpt"),
+                                "threads": max(1, torch.get_num_threads() // 2)})
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
@@ -160,6 +163,7 @@ import os, sys
 ROOT = %(root)r
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "acoustic-image-generation_amd"))
 import torch, torch.distributed as dist
+torch.set_num_threads(%(threads)d)
 # launched by torch.distributed.run in a FRESH process: nothing has touched the GPU before this point
 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
 dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -215,7 +219,8 @@ def test_rccl_exchange_at_world_size_one(tmp_path):
     identity, so the bucketed-overlapped and the whole-buffer form, on the one-stream and on the pipelined entry, must
     all reproduce the plain step bit for bit."""
     script = tmp_path / "rccl_worker.py"
-    script.write_text(RCCL_WORKER % {"root": ROOT})
+    import torch
+    script.write_text(RCCL_WORKER % {"root": ROOT, "threads": torch.get_num_threads()})
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90), str(script)],

@@ -1132,6 +1132,80 @@ def test_two_pass_conv3_equals_conv_then_bn_pass(device, case):
     close(got, r64.reshape(rows, K), tol=2e-6, what="two-pass conv3 vs fp64 %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(134400, 64, 256), (34048, 256, 1024), (20011, 128, 512), (8512, 512, 2048), (37, 64, 100),
+                                  (4099, 128, 136), (50, 256, 256)])
+def test_gram_statistics_match_fp64(device, case):
+    """acimg_gram_stats (round 4, csrc/gram.hip): the batch-norm statistics of a 1x1 conv's output from the column sums and
+    the Gram matrix of its INPUT (split planes in brick order), finalised into scale / shift and the moving averages -
+    against fp64 statistics of y = x w over the values the planes actually hold, against acimg_bn_finalize fed with those
+    fp64 sums (the same finalisation arithmetic), and against the statistics pass it replaces; row counts that are not
+    multiples of 16 / 32, one row, K not a multiple of 16; deterministic (two runs, the same bits)"""
+    from acimg import ops
+
+    rows, Cc, K = case
+    g = torch.Generator().manual_seed(11 + rows % 97 + Cc)
+    x = torch.relu(torch.randn(rows, Cc, generator=g) + 0.3) * (0.5 + torch.rand(Cc, generator=g))
+    ldw = -(-K // 4) * 4
+    w = torch.zeros(Cc, ldw)
+    w[:, :K] = torch.randn(Cc, K, generator=g) * (2.6 / Cc) ** 0.5
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.rand(K, generator=g) - 0.5
+    mm0, mv0 = torch.randn(K, generator=g) * 0.1, torch.rand(K, generator=g) + 0.5
+    lo = plane_bytes(rows, Cc)
+    plan = ops.Plan(device, eager=True)
+    xp = torch.zeros(lo * 2, dtype=torch.uint8, device=device)
+    ops.bn_relu_split(plan, x.to(device), torch.ones(Cc, device=device), torch.zeros(Cc, device=device), 1, xp, lo, rows, Cc)
+    need = ops.gram_stats_workspace(rows, Cc)
+    assert need > 0
+    outs = []
+    for rep in range(2):
+        ws = torch.full((need,), 0xff if rep else 0, dtype=torch.uint8, device=device)      # no dependence on its contents
+        sc = torch.full((K,), float("nan"), device=device)
+        sh = torch.full((K,), float("nan"), device=device)
+        mm, mv = mm0.to(device), mv0.to(device)
+        ops.gram_stats(plan, xp, lo, rows, Cc, w.to(device), ldw, K, gamma.to(device), beta.to(device), mm, mv, sc, sh, ws,
+                       decay=0.997, eps=1e-5)
+        torch.cuda.synchronize()
+        outs.append((sc.cpu(), sh.cpu(), mm.cpu(), mv.cpu()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    sc, sh, mm, mv = outs[0]
+    # fp64 reference on the values the planes hold (hi + lo: x to 2^-22)
+    xv = unsplit(xp, lo, rows, Cc).double().cpu()
+    y = xv @ w[:, :K].double()
+    mean = y.mean(0)
+    var = (y * y).mean(0) - mean * mean
+    inv = 1.0 / torch.sqrt(var.float() + 1e-5).double()
+    sc_ref = gamma.double() * inv
+    sh_ref = beta.double() - mean.float().double() * sc_ref
+    # statistics: mean to 1e-6 of the output's scale, variance to 2e-6 relative
+    mean_got = (beta.double() - sh.double()) / sc.double()
+    var_got = (gamma.double() / sc.double()) ** 2 - 1e-5
+    scale_y = float(y.abs().max()) if rows > 1 else 1.0
+    assert float((mean_got - mean).abs().max()) <= 2e-6 * scale_y, float((mean_got - mean).abs().max())
+    if rows > 1:
+        assert float(((var_got - var).abs() / var.clamp_min(1e-12)).max()) <= 4e-6, float(((var_got - var).abs() / var).max())
+    close(sc, sc_ref, tol=3e-6, what="gram scale %s" % (case,))
+    close(sh, sh_ref, tol=3e-6, what="gram shift %s" % (case,))
+    unb = var * (rows / (rows - 1.0)) if rows > 1 else var
+    close(mm, 0.997 * mm0.double() + 0.003 * mean, tol=2e-6, what="gram moving mean")
+    close(mv, 0.997 * mv0.double() + 0.003 * unb, tol=2e-6, what="gram moving variance")
+    # the statistics pass this replaces (same planes, split weights), finalised by acimg_bn_finalize
+    if K % 128 == 0 and rows >= 128 * 200:
+        d = ops.conv_desc(1, 1, rows, Cc, K, 1, 1, 1, "SAME")
+        wsplit = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=device)
+        ops.conv2d_split3_prepare(plan, d, w[:, :K].reshape(1, 1, Cc, K).contiguous().to(device), wsplit)
+        tws = torch.zeros(ops.conv2d_fwd_split3p_workspace(d), dtype=torch.uint8, device=device)
+        srows = ops.conv2d_fwd_split3p_stats_rows(d)
+        st = torch.zeros(srows, 2, K, device=device)
+        ops.conv2d_fwd_split3p_stats(plan, d, xp, lo, wsplit, st, tail_ws=tws)
+        sc2, sh2 = torch.zeros(K, device=device), torch.zeros(K, device=device)
+        mm2, mv2 = mm0.to(device), mv0.to(device)
+        ops.bn_finalize(plan, st, srows, K, K, rows, gamma.to(device), beta.to(device), mm2, mv2, sc2, sh2, 0.997, 1e-5, True)
+        torch.cuda.synchronize()
+        close(sc, sc2.cpu(), tol=3e-6, what="gram scale vs statistics pass")
+        close(sh, sh2.cpu(), tol=3e-6, what="gram shift vs statistics pass")
+
+
 @pytest.mark.parametrize("case", [(3, 14, 19, 64, 128), (2, 28, 38, 32, 160), (1, 56, 75, 32, 128), (5, 9, 79, 32, 128),
                                   (37, 5, 3, 32, 128), (200, 3, 1, 64, 128), (1, 1, 1, 32, 128), (2, 75, 56, 96, 256)])
 def test_halo_kernel_edges(device, case):
