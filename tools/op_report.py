@@ -1,5 +1,5 @@
 """Per-call report of the recorded train step, measured in place: every C-ABI call of the plan is bracketed with
-events (Plan.run_probed) over a few steps.  Run on the GPU box.  usage: python tools/op_report.py [batch] [first_call] [trainer_mask|unet_rgb|unet_sound]"""
+events (Plan.run_probed) over a few steps.  Run on the GPU box.  usage: python tools/op_report.py [batch] [first_call] [trainer_mask|unet_rgb|unet_sound] [precision of the U-Net: split|bf16|f32]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "acoustic-image-generation_amd"))
@@ -30,7 +30,8 @@ if workload == "trainer_mask":
 else:
     from acimg.trainer_vae import TrainerVAE
     from acimg.unet_vae import UNet, UNetSound
-    tr = TrainerVAE((UNet if workload == "unet_rgb" else UNetSound)(), learning_rate=1e-4, session=sess)
+    prec = sys.argv[4] if len(sys.argv) > 4 else "split"
+    tr = TrainerVAE((UNet if workload == "unet_rgb" else UNetSound)(precision=prec), learning_rate=1e-4, session=sess)
     g = tr._build_functions(batch_size=B)
     tr.model.initialize(seed=1240)
     g.images.copy_(torch.rand(*g.images.shape, generator=gen))
