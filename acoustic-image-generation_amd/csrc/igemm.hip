@@ -35,9 +35,37 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const float* s
     float v = 0.f;
     for (int z = 0; z < splits; ++z) v += slab[((long)z * M + m) * slab_ld + n];
     if (n >= e.Nstore) return;
-    int cn, pixoff;
-    epi_col(e, n, cn, pixoff);
-    epi_store(e, epi_row_pix(e, m) + pixoff, cn, v);
+    int cn, pixoff, r, q, oh, ow;
+    epi_col(e, n, cn, pixoff, r, q);
+    const long rp = epi_row_pix(e, m, oh, ow);
+    if (epi_lands(e, oh, ow, r, q)) epi_store(e, rp + pixoff, cn, v);
+}
+
+// ------------------------------------------------------------------------------------------
+// SUB-PIXEL form of the stride-2 transposed convolutions with overlapping taps (round 4): the transposed conv
+// `conv2d_transpose(k > 2, s = 2)` (models/unet_architecture.py:192-206: upconv_2D with (2,3) kernels) and the data
+// gradient of a stride-2 conv (the strided "pool" convs, :168-176).  Both compute
+//     Y[s i + a + oy0][s j + b + ox0][ko] = sum_{u, v, kin} A[i - u][j - v][kin] * w[a + 2 u][b + 2 v][ko][kin]
+// i.e. an output pixel of parity class (a, b) only sees the kernel taps of its class: ceil(R/2) x ceil(S/2) of them.
+// Round 1 ran these as a stride-1 correlation over a ZERO-INSERTED copy of A (4x the pixels, 3 of 4 products against
+// zeros, plus the copy's 4x write and read).  Here the four classes are the column groups of ONE implicit GEMM over A's own
+// grid - rows (i, j), K = (u', v', kin) with a ceil(R/2) x ceil(S/2) gather, columns (a, b, ko) - whose epilogue scatters
+// element (i, j, a, b, ko) to pixel (2 i + a + oy0, 2 j + b + ox0): the k <= s scatter of the non-overlapping transposed
+// convs, bounds-checked (EpiParams::scatter = 2).  The combined weight matrix is gathered from the layer's kernel by
+// `subpixel_weights_kernel` (the kernels change every step).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void subpixel_weights_kernel(const float* w, int R, int S, int Ko, int Kin, int ldw, int U,
+                                                               int V, float* wc, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int ncol = 4 * Ko;
+    const int row = idx / ncol, col = idx - row * ncol;
+    const int kin = row % Kin, tap = row / Kin;
+    const int up = tap / V, vp = tap - up * V;
+    const int cls = col / Ko, ko = col - cls * Ko;
+    const int a = cls >> 1, b = cls & 1;
+    const int r = a + 2 * (U - 1 - up), q = b + 2 * (V - 1 - vp);
+    wc[idx] = (r < R && q < S) ? w[((long)(r * S + q) * Ko + ko) * ldw + kin] : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1290,6 +1318,47 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
     return launch_igemm(p, false, ws, ws_bytes, tickets, (hipStream_t)stream);
 }
 
+// the sub-pixel form pays from 16 output channels on: with 8 (the full-resolution layers) its scatter writes 16-byte
+// pieces of 32-byte pixels and the zero-inserted copy + the direct few-channel kernel is faster (224x298 8->8 3x3/2 data
+// gradient: 99 us against 144 us; profiles/r04/op_report_unet_rgb_bf16_r04g_subpixel.txt)
+static bool subpixel_ok(int stride, int Ko, int Kin) { return stride == 2 && (Ko & 3) == 0 && (Kin & 3) == 0 && Ko >= 16; }
+static size_t subpixel_ws_bytes(int N, int YH, int YW, int oy0, int ox0, int R, int S, int Kin, int Ko) {
+    const int U = (R + 1) / 2, V = (S + 1) / 2;
+    const int AH = (YH - 1 - oy0) / 2 + 1, AW = (YW - 1 - ox0) / 2 + 1;
+    const size_t wc = ((size_t)U * V * Kin * 4 * Ko * 4 + 255) & ~(size_t)255;
+    const size_t a = igemm_ws_bytes(N * AH * AW, 4 * Ko, U * V * cdiv(Kin, 32));
+    const size_t b = igemm_ws_bytes(N * AH * AW, 4 * Ko, U * cdiv(V * Kin, 32));
+    return wc + (a > b ? a : b);
+}
+// A: [N][aH][aW][Kin] (pixel stride lda); w[r][s][ko][kin] with row pitch ldw; Y: [N][YH][YW] pixels of ldy floats
+static int launch_subpixel(const float* A, int N, int aH, int aW, int Kin, int lda, const float* w, int R, int S, int ldw,
+                           int Ko, float* Y, int ldy, int YH, int YW, int oy0, int ox0, const float* bias, const float* res,
+                           int ldres, const float* mask, int ldmask, int act, void* ws, size_t ws_bytes, void* tickets,
+                           hipStream_t st, const char* what) {
+    const int U = (R + 1) / 2, V = (S + 1) / 2;
+    const int AH = (YH - 1 - oy0) / 2 + 1, AW = (YW - 1 - ox0) / 2 + 1;
+    const int rows = U * V * Kin, ncol = 4 * Ko;
+    const size_t wcb = ((size_t)rows * ncol * 4 + 255) & ~(size_t)255;
+    if (!ws || ws_bytes < wcb || !aligned16(ws)) return fail(ACIMG_EWORKSPACE, "%s: workspace too small for the sub-pixel weights", what);
+    if ((Ko & 3) || (Kin & 3)) return fail(ACIMG_EINVAL, "%s: channel counts must be multiples of 4", what);
+    float* wc = static_cast<float*>(ws);
+    hipLaunchKernelGGL(subpixel_weights_kernel, dim3(cdiv((long)rows * ncol, 256)), dim3(256), 0, st, w, R, S, Ko, Kin, ldw, U, V, wc,
+                       rows * ncol);
+    int rc = check_launch("subpixel_weights");
+    if (rc) return rc;
+    IgemmParams p{};
+    p.A = A; p.H = aH; p.W = aW; p.C = Kin; p.lda = lda; p.OH = AH; p.OW = AW;
+    p.R = U; p.S = V; p.stride = 1; p.pad_t = U - 1; p.pad_l = V - 1;
+    p.M = N * AH * AW;
+    p.rowrun = (V > 1 && lda == Kin) ? 1 : 0;
+    p.B = wc; p.ldb = ncol; p.Nld = ncol; p.Ngemm = ncol; p.tap_stride = 0; p.flip = 0;
+    p.e.Y = Y; p.e.ldy = ldy; p.e.M = p.M; p.e.Nstore = ncol; p.e.bias = bias; p.e.act = act;
+    p.e.res = res; p.e.ldres = ldres; p.e.mask = mask; p.e.ldmask = ldmask;
+    p.e.scatter = 2; p.e.Ko = Ko; p.e.Sq = 2; p.e.sc = 2; p.e.YH = YH; p.e.YW = YW; p.e.AH = AH; p.e.AW = AW;
+    p.e.oy0 = oy0; p.e.ox0 = ox0;
+    return launch_igemm(p, false, static_cast<char*>(ws) + wcb, ws_bytes - wcb, tickets, st);
+}
+
 static bool dgrad_is_patch(const AcimgConvDesc* d) {
     return d->stride > 1 && d->stride == d->R && d->stride == d->S && !d->pad_t && !d->pad_l &&
            d->OH * d->stride == d->H && d->OW * d->stride == d->W;
@@ -1301,6 +1370,8 @@ static size_t dilated_bytes(int N, int H, int W, int C, int s) {
 size_t acimg_conv2d_dgrad_workspace(const AcimgConvDesc* d) {
     if (dgrad_is_patch(d)) return igemm_ws_bytes(d->N * d->OH * d->OW, d->R * d->S * d->C, cdiv(up4(d->K), 32));
     const int ca = up4(d->K);
+    if (subpixel_ok(d->stride, d->C, ca))   // sub-pixel form: combined weights + the GEMM's own split-K slabs
+        return subpixel_ws_bytes(d->N, d->H, d->W, -d->pad_t, -d->pad_l, d->R, d->S, ca, d->C);
     if (d->stride > 1)   // zero-inserted copy of gy, then the stride-1 path
         return dilated_bytes(d->N, d->OH, d->OW, ca, d->stride) +
                igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * d->S * cdiv(ca, 32)) +
@@ -1341,6 +1412,11 @@ int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
     if (lddx < d->C) return fail(ACIMG_EINVAL, "conv2d_dgrad: lddx < C");
     p.e.Y = dx; p.e.ldy = lddx; p.e.res = residual; p.e.ldres = ldres; p.e.mask = mask; p.e.ldmask = ldmask;
     p.e.act = ACIMG_ACT_NONE;
+    if (subpixel_ok(d->stride, d->C, ca) && !dgrad_is_patch(d))
+        // dx[2 oy - pad_t + r][2 ox - pad_l + s][c] += gy[oy][ox][k] w[r][s][c][k]: the sub-pixel form over gy's own grid
+        return launch_subpixel(gy, d->N, d->OH, d->OW, ca, ldgy, w, d->R, d->S, d->ldw, d->C, dx, lddx, d->H, d->W, -d->pad_t,
+                               -d->pad_l, nullptr, residual, ldres, mask, ldmask, ACIMG_ACT_NONE, ws, ws_bytes, tickets,
+                               (hipStream_t)stream, "conv2d_dgrad");
     if (d->stride > 1 && !dgrad_is_patch(d)) {
         // general stride: the strided conv is a subsampled stride-1 conv, so its data gradient is the stride-1
         // data gradient of the zero-inserted gy
@@ -1433,6 +1509,10 @@ size_t acimg_deconv_workspace(const AcimgConvDesc* d) {
         const size_t dd = direct_ws_bytes(d->R, d->S, up4(d->K), (d->C + 7) & ~7);
         m = m > dd ? m : dd;
     }
+    if ((d->R > d->stride || d->S > d->stride) && subpixel_ok(d->stride, d->K, d->C)) {   // forward in the sub-pixel form
+        const size_t sp = subpixel_ws_bytes(d->N, d->OH, d->OW, 0, 0, d->R, d->S, d->C, d->K);
+        return m > sp ? m : sp;
+    }
     if (d->R > d->stride || d->S > d->stride)   // forward goes through a zero-inserted copy of x
         m += dilated_bytes(d->N, d->H, d->W, d->C, d->stride) +
              igemm_ws_bytes(d->N * d->OH * d->OW, d->K, d->R * d->S * cdiv(d->C, 32)) +
@@ -1451,6 +1531,12 @@ int acimg_deconv_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
         // [OH,OW,K] -> [(H-1)s+1, (W-1)s+1, C] whose HWIO kernel is this layer's [R][S][K][C]
         if (d->OH != (d->H - 1) * d->stride + d->R || d->OW != (d->W - 1) * d->stride + d->S)
             return fail(ACIMG_EINVAL, "deconv_fwd: kernel>stride needs OH=(H-1)*stride+R");
+        if (subpixel_ok(d->stride, d->K, d->C))
+            // y[2 h + r][2 w + s][k] += x[h][w][c] W[r][s][k][c]: the sub-pixel form over x's own grid (every output
+            // pixel belongs to exactly one parity class: written once, bias included)
+            return launch_subpixel(x, d->N, d->H, d->W, d->C, d->ldx, w, d->R, d->S, d->ldw, d->K, y, d->ldy, d->OH, d->OW, 0, 0,
+                                   bias, nullptr, 0, nullptr, 0, d->act, ws, ws_bytes, tickets, (hipStream_t)stream,
+                                   "deconv_fwd");
         const size_t db = dilated_bytes(d->N, d->H, d->W, d->C, d->stride);
         if (ws_bytes < db || !ws) return fail(ACIMG_EWORKSPACE, "deconv_fwd: workspace too small for the dilated input");
         const int H1 = (d->H - 1) * d->stride + 1, W1 = (d->W - 1) * d->stride + 1;

@@ -18,8 +18,11 @@ struct EpiParams {
     int act;
     // scatter mode (kernel<=stride transposed conv / patch dgrad): row m is a pixel (img,h,w) of
     // an AH x AW grid, column n = (tap, ko); element lands at pixel (img, sc*h+r, sc*w+q), chan ko
+    // scatter = 2 (round 4, sub-pixel form of a stride-2 transposed conv / data gradient with OVERLAPPING taps): as 1,
+    // the landing pixel shifted by (oy0, ox0) and dropped when it falls outside YH x YW
     int scatter;
     int Ko, Sq, sc, YH, YW, AH, AW;
+    int oy0, ox0;
     // per-row-block column statistics of the raw accumulator (batch-norm), [gridDim.x][2][stats_ld]
     float* stats;
     int stats_ld;

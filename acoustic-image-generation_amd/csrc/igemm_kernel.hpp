@@ -23,26 +23,46 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigne
 constexpr unsigned OOB = 0x80000000u;  // >= num_records of every descriptor (tensors < 2 GiB)
 
 // ---- epilogue -------------------------------------------------------------------------------
-__device__ __forceinline__ long epi_row_pix(const EpiParams& e, int m) {
+// row m -> linear output pixel; (oh, ow): where tap (0, 0) of the row lands (scatter modes)
+__device__ __forceinline__ long epi_row_pix(const EpiParams& e, int m, int& oh, int& ow) {
+    oh = 0;
+    ow = 0;
     if (!e.scatter) return m;
     const int hw = e.AH * e.AW;
     const int img = m / hw;
     const int rem = m - img * hw;
     const int h = rem / e.AW;
     const int w = rem - h * e.AW;
-    return ((long)img * e.YH + (long)e.sc * h) * e.YW + (long)e.sc * w;
+    oh = e.sc * h + e.oy0;
+    ow = e.sc * w + e.ox0;
+    return ((long)img * e.YH + oh) * e.YW + ow;
 }
-__device__ __forceinline__ void epi_col(const EpiParams& e, int n, int& cn, int& pixoff) {
+__device__ __forceinline__ long epi_row_pix(const EpiParams& e, int m) {
+    int oh, ow;
+    return epi_row_pix(e, m, oh, ow);
+}
+// column n -> channel, pixel offset of its tap, and the tap (r, q) itself
+__device__ __forceinline__ void epi_col(const EpiParams& e, int n, int& cn, int& pixoff, int& r, int& q) {
+    r = 0;
+    q = 0;
     if (!e.scatter) {
         cn = n;
         pixoff = 0;
     } else {
         const int t = n / e.Ko;
         cn = n - t * e.Ko;
-        const int r = t / e.Sq;
-        const int q = t - r * e.Sq;
+        r = t / e.Sq;
+        q = t - r * e.Sq;
         pixoff = r * e.YW + q;
     }
+}
+__device__ __forceinline__ void epi_col(const EpiParams& e, int n, int& cn, int& pixoff) {
+    int r, q;
+    epi_col(e, n, cn, pixoff, r, q);
+}
+// scatter = 2: does tap (r, q) of a row whose tap (0, 0) lands at (oh, ow) fall inside the output?
+__device__ __forceinline__ bool epi_lands(const EpiParams& e, int oh, int ow, int r, int q) {
+    return e.scatter != 2 || ((unsigned)(oh + r) < (unsigned)e.YH && (unsigned)(ow + q) < (unsigned)e.YW);
 }
 __device__ __forceinline__ float epi_act(float v, int act) {
     if (act == ACIMG_ACT_RELU) return fmaxf(v, 0.f);
@@ -120,19 +140,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
     }
 
     const EpiParams& e = p.e;
-    int cn[TN], pixoff[TN];
+    int cn[TN], pixoff[TN], tr[TN], tq[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) epi_col(e, n0 + wn * WTN + j * 16 + 4 * g, cn[j], pixoff[j]);
+    for (int j = 0; j < TN; ++j) epi_col(e, n0 + wn * WTN + j * 16 + 4 * g, cn[j], pixoff[j], tr[j], tq[j]);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * WTM + i * 16 + li;
         if (m >= e.M || stats_only) continue;
-        const long rp = epi_row_pix(e, m);
+        int oh, ow;
+        const long rp = epi_row_pix(e, m, oh, ow);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n4 = n0 + wn * WTN + j * 16 + 4 * g;
             const int nvalid = e.Nstore - n4;
-            if (nvalid > 0)
+            if (nvalid > 0 && epi_lands(e, oh, ow, tr[j], tq[j]))
                 epi_store4(e, rp + pixoff[j], cn[j], nvalid < 4 ? nvalid : 4,
                            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]));
         }
