@@ -199,27 +199,51 @@ def regulariser(model, p):
 ORDER = (("ac", "UNetAc2"), ("video", "Unet2"), ("audio", "UNetSound22"))     # tf.concat order of Jointmvae's inputs
 
 
-def joint_forward(params, pj, batch, eps, relu_masks=None):
-    """params {modality: model params}, pj: Jointmvae params, batch / eps {modality: tensor}.
-    -> (per-modality decoder outputs, features, new moving statistics, relu masks)"""
+MODES = ("all", "fusion", "onlyaudiovideo")
+# the fusion MLP each mode TRAINS and the modalities it reads (trainer/trainermulti.py:50-53,98; main.py:194-201)
+MODE_MLP = {"all": ("Jointmvae", ("ac", "video", "audio")), "fusion": ("JointTwomvae2", ("video", "audio")),
+            "onlyaudiovideo": ("JointTwomvae", ("video", "audio"))}
+
+
+def joint_forward(params, pj, batch, eps, relu_masks=None, mode="all", pj0=None, moddrop_on=None):
+    """params {modality: model params}, pj: the trained fusion MLP's params, batch / eps {modality: tensor}.
+    mode "all": Jointmvae on the three feature maps, three decoders (trainermulti.py:53-81);
+         "fusion": JointTwomvae2 on (video, audio), three decoders (:50-51);
+         "onlyaudiovideo": the FROZEN Jointmvae `pj0` on the three maps gives the acoustic feature target, JointTwomvae on
+                           (video, audio) feeds the acoustic decoder alone (:97-103).
+    moddrop_on: FLAGS.moddrop - the scalar 0 / 1 that multiplies the acoustic feature map (`modDrop`, :446-450; the one
+    random draw per step is an explicit input).
+    -> (decoder outputs, features, heads of the trained MLP, new moving statistics, relu masks, heads of pj0 or None)"""
     rm = relu_masks or {}
+    scope, reads = MODE_MLP[mode]
     nets = OrderedDict((m, _Net(model, params[m], True, rm.get(m))) for m, model in ORDER)
     feats = OrderedDict((m, nets[m].encoder(batch[m])) for m, _ in ORDER)
-    heads, jm = multimodal.joint_forward(pj, "Jointmvae", [feats[m] for m, _ in ORDER], rm.get("joint"))
-    outs = OrderedDict((m, nets[m].decoder(heads["output" + m], eps[m])) for m, _ in ORDER)
+    if moddrop_on is not None:
+        feats["ac"] = feats["ac"] * float(moddrop_on)
+    heads, jm = multimodal.joint_forward(pj, scope, [feats[m] for m in reads], rm.get("joint"))
+    heads0 = None
+    decoded = [m for m, _ in ORDER]
+    if mode == "onlyaudiovideo":
+        with torch.no_grad():
+            heads0, _ = multimodal.joint_forward(pj0, "Jointmvae", [feats[m] for m, _ in ORDER], rm.get("joint0"))
+        decoded = ["ac"]
+    outs = OrderedDict((m, nets[m].decoder(heads["output" + m], eps[m])) for m in decoded)
     stats = OrderedDict()
     masks = OrderedDict(joint=jm)
     for m, _ in ORDER:
         stats.update(nets[m].new_stats)
         masks[m] = nets[m].masks
-    return outs, feats, heads, stats, masks
+    return outs, feats, heads, stats, masks, heads0
 
 
-def joint_losses(params, batch, outs):
-    """trainer/trainermulti.py:58-81"""
+def joint_losses(params, batch, outs, mode="all", heads=None, heads0=None):
+    """trainer/trainermulti.py:58-81 (all / fusion) and :100-106 (onlyaudiovideo: + the feature-matching MSE; the decoder
+    regularisers of the video / audio models are not in that graph: only their `_build_network` halves were built)"""
     ls = OrderedDict()
     mse = hub = kl = 0.0
     for m, model in ORDER:
+        if m not in outs:
+            continue
         ls["mse_" + m] = tfsem.mse_loss(batch[m], outs[m]["output"])
         ls["huber_" + m] = tfsem.huber_loss(batch[m], outs[m]["output"])
         mu, sg = outs[m]["mean"], outs[m]["std"]
@@ -227,22 +251,39 @@ def joint_losses(params, batch, outs):
         mse, hub = mse + ls["mse_" + m], hub + ls["huber_" + m]
     ls["mse"], ls["huber"] = mse, hub
     ls["latent"] = kl.mean(0) / 1000000
-    ls["reg"] = sum(regulariser(model, params[m]) for m, model in ORDER)
-    ls["loss"] = ls["latent"] + mse + hub + ls["reg"]
+    if mode == "onlyaudiovideo":
+        ls["feature"] = tfsem.mse_loss(heads0["outputac"], heads["outputac"])
+        reg = 0.0
+        for m, model in ORDER:
+            cfg = MODELS[model]
+            for n, w in params[m].items():
+                if n.endswith("/kernel") and ("/layer" in n or "/upsample_" in n) and is_encoder_var(model, n) and cfg["wd_enc"]:
+                    reg = reg + tfsem.l2_regularizer(w, cfg["wd_enc"])
+        ls["reg"] = reg
+        ls["loss"] = ls["latent"] + mse + hub + ls["feature"] + ls["reg"]
+    else:
+        ls["reg"] = sum(regulariser(model, params[m]) for m, model in ORDER)
+        ls["loss"] = ls["latent"] + mse + hub + ls["reg"]
     return ls
 
 
 class Oracle(object):
-    def __init__(self, learning_rate=1e-4, dtype=torch.float32, params=None, joint_params=None, seed=1251):
-        self.lr, self.dtype = learning_rate, dtype
+    def __init__(self, learning_rate=1e-4, dtype=torch.float32, params=None, joint_params=None, seed=1251, mode="all"):
+        assert mode in MODES
+        self.lr, self.dtype, self.mode = learning_rate, dtype, mode
         self.params = OrderedDict()
         for i, (m, model) in enumerate(ORDER):
             src = params[m] if params is not None else init_params(model, seed + i, bias_std=0.02, bn_jitter=0.1)
             self.params[m] = OrderedDict((k, v.to(dtype).clone()) for k, v in src.items())
-        cin = sum(feature_channels(model) for _, model in ORDER)
-        src = joint_params if joint_params is not None else multimodal.joint_init_params("Jointmvae", cin, seed + 7,
-                                                                                         bias_std=0.02)
+        fc = OrderedDict((m, feature_channels(model)) for m, model in ORDER)
+        scope, reads = MODE_MLP[mode]
+        cin = sum(fc[m] for m in reads)
+        src = joint_params if joint_params is not None else multimodal.joint_init_params(scope, cin, seed + 7, bias_std=0.02)
         self.pj = OrderedDict((k, v.to(dtype).clone()) for k, v in src.items())
+        self.pj0 = None
+        if mode == "onlyaudiovideo":       # the frozen three-modality MLP that provides the feature target
+            src0 = multimodal.joint_init_params("Jointmvae", sum(fc.values()), seed + 8, bias_std=0.02)
+            self.pj0 = OrderedDict((k, v.to(dtype).clone()) for k, v in src0.items())
         self.m = OrderedDict((k, torch.zeros_like(v)) for k, v in self.pj.items())
         self.v = OrderedDict((k, torch.zeros_like(v)) for k, v in self.pj.items())
         self.step = 0
@@ -252,15 +293,18 @@ class Oracle(object):
         for m, _ in ORDER:
             out.update(self.params[m])
         out.update(self.pj)
+        if self.pj0 is not None:
+            out.update(self.pj0)
         return out
 
-    def train_step(self, batch, eps, apply=True, relu_masks=None):
+    def train_step(self, batch, eps, apply=True, relu_masks=None, moddrop_on=None):
         dt = self.dtype
         batch = OrderedDict((k, v.to(dt)) for k, v in batch.items())
         eps = OrderedDict((k, v.to(dt)) for k, v in eps.items())
         pj = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in self.pj.items())
-        outs, feats, heads, stats, masks = joint_forward(self.params, pj, batch, eps, relu_masks)
-        ls = joint_losses(self.params, batch, outs)
+        outs, feats, heads, stats, masks, heads0 = joint_forward(self.params, pj, batch, eps, relu_masks, self.mode, self.pj0,
+                                                                 moddrop_on)
+        ls = joint_losses(self.params, batch, outs, self.mode, heads, heads0)
         names = list(pj)
         grads = torch.autograd.grad(ls["loss"], [pj[k] for k in names])
         g = OrderedDict(zip(names, grads))
@@ -273,7 +317,7 @@ class Oracle(object):
                     if k in self.params[m]:
                         self.params[m][k] = v.detach()
         return dict(losses=OrderedDict((k, float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in ls.items()),
-                    grads=g, outs=outs, feats=feats, heads=heads, new_stats=stats, masks=masks)
+                    grads=g, outs=outs, feats=feats, heads=heads, heads0=heads0, new_stats=stats, masks=masks)
 
 
 def synthetic_batch(n, seed=1234, dtype=torch.float32):

@@ -41,8 +41,11 @@ def _device_masks(tr):
                 mm[name] = (a.t.view(a.N, a.H, a.W, -1)[..., :a.C] > 0).cpu()
             mm["dense"] = (m.dns.t > 0).cpu().reshape(m.N, -1)
         masks[key] = mm
-    ma = tr.modelassociator
+    ma = tr.modelassociator1 if tr.mode == "onlyaudiovideo" else tr.modelassociator
     masks["joint"] = OrderedDict((name, (y[:, :d.K] > 0).cpu().view(g.N, 12, 16, d.K)) for name, d, x, ldx, y, attr in ma.layers)
+    if tr.mode == "onlyaudiovideo":      # the frozen three-modality MLP that provides the feature target
+        m0 = tr.modelassociator
+        masks["joint0"] = OrderedDict((name, (y[:, :d.K] > 0).cpu().view(g.N, 12, 16, d.K)) for name, d, x, ldx, y, attr in m0.layers)
     return masks
 
 
@@ -90,3 +93,64 @@ def test_joint_step_matches_oracle():
     assert moved and all(k.startswith("Jointmvae/") for k in moved), moved[:5]
     for k in moved:
         assert rel(after[k], oracle_after[k]) < 2e-3, k
+
+
+
+@pytest.mark.parametrize("mode,moddrop_on", [("fusion", None), ("onlyaudiovideo", None), ("all", 0.0), ("all", 1.0)])
+def test_joint_step_other_branches(mode, moddrop_on):
+    """The other branches of trainer/trainermulti.py `_build_functions` (round 4): `fusion` (:50-51, JointTwomvae2 on the video
+    and audio maps, three decoders), `onlyaudiovideo` (:97-125, the frozen Jointmvae's acoustic head as a feature target for
+    JointTwomvae, the acoustic decoder alone, + the feature-matching MSE) and FLAGS.moddrop (:46-47: the acoustic feature map
+    times the step's 0 / 1 draw) - loss terms, heads, reconstructions, every gradient of the trained MLP, and the Adam step
+    moving that MLP only, against oracle/joint.py"""
+    from acimg.multimodal import Jointmvae, JointTwomvae, JointTwomvae2
+    from acimg.session import Session
+    from acimg.trainer_multi import TrainerMulti
+    from acimg.unet_joint import UNetAc2, UNetSound22, Unet2
+    from oracle import joint
+
+    dev = torch.device("cuda:0")
+    N = 2
+    orc = joint.Oracle(learning_rate=1e-3, mode=mode)
+    sess = Session(dev)
+    assoc = {"all": Jointmvae, "fusion": JointTwomvae2, "onlyaudiovideo": Jointmvae}[mode]()
+    assoc1 = JointTwomvae() if mode == "onlyaudiovideo" else None
+    tr = TrainerMulti(UNetAc2([36, 48, 12]), UNetSound22([193, 257, 1]), Unet2([224, 298, 3]), assoc, assoc1,
+                      learning_rate=1e-3, session=sess, mode=mode, moddrop=moddrop_on is not None)
+    g = tr._build_functions(batch_size=N)
+    sess.store.load_state(orc.state_dict(), strict=True)
+    before = {k: v.clone() for k, v in sess.store.state_dict().items()}
+    batch, eps = joint.synthetic_batch(N, seed=77)
+    got = tr.train_step((batch["ac"], batch["audio"], batch["video"]), eps=eps, apply=False, moddrop_on=moddrop_on)
+    torch.cuda.synchronize()
+    masks = _device_masks(tr)
+    ref = orc.train_step(batch, eps, apply=True, relu_masks=masks, moddrop_on=moddrop_on)
+    keys = ["mse_ac", "huber_ac", "latent", "reg", "loss"]
+    if mode != "onlyaudiovideo":
+        keys += ["mse_video", "huber_video", "mse_audio", "huber_audio"]
+    else:
+        keys += ["feature"]
+    for k in keys:
+        assert abs(got[k] - ref["losses"][k]) <= 1e-3 * abs(ref["losses"][k]) + 1e-12, (mode, k, got[k], ref["losses"][k])
+    trained = tr.modelassociator1 if mode == "onlyaudiovideo" else tr.modelassociator
+    for key, (m, _, attr) in g.mods.items():
+        assert rel(getattr(trained, attr), ref["heads"][attr]) < 1e-3, attr
+        assert rel(m.output[..., :m.channels], ref["outs"][key]["output"]) < 1e-3, key
+        assert rel(m.mean, ref["outs"][key]["mean"]) < 1e-3 and rel(m.std, ref["outs"][key]["std"]) < 1e-3, key
+    if mode == "onlyaudiovideo":
+        assert rel(tr.modelassociator.outputac, ref["heads0"]["outputac"]) < 1e-3
+    if moddrop_on == 0.0:        # the acoustic map is dropped: the MLP sees zeros there
+        assert float(g.concat[..., :133].abs().max()) == 0.0
+    grads = sess.store.grad_dict()
+    worst = max((rel(grads[k], v), k) for k, v in ref["grads"].items())
+    print("%s: worst gradient %s %.2e" % (mode, worst[1], worst[0]))
+    assert worst[0] < 1e-3, worst
+    tr.train_step(None, eps=eps, apply=True, moddrop_on=moddrop_on)
+    torch.cuda.synchronize()
+    after = sess.store.state_dict()
+    oracle_after = orc.state_dict()
+    moved = [k for k in after if not torch.equal(after[k], before[k]) and not k.endswith(("moving_mean", "moving_variance"))]
+    assert moved and all(k.startswith(trained.scope + "/") for k in moved), moved[:5]
+    for k in moved:
+        assert rel(after[k], oracle_after[k]) < 2e-3, k
+

@@ -450,6 +450,50 @@ def test_joint_mlp_oracle_and_host_graph(which, widths):
         getattr(multimodal, which)()._build_model(*parts[::-1], session=Session(torch.device("cpu")))
 
 
+@pytest.mark.parametrize("mode", ["all", "fusion", "onlyaudiovideo"])
+def test_joint_trainer_branches_oracle_and_host_graph(mode):
+    """the three branches of trainer/trainermulti.py `_build_functions` (FLAGS.fusion / FLAGS.onlyaudiovideo, main.py:194-201):
+    the oracle's loss terms and trained variable set per mode, and the device plan recorded on a CPU session (which MLP
+    the Adam range covers, which decoders exist)"""
+    from acimg.multimodal import Jointmvae, JointTwomvae, JointTwomvae2
+    from acimg.session import Session
+    from acimg.trainer_multi import TrainerMulti
+    from acimg.unet_joint import UNetAc2, UNetSound22, Unet2
+    from oracle import joint
+
+    scope = {"all": "Jointmvae", "fusion": "JointTwomvae2", "onlyaudiovideo": "JointTwomvae"}[mode]
+    o = joint.Oracle(learning_rate=1e-3, mode=mode)
+    assert all(k.startswith(scope + "/") for k in o.pj)
+    assert o.pj[scope + "/dense/kernel"].shape[0] == (773 if mode == "all" else 640)     # 133 + 512 + 128 | 512 + 128
+    assert (o.pj0 is not None) == (mode == "onlyaudiovideo")
+    b, e = joint.synthetic_batch(1)
+    r = o.train_step(b, e, apply=False, moddrop_on=0.0 if mode == "all" else None)
+    ls = r["losses"]
+    if mode == "onlyaudiovideo":
+        assert "feature" in ls and "mse_video" not in ls and len(r["grads"]) == 8
+        assert abs(ls["loss"] - (ls["mse"] + ls["huber"] + ls["latent"] + ls["feature"] + ls["reg"])) < 1e-6
+        full = sum(float(joint.regulariser(model, o.params[m])) for m, model in joint.ORDER)
+        assert 0 < ls["reg"] < full                    # encoder regularisers only: the video / audio decoders are not built
+    else:
+        assert set(k for k in ls if k.startswith("mse_")) == {"mse_ac", "mse_video", "mse_audio"} and len(r["grads"]) == 12
+    if mode == "all":                                  # modDrop with the step's draw at 0: the acoustic map is zeros
+        assert float(r["feats"]["ac"].abs().max()) == 0.0
+    sess = Session(torch.device("cpu"))
+    assoc = {"all": Jointmvae, "fusion": JointTwomvae2, "onlyaudiovideo": Jointmvae}[mode]()
+    assoc1 = JointTwomvae() if mode == "onlyaudiovideo" else None
+    tr = TrainerMulti(UNetAc2([36, 48, 12]), UNetSound22([193, 257, 1]), Unet2([224, 298, 3]), assoc, assoc1, session=sess,
+                      mode=mode, moddrop=mode == "all")
+    g = tr._build_functions(batch_size=2)
+    g.plan_train.finalize()
+    names = [n for n, off, c in sess.store.train_ranges() if g.off <= off < g.off + g.numel]
+    assert names and all(n.startswith(scope + "/") for n in names), names[:3]
+    assert list(g.mods) == (["ac"] if mode == "onlyaudiovideo" else ["ac", "audio", "video"])
+    assert (g.moddrop_mask is not None) == (mode == "all") and (g.feat_sum is not None) == (mode == "onlyaudiovideo")
+    with pytest.raises(AssertionError):
+        TrainerMulti(UNetAc2([36, 48, 12]), UNetSound22([193, 257, 1]), Unet2([224, 298, 3]), Jointmvae(), None,
+                     session=Session(torch.device("cpu")), mode="onlyaudiovideo")
+
+
 def test_stft_and_resize_restatements_known_answers():
     """oracle.frontend.stft_mag / resize_bilinear (TensorFlow definitions, unpinned): closed-form cases"""
     n = 12288
