@@ -94,6 +94,9 @@ def parse():
     ap.add_argument("--stage-cut", type=int, default=8, help="bottleneck units in trunk stage 1 (of 16)")
     ap.add_argument("--two-pass-cin", type=int, default=256,
                     help="conv3 of the stride-1 units in two passes up to this many input channels (0 = never; 256 = shipped)")
+    ap.add_argument("--unet-precision", default="split", choices=["split", "bf16", "f32"],
+                    help="--workload unet_rgb / unet_sound: arithmetic of the >= 32-channel layers (bf16 = BASELINE "
+                         "configs[1] as stated; split = fp32-class)")
     ap.add_argument("--no-gram", action="store_true",
                     help="statistics of the fused-tail conv3 layers from a second K loop (round 3) instead of the Gram matrix "
                          "of the conv's input (round 4): A/B switch")
@@ -169,14 +172,19 @@ def cpu_baseline(args):
                       "%d threads" % (args.num_skip, args.cpu_batch, done, dt, warm, n)}
 
 
-def load_traffic_profile(kernel_name):
+TRAFFIC_TAGS = ("unet_rgb", "b64")    # hbm_traffic_<tag>_*.txt: PMC summaries of the other bench workloads
+
+
+def load_traffic_profile(kernel_name, tag=None):
     """HBM bytes from the newest PMC summary committed under profiles/ (tools/pmc_traffic.sh + tools/pmc_summary.py:
     FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc passes of THIS bench at batch 32
-    f16x3).  Returns {file, commit, step_bytes, kernel_bytes_per_launch} or None: nothing is hard-coded here."""
+    f16x3; tag "unet_rgb": of `--workload unet_rgb --unet-precision bf16`, "b64": of `--num-skip 2 --batch 64`).
+    Returns {file, commit, step_bytes, kernel_bytes_per_launch} or None: nothing is hard-coded here."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic_*.txt")),
-                   key=lambda f: (int(re.search(r"profiles/r(\d+)/", f).group(1)), os.path.getmtime(f), f))
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic_*.txt"))
+             if (("hbm_traffic_%s_" % tag) in f if tag else not any(("hbm_traffic_%s_" % t) in f for t in TRAFFIC_TAGS))]
+    files = sorted(files, key=lambda f: (int(re.search(r"profiles/r(\d+)/", f).group(1)), os.path.getmtime(f), f))
     if not files:
         return None
     f = files[-1]
@@ -197,6 +205,27 @@ def load_traffic_profile(kernel_name):
         if m and m.group(1).replace(" ", "") == want:
             out["kernel_bytes_per_launch"] = (float(m.group(3)) + float(m.group(4))) * 1e6
     return out
+
+
+# activation elements per image of the single-modality U-Net VAEs; ~8 accesses of 4 bytes each per
+# train step (written once and read once forward, saved activations re-read in backward, gradients written and read)
+VAE_ACT_ELEMS = {"unet_rgb": 6.95e6, "unet_sound": 1.78e6}
+
+
+def vae_roofline(workload, B, ms_per_step, tag=None):
+    """the HBM roofline object of a U-Net VAE step: these nets are 8 - 32 channels at up to 224 x 298, so the step is bound
+    by bytes, not by a dominant kernel - algorithmic bytes of the whole step against the 8 TB/s peak, beside the counter
+    traffic of the committed PMC pass (profiles/r*/hbm_traffic_<tag>_*.txt) when one exists"""
+    alg = VAE_ACT_ELEMS[workload] * 8 * 4 * B
+    ach = alg / (ms_per_step * 1e-3) / 1e9
+    prof = load_traffic_profile("", tag) if tag else None
+    sb = prof["steady_bytes"] or prof["step_bytes"] if prof else None
+    return {"bound": "hbm", "kernel": "whole step (no dominant kernel: few-channel layers)", "achieved": ach, "peak": 8000.0,
+            "unit": "GB/s", "frac": ach / 8000.0, "alg_bytes": alg, "traffic": sb,
+            "traffic_ratio": (sb / alg) if sb else None, "traffic_GBps": (sb / (ms_per_step * 1e-3) / 1e9) if sb else None,
+            "traffic_source": prof["file"] if prof else None, "traffic_commit": prof["commit"] if prof else None,
+            "measured": "algorithmic bytes of one step (SURVEY 8(d): activation elements x 8 accesses x 4 B x batch) over the "
+                        "measured step time; traffic: PMC counter bytes of the committed pass, not of this run"}
 
 
 def secondary_unet_rgb(args):
@@ -227,6 +256,7 @@ def secondary_unet_rgb(args):
     return {"workload": "BASELINE configs[1]: UNet RGB VAE train step (models/unet_architecture.py + trainer/trainer.py), "
                         "224x298x3, batch 32, bf16", "value": 32 / dt, "unit": "images/s", "ms_per_step": dt * 1e3,
             "dtype": "bf16 operands of the MFMA convs, f32 accumulate / statistics / loss / Adam",
+            "roofline": vae_roofline("unet_rgb", 32, dt * 1e3, "unet_rgb"),
             "f32_class": {"value": 32 / res["split"], "unit": "images/s", "ms_per_step": res["split"] * 1e3,
                           "dtype": "f32 (f16x3 / bf16x3 split MFMA)"}}
 
@@ -240,7 +270,7 @@ def dominant_trunk_kernel(g, f16):
     from acimg import ops
     cand = {}
     for i, (name, fn, a) in enumerate(g.plan_train.calls):
-        if name == "conv2d_fwd_split3p" and f16:      # the trunk's pre-split LDS-DMA kernels
+        if name in ("conv2d_fwd_split3p", "conv2d_fwd_split1p") and f16:      # the trunk's pre-split LDS-DMA kernels
             d = a[0]._obj
             key = ops.conv2d_fwd_split3_tiling(d)
         elif name == "conv2d_fwd" and not f16:
@@ -315,6 +345,11 @@ def secondary_configs2(args):
             "alg_bytes": sum(alg_bytes.values()) / len(alg_bytes), "traffic": None,
             "launches_per_step": len(probe_idx), "avg_launch_ms": ms / len(ev),
             "measured": "HIP events around every launch of the kernel in 3 one-stream steps after the timed region"}
+    prof = load_traffic_profile(kernel_name, "b64") if f16 else None
+    if prof and prof["kernel_bytes_per_launch"]:
+        roof.update(traffic=prof["kernel_bytes_per_launch"], traffic_ratio=prof["kernel_bytes_per_launch"] / roof["alg_bytes"],
+                    traffic_source=prof["file"], traffic_commit=prof["commit"],
+                    step_hbm_bytes=prof["steady_bytes"] or prof["step_bytes"])
     return {"workload": "BASELINE configs[2]: TrainerMask train step, ResNet-50-mod + UNetAcRes 2-skip "
                         "(models/unet_acresnet2skip.py), batch 64", "value": B / dt, "unit": "images/s",
             "ms_per_step": dt * 1e3, "dtype": "f32", "final_loss": tr._scalars(g)["loss"], "roofline": roof}
@@ -340,8 +375,9 @@ def fill_inputs(g, B, seed):
 
 
 def other_workload(args):
-    """single-GPU timing of the other train steps (same JSON contract, no roofline probe: these steps have no
-    single dominant kernel; HBM-bound few-channel layers)"""
+    """single-GPU timing of the other train steps (same JSON contract; roofline: the U-Net VAEs against the HBM roof -
+    no dominant kernel, HBM-bound few-channel layers, DESIGN.md §8 - the classifier step of configs[4] through its
+    dominant kernel, the trunk's)"""
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     from acimg.session import Session
@@ -352,7 +388,7 @@ def other_workload(args):
         from acimg.trainer_vae import TrainerVAE
         from acimg.unet_vae import UNet, UNetSound
         cls = UNet if args.workload == "unet_rgb" else UNetSound
-        tr = TrainerVAE(cls(), learning_rate=1e-4, session=sess)
+        tr = TrainerVAE(cls(precision=args.unet_precision), learning_rate=1e-4, session=sess)
         g = tr._build_functions(batch_size=B)
         tr.model.initialize(seed=1240)
         g.images.copy_(torch.rand(*g.images.shape, generator=gen))
@@ -384,6 +420,7 @@ def other_workload(args):
                 "forward (inference mode) + DualCamNet forward/backward + Adam, %d clips of 12 frames" % (B // 12))
         last = lambda: dict(zip(("loss", "correct"), g.out[:2].tolist()))  # noqa: E731
         launches = len(g.plan_train) + 1
+        cls_probe = dominant_trunk_kernel(g, args.precision in ("f16x3", "f16"))
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -392,15 +429,40 @@ def other_workload(args):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    roof = None
+    if args.workload in VAE_ACT_ELEMS:
+        roof = vae_roofline(args.workload, B, dt / args.steps * 1e3,
+                            "unet_rgb" if (args.workload == "unet_rgb" and args.unet_precision == "bf16" and B == 32) else None)
+    else:
+        # configs[4]: the dominant kernel is the trunk's (inference-mode forward of the frozen encoder): HIP events around
+        # its launches in 3 more steps (one stream: the plan has no second lane here)
+        probe_idx, flops, alg_bytes, kernel_name = cls_probe
+        ev = []
+        for _ in range(3):
+            g.plan_train.run_probed(probe_idx, ev)
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in ev)
+        fl = sum(flops[i] for i, _, _ in ev)
+        terms = 1 if args.precision == "f16" else 3
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16_MFMA_TFLOPS
+        ach = fl / (ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": kernel_name if terms == 3 else kernel_name.replace("0, 3, 0>", "0, 1, 0>"),
+                "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "hw_flop_factor": 1 if args.precision == "f32" else terms, "hw_frac": ach * (1 if args.precision == "f32" else terms) / peak,
+                "alg_bytes": sum(alg_bytes.values()) / len(alg_bytes), "traffic": None,
+                "launches_per_step": len(probe_idx), "avg_launch_ms": ms / len(ev),
+                "measured": "HIP events around every launch of the kernel in 3 steps after the timed region (one stream)"}
     print(json.dumps({
         "metric": "train-step images/sec", "value": B * args.steps / dt, "unit": "images/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 trunk operands, f32 accumulate / statistics / loss" if args.precision == "f16" else "f32",
+        "dtype": ("f16 trunk operands, f32 accumulate / statistics / loss" if args.precision == "f16" else
+                  "bf16 operands of the MFMA convs, f32 accumulate / statistics / loss / Adam"
+                  if (args.workload in VAE_ACT_ELEMS and args.unet_precision == "bf16") else "f32"),
         "data": "synthetic",
         "config": {"workload": name, "per_gpu_batch": B, "global_batch": B, "parallelism": "dp1",
                    "launches_per_step": launches},
-        "final": last(), "roofline": None}))
+        "final": last(), "roofline": roof}))
 
 
 class _QuietStdout(object):

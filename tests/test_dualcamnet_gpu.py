@@ -207,7 +207,24 @@ def test_configs4_fp16_operand_storage():
         ep16, ep32 = {}, {}
         _, _, gen16, _ = orc16.forward(video, mfcc, eps, False, ep16)
         _, _, gen32, _ = orc32.forward(video, mfcc, eps, False, ep32)
+    # the same rounded arithmetic evaluated in fp64 (same fp32 weights): what the ORACLE ITSELF moves by when only its
+    # accumulation precision changes - values within fp32 rounding of an fp16 tie round apart and the 53-layer random-init
+    # trunk amplifies it.  The product is held to 3x that spread (the bound of tests/test_unet_vae_gpu.py's bf16 mode): the
+    # 1e-2 cap below is not the bar, the oracle's own discontinuity is ("10x the stated bar")
+    orc64 = otr.Oracle(num_skip=1, randomize=True, f16_operands=True, dtype=torch.float64)
+    for k in orc64.res:
+        orc64.res[k] = orc16.res[k].double()
+    for k in orc64.gen:
+        orc64.gen[k] = orc16.gen[k].double()
+    with torch.no_grad():
+        ep64 = {}
+        orc64.forward(video.double(), mfcc.double(), eps.double(), False, ep64)
     feat = tr.model_encoder_images.output
+    spread = rel(ep16["resnet_v1_50/conv_map"], ep64["resnet_v1_50/conv_map"])
+    e_feat64 = rel(feat, ep64["resnet_v1_50/conv_map"])
+    print("fp16 operand storage: oracle fp32 vs fp64 under the same rounding %.2e; product vs the fp64 evaluation %.2e"
+          % (spread, e_feat64))
+    assert e_feat64 <= 3.0 * spread + 1e-4, (e_feat64, spread)
     e_feat = rel(feat, ep16["resnet_v1_50/conv_map"])
     e_gen = rel(tr.model_encoder_acoustic.output, gen16)
     cost = rel(ep16["resnet_v1_50/conv_map"], ep32["resnet_v1_50/conv_map"])

@@ -1,6 +1,8 @@
 """HBM traffic per kernel from the two rocprofv3 --pmc passes of tools/pmc_traffic.sh (FETCH_SIZE, WRITE_SIZE; KB per
 dispatch).  FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (128-B requests of
-16-B/lane streams are tallied at 64 B).  usage: python tools/pmc_summary.py <dir with fetch/ and write/> [steps] [commit]"""
+16-B/lane streams are tallied at 64 B).
+usage: python tools/pmc_summary.py <dir with fetch/ and write/> [steps the profiled command ran, warm-up included] [commit]
+       [description of the profiled command]"""
 import csv, os, sys, collections
 root = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -37,8 +39,8 @@ for k, (n, kb) in rd.items():
     rows.append((k, n / steps, rmb, wmb, (rmb + wmb) * n / steps / 1e3))
 rows.sort(key=lambda r: -r[4])
 print("commit %s   (tree the PMC passes ran on; bench.py reads this file: load_traffic_profile)" % (sys.argv[3] if len(sys.argv) > 3 else head_commit()))
-print("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
-      "(%d steps, batch 32)" % steps)
+desc = sys.argv[4] if len(sys.argv) > 4 else "python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary"
+print("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- %s (%d steps)" % (desc, steps))
 print("FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests of 16-B/lane streams at 64 B); "
       "MB per launch, averaged")
 print("%-62s %10s %14s %15s %12s" % ("kernel", "calls/step", "read MB/launch", "write MB/launch", "GB/step"))
