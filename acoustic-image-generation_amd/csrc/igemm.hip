@@ -814,7 +814,9 @@ static size_t wgrad_ws_bytes(int M, int KK, int Ngemm, int ldo) {
     // one sizing query serves acimg_conv2d_wgrad and acimg_conv2d_wgrad_split3 / _bf16: the larger of their slab counts
     int bmo, bn;
     wgrad_tile(Ngemm, bmo, bn);
-    const int s = std::max(pick_wgrad_splits(M, KK, Ngemm, bmo, bn), pick_wgrad_splits(M, KK, Ngemm, bmo, wgrad_split3_bn(Ngemm)));
+    int s = std::max(pick_wgrad_splits(M, KK, Ngemm, bmo, bn), pick_wgrad_splits(M, KK, Ngemm, bmo, wgrad_split3_bn(Ngemm)));
+    // the halo form of the 3x3 32- / 64-channel -> 32-column layers (wgrad_halo16_kernel) leaves one slab per CU
+    if (Ngemm == 32 && (KK == 9 * 32 || KK == 9 * 64) && M >= 65536 && s < 256) s = 256;
     return s > 1 ? (size_t)(s + 1) * ((size_t)KK + 1) * ldo * sizeof(float) : 0;
 }
 
@@ -1028,6 +1030,194 @@ static bool wgrad_halo_ok(const WgradParams& p) {
 }
 
 // db (optional): fused bias gradient, db[n] = sum_m G[m][n] for n < Ngemm
+// ------------------------------------------------------------------------------------------
+// HALO form of the bf16 / bf16x3 weight gradient of the 3x3 / stride-1 layers with 32 or 64 input channels and 32 output
+// channels (round 4; the 112x149 and 56x74 stages of the RGB / spectrogram U-Nets, models/unet_architecture.py:161-166,
+// configs[1]).  As an implicit GEMM (wgrad_split3_kernel) these layers re-gather x once per tap through L2 - nine times the
+// tensor for 2 x 576 x 32 MACs per pixel: 112x149 64->32 took 225 us against 41 us of HBM time for x and gy.  Here a
+// workgroup stages a TH x 32 output-pixel tile of gy and the x tile WITH ITS HALO once, as bf16 (hi [, lo]) planes in LDS
+// ([pixel][channel], 16-byte chunks swizzled by the pixel's COLUMN so that the transposing fragment reads - 4 pixels x 16
+// channels per 16-lane group - are conflict free at every tap shift, and row offsets stay compile-time immediates), and
+// forms all nine taps from there: K = the tile's pixels, one 32-pixel row per step, no barrier inside a tile.  gy^T sits in
+// the A slot (a lane's 4 accumulators are 4 consecutive output channels of one dW row: 16-byte slab stores); the bias
+// gradient rides as an MFMA against a constant ones fragment.  One workgroup per CU with the NEXT tile's global loads held in
+// registers while the current one is multiplied (2 waves per SIMD: the 256-register budget pays for that); workgroups walk
+// tiles grid-stride and keep their sums in registers: one partial slab each, then the deterministic slab reduce.
+// Waves: C = 64: 4 channel tiles x 2 column tiles; C = 32: 2 x 2 x the tile's even / odd rows (summed through LDS at the end).
+// ------------------------------------------------------------------------------------------
+struct WgradHalo16Params {
+    const float* X; int H, W, ldx;
+    const float* G; int ldg;
+    int tiles_x, tiles_y; long tiles;
+    float* out; float* db_out; int ldo;      // slabs [gridDim.x][9 C][ldo], [gridDim.x][ldo]
+};
+
+template <int C, int TERMS>
+__global__ __launch_bounds__(512, 1) void wgrad_halo16_kernel(const WgradHalo16Params p) {
+    constexpr int TH = TERMS == 1 ? 8 : 4, TW = 32, XH = TH + 2, XWV = TW + 2, XW = 36;
+    constexpr int PITCH = C * 2;                      // bytes per pixel and plane
+    constexpr int XPL = XH * XW * PITCH;              // one x plane
+    constexpr int GPL = TH * TW * 64;                 // one gy plane (32 columns of bf16)
+    constexpr int NCT = C / 16;                       // 16-channel tiles
+    constexpr int NJ = 8 / (NCT * 2);                 // row groups: waves with the same (channel tile, column tile)
+    constexpr int NXL = (XH * XWV * (C / 4) + 511) / 512, NGL = TH * TW * 8 / 512;     // float4 loads per thread and tile
+    static_assert((C == 64 || C == 32) && TH % NJ == 0 && TH * TW * 8 % 512 == 0, "shape");
+    extern __shared__ __attribute__((aligned(16))) float wh16_smem[];
+    char* const lds = reinterpret_cast<char*>(wh16_smem);
+    char* const gl = lds + (TERMS == 3 ? 2 : 1) * XPL;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
+    const int ct = wid % NCT, nt = (wid / NCT) & 1, jh = wid / (NCT * 2);
+    auto swx = [](int col) { return C == 64 ? 2 * (((col >> 1) & 1) | (((col >> 3) & 1) << 1)) : 2 * ((col >> 3) & 1); };
+    auto swg = [](int col) { return 2 * ((col >> 3) & 1); };
+
+    // fragment read addresses: lane (q, pp) of group g supplies pixel column s + 8 g + 4 h + q, channels 4 pp .. + 3 of its
+    // 16-channel tile; the tile row is a compile-time distance
+    int xb[3][2], gb[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = 8 * g + 4 * h + q;
+        gb[h] = (jh * TW + col) * 64 + (((2 * nt + (pp >> 1)) ^ swg(col)) << 4) + 8 * (pp & 1);
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) {
+            const int cx = col + s_;
+            xb[s_][h] = (jh * XW + cx) * PITCH + (((2 * ct + (pp >> 1)) ^ swx(cx)) << 4) + 8 * (pp & 1);
+        }
+    }
+
+    // this thread's items of a tile: x float4 (pixel of the XH x 34 window, 4 channels), gy float4 (pixel, 4 columns)
+    float4 rx[NXL], rg[NGL];
+    auto load_tile = [&](long tile) {
+        const int tx = (int)(tile % p.tiles_x);
+        const long t2 = tile / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y);
+        const long img = t2 / p.tiles_y;
+        const float* xi = p.X + img * p.H * p.W * p.ldx;
+        const float* gi = p.G + img * p.H * p.W * p.ldg;
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) {
+            const int i = tid + 512 * k;
+            const int c4 = i % (C / 4), pix = i / (C / 4);
+            const int row = pix / XWV, col = pix - row * XWV;
+            const int iy = ty * TH + row - 1, ix = tx * TW + col - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < XH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *reinterpret_cast<const float4*>(xi + ((long)iy * p.W + ix) * p.ldx + c4 * 4);
+            rx[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NGL; ++k) {
+            const int i = tid + 512 * k;
+            const int c4 = i & 7, pix = i >> 3;
+            const int row = pix / TW, col = pix - row * TW;
+            const int oy = ty * TH + row, ox = tx * TW + col;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (oy < p.H && ox < p.W) v = *reinterpret_cast<const float4*>(gi + ((long)oy * p.W + ox) * p.ldg + c4 * 4);
+            rg[k] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) {
+            const int i = tid + 512 * k;
+            const int c4 = i % (C / 4), pix = i / (C / 4);
+            const int row = pix / XWV, col = pix - row * XWV;
+            if (row < XH) {
+                const int off = (row * XW + col) * PITCH + (((c4 >> 1) ^ swx(col)) << 4) + 8 * (c4 & 1);
+                uint2 hi, lo;
+                split4<SplitBF16>(rx[k], hi, lo);
+                *reinterpret_cast<uint2*>(lds + off) = hi;
+                if (TERMS == 3) *reinterpret_cast<uint2*>(lds + XPL + off) = lo;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NGL; ++k) {
+            const int i = tid + 512 * k;
+            const int c4 = i & 7, pix = i >> 3;
+            const int col = pix & (TW - 1);
+            const int off = pix * 64 + (((c4 >> 1) ^ swg(col)) << 4) + 8 * (c4 & 1);
+            uint2 hi, lo;
+            split4<SplitBF16>(rg[k], hi, lo);
+            *reinterpret_cast<uint2*>(gl + off) = hi;
+            if (TERMS == 3) *reinterpret_cast<uint2*>(gl + GPL + off) = lo;
+        }
+    };
+    typedef short s16x4_ __attribute__((ext_vector_type(4)));
+    typedef short s16x8_ __attribute__((ext_vector_type(8)));
+    auto frag = [&](const char* base, int a0, int a1) -> b16x8 {
+        const s16x4_ v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(base + a0));
+        const s16x4_ v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)(base + a1));
+        const s16x8_ v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        return __builtin_bit_cast(b16x8, v);
+    };
+
+    f32x4 acc[9], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const __bf16 one = (__bf16)1.f;
+    const b16x8 ones = {one, one, one, one, one, one, one, one};
+
+    long tile = blockIdx.x;
+    if (tile < p.tiles) load_tile(tile);
+    for (; tile < p.tiles; tile += gridDim.x) {
+        __syncthreads();                               // everyone has finished reading the previous tile
+        store_tile();
+        __syncthreads();
+        if (tile + gridDim.x < p.tiles) load_tile(tile + gridDim.x);     // in flight while this tile is multiplied
+#pragma unroll
+        for (int jj = 0; jj < TH / NJ; ++jj) {
+            const int j = jj * NJ;                     // (+ jh: in the lane bases)
+            const b16x8 gh = frag(gl + j * TW * 64, gb[0], gb[1]);
+            b16x8 glo;
+            if (TERMS == 3) glo = frag(gl + GPL + j * TW * 64, gb[0], gb[1]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s_ = 0; s_ < 3; ++s_) {
+                    const char* xrow = lds + (j + r) * XW * PITCH;
+                    const b16x8 xh = frag(xrow, xb[s_][0], xb[s_][1]);
+                    if (TERMS == 3) {
+                        const b16x8 xl = frag(xrow + XPL, xb[s_][0], xb[s_][1]);
+                        acc[r * 3 + s_] = SplitBF16::mfma(glo, xh, acc[r * 3 + s_]);
+                        acc[r * 3 + s_] = SplitBF16::mfma(gh, xl, acc[r * 3 + s_]);
+                    }
+                    acc[r * 3 + s_] = SplitBF16::mfma(gh, xh, acc[r * 3 + s_]);
+                }
+            if (ct == 0) {
+                if (TERMS == 3) accb = SplitBF16::mfma(glo, ones, accb);
+                accb = SplitBF16::mfma(gh, ones, accb);
+            }
+        }
+    }
+    // the row groups of one (channel tile, column tile) meet through LDS (C = 32), then lane (li, g) of acc[tap] holds
+    // dW[tap * C + 16 ct + li][16 nt + 4 g .. + 3]
+    if (NJ > 1) {
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(lds);
+        if (jh == 1) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) red[((wid - NCT * 2) * 10 + t) * 64 + lane] = acc[t];
+            red[((wid - NCT * 2) * 10 + 9) * 64 + lane] = accb;
+        }
+        __syncthreads();
+        if (jh == 1) return;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] += red[(wid * 10 + t) * 64 + lane];
+        accb += red[(wid * 10 + 9) * 64 + lane];
+    }
+    float* out = p.out + (long)blockIdx.x * (9 * C) * p.ldo;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        *reinterpret_cast<f32x4*>(out + (long)(t * C + ct * 16 + li) * p.ldo + nt * 16 + 4 * g) = acc[t];
+    if (p.db_out && ct == 0 && li == 0)
+        *reinterpret_cast<f32x4*>(p.db_out + (long)blockIdx.x * p.ldo + nt * 16 + 4 * g) = accb;
+}
+
+static bool wgrad_halo16_ok(const WgradParams& p, bool split3) {
+    return split3 && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && (p.C == 32 || p.C == 64) &&
+           p.Ngemm == 32 && p.Nld == 32 && p.OH == p.H && p.OW == p.W && p.ldo >= 32 && (long)p.M >= 65536 && g_cfg.wgrad_halo;
+}
+
 static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t st,
                         bool split3 = false, int terms = 3) {
     if ((p.C & 3) || (p.ldx & 3) || (p.ldg & 3) || (p.ldo & 3))
@@ -1036,6 +1226,46 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
         return fail(ACIMG_EINVAL, "wgrad: operands must be 16-byte aligned");
     int bmo, bn;
     wgrad_tile(p.Ngemm, bmo, bn);
+    if (wgrad_halo16_ok(p, split3)) {
+        WgradHalo16Params q{};
+        q.X = p.X; q.H = p.H; q.W = p.W; q.ldx = p.ldx; q.G = p.G; q.ldg = p.ldg; q.ldo = p.ldo;
+        const int th = terms == 1 ? 8 : 4;
+        q.tiles_x = cdiv(p.W, 32); q.tiles_y = cdiv(p.H, th);
+        q.tiles = (long)(p.M / (p.H * p.W)) * q.tiles_x * q.tiles_y;
+        int nb = 256;                                                 // one workgroup per CU
+        if (nb > q.tiles) nb = (int)q.tiles;
+        const size_t need = (size_t)nb * ((size_t)p.KK + 1) * p.ldo * sizeof(float);
+        if (ws != nullptr && ws_bytes >= need) {      // (the sizing query covers it: pick_wgrad_splits gives these shapes >= 256 slabs)
+            q.out = static_cast<float*>(ws);
+            float* db_slab = q.out + (size_t)nb * p.KK * p.ldo;
+            q.db_out = db ? db_slab : nullptr;
+            const int xh = th + 2, planes = terms == 3 ? 2 : 1;
+            int lds = planes * (xh * 36 * p.C * 2 + th * 32 * 64);
+            if (p.C == 32 && lds < 4 * 10 * 64 * 16) lds = 4 * 10 * 64 * 16;      // the row groups' final sum through LDS
+#define ACIMG_WH16(Cv, Tv)                                                                                              \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo16_kernel<Cv, Tv>),                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (10 * 36 * 64 * 2 + 8 * 32 * 64)); \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL((wgrad_halo16_kernel<Cv, Tv>), dim3(nb), dim3(512), lds, st, q);                             \
+    } while (0)
+            if (p.C == 64 && terms == 1) ACIMG_WH16(64, 1);
+            else if (p.C == 64) ACIMG_WH16(64, 3);
+            else if (terms == 1) ACIMG_WH16(32, 1);
+            else ACIMG_WH16(32, 3);
+#undef ACIMG_WH16
+            int rc = check_launch("wgrad_halo16");
+            if (rc) return rc;
+            const long total = (long)p.KK * p.Ngemm;
+            const int nb1 = (int)cdiv(total, 32), nb2 = db ? cdiv(p.Ngemm, 32) : 0;
+            hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(nb1 + nb2), dim3(256), 0, st, q.out, nb, (long)p.KK, p.Ngemm,
+                               p.ldo, dw, nb1, db_slab, db);
+            return check_launch("wgrad_reduce");
+        }
+    }
     if (wgrad_halo_ok(p)) {
         WgradHaloParams q{};
         q.X = p.X; q.H = p.H; q.W = p.W; q.C = p.C; q.ldx = p.ldx;

@@ -79,6 +79,30 @@ def test_error_codes_and_text(lib):
     assert rc == -1 and "nframes" in _lib.last_error()
 
 
+def test_gram_stats_host_side(lib):
+    """acimg_gram_stats (include/acimg.h, round 4): workspace sizes are pure host arithmetic and the argument checks fire
+    before any launch (no GPU here): unsupported channel counts, a lo plane that overlaps the hi plane, a short workspace"""
+    import ctypes as C
+
+    from acimg import _lib
+
+    assert lib.acimg_gram_stats_workspace(134400, 128) > 16 * 2 ** 20          # ~256 pixel ranges x 64 KiB + V + sums
+    assert lib.acimg_gram_stats_workspace(134400, 64) > 0 and lib.acimg_gram_stats_workspace(8512, 512) > 0
+    assert lib.acimg_gram_stats_workspace(1000, 96) == 0 and lib.acimg_gram_stats_workspace(0, 128) == 0
+    buf = (C.c_float * 64)()
+    big = (C.c_char * 4096)()
+    a = C.addressof(big) + (-C.addressof(big)) % 16
+    rc = lib.acimg_gram_stats(a, 2048, 16, 96, C.addressof(buf), 4, 4, None, None, None, None, 0.9, 1e-5, C.addressof(buf),
+                              C.addressof(buf), a, 4096, None)
+    assert rc == -1 and "multiple of 128" in _lib.last_error()
+    rc = lib.acimg_gram_stats(a, 16, 16, 64, C.addressof(buf), 4, 4, None, None, None, None, 0.9, 1e-5, C.addressof(buf),
+                              C.addressof(buf), a, 4096, None)
+    assert rc == -1 and "overlapping" in _lib.last_error()
+    rc = lib.acimg_gram_stats(a, 2048, 16, 64, C.addressof(buf), 4, 4, None, None, None, None, 0.9, 1e-5, C.addressof(buf),
+                              C.addressof(buf), a, 64, None)
+    assert rc == -1 and "workspace too small" in _lib.last_error()
+
+
 def _build(num_skip, ae, batch=2):
     from acimg.flags import FLAGS
     from acimg.session import Session

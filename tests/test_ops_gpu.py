@@ -1132,6 +1132,46 @@ def test_two_pass_conv3_equals_conv_then_bn_pass(device, case):
     close(got, r64.reshape(rows, K), tol=2e-6, what="two-pass conv3 vs fp64 %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(4, 112, 149, 32, 0), (5, 112, 149, 64, 0), (9, 85, 90, 64, 32), (17, 61, 67, 32, 8),
+                                  (40, 56, 74, 64, 0)])
+@pytest.mark.parametrize("bf16", [True, False])
+def test_wgrad_halo16_matches_fp64(device, case, bf16):
+    """The halo form of the weight gradient of the 3x3 / stride-1 layers with 32 or 64 input and 32 output channels (round 4,
+    wgrad_halo16_kernel behind acimg_conv2d_wgrad_bf16 / _split3 from 65536 pixels on): x and gy tiles staged once as bf16
+    planes, nine taps formed from LDS.  bf16 = one MFMA per product on ROUNDED operands (compared with the fp64 gradient of
+    the rounded operands), else the three-term bf16 split (fp32-class, against fp64 of the unrounded operands); image
+    heights / widths that are not multiples of the 8 x 32 (4 x 32) tile, x as a channel slice of a wider concat buffer,
+    gy with a wider pixel stride; weight AND bias gradient; deterministic (two runs, the same bits)"""
+    from acimg import ops
+
+    N, H, W, Cc, xoff = case
+    K = 32
+    g = torch.Generator().manual_seed(5 + N + Cc + int(bf16))
+    ldx = Cc + xoff + (8 if xoff else 0)
+    xw = torch.randn(N, H, W, ldx, generator=g)
+    gyw = torch.randn(N, H, W, K + 16, generator=g) * 1e-2
+    x, gy = xw[..., xoff:xoff + Cc], gyw[..., :K]
+    d = ops.conv_desc(N, H, W, Cc, K, 3, 3, 1, "SAME", ldx=ldx)
+    plan = ops.Plan(device, eager=True)
+    xd, gyd = xw.to(device), gyw.to(device)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((3, 3, Cc, K), float("nan"), device=device)
+        db = torch.full((K,), float("nan"), device=device)
+        ops.conv2d_wgrad_split3(plan, d, ops.Ptr(xd, xoff), gyd, K + 16, dw, db, bf16=bf16)
+        torch.cuda.synchronize()
+        outs.append((dw.cpu(), db.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    rnd_ = (lambda t: t.float().to(torch.bfloat16).double()) if bf16 else (lambda t: t.double())
+    xr = rnd_(x).permute(0, 3, 1, 2)
+    gr = rnd_(gy).permute(0, 3, 1, 2)
+    wz = torch.zeros(K, Cc, 3, 3, dtype=torch.float64, requires_grad=True)
+    yr = torch.nn.functional.conv2d(xr, wz, padding=1)
+    (gw,) = torch.autograd.grad(yr, (wz,), gr)
+    close(outs[0][0], gw.permute(2, 3, 1, 0), tol=2e-5 if bf16 else 4e-5, what="halo16 wgrad %s bf16=%s" % (case, bf16))
+    close(outs[0][1], gr.sum((0, 2, 3)), tol=2e-5 if bf16 else 4e-5, what="halo16 bias gradient %s" % (case,))
+
+
 @pytest.mark.parametrize("case", [(134400, 64, 256), (34048, 256, 1024), (20011, 128, 512), (8512, 512, 2048), (37, 64, 100),
                                   (4099, 128, 136), (50, 256, 256)])
 def test_gram_statistics_match_fp64(device, case):
