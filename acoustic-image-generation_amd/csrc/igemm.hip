@@ -1872,8 +1872,234 @@ static Split3Cfg pick_split3(int M, int K, bool allow32 = false) {
     return {128, 128};
 }
 
+extern "C++" {
+// ------------------------------------------------------------------------------------------
+// HALO form of the FORWARD conv / DATA GRADIENT of the same 3x3 / stride-1 / SAME layers with 32 or 64 channels on either
+// side (round 4; configs[1]'s 112x149 and 56x74 stages).  As an implicit GEMM with a 32- or 64-column tile these layers
+// gather x once per tap through L2 (112x149 64->32 forward: 121 us against ~50 us of bytes).  Here a workgroup stages a
+// TH x 32 pixel tile of the input WITH ITS HALO once (fp32 -> 16-bit hi [, lo] planes, [pixel][channel] rows padded by 16
+// bytes: conflict-light ds_read_b128 fragments at every tap shift with no swizzle) and keeps the layer's whole weight image
+// in LDS (rows padded the same way); K walks (tap, 32-channel chunk); weights in the A slot, so a lane's 4 accumulators are
+// 4 consecutive output channels of one pixel (16-byte stores).  MODE 0: forward - bias, raw fp32 output, batch-norm partials
+// of conv + bias accumulated over the workgroup's tiles: ONE statistics row per workgroup.  MODE 1: data gradient - a
+// forward conv of gy with the flipped / transposed image of acimg_conv2d_split3_prepare_dgrad; residual and ReLU mask in the
+// epilogue.  One workgroup per CU, the next tile's loads held in registers while the current one is multiplied.
+// ------------------------------------------------------------------------------------------
+struct ConvHaloParams {
+    const float* X; int H, W, ldx;
+    const char* Wimg; unsigned w_lo_off;         // 16-bit image [rows][9 CIN], hi plane; lo plane w_lo_off bytes further
+    float* Y; int ldy;
+    const float* bias; const float* res; int ldres; const float* mask; int ldmask;
+    float* stats; int stats_ld;                  // [gridDim.x][2][stats_ld] or null
+    int tiles_x, tiles_y; long tiles;
+};
+
+template <typename TR, int TERMS, int CIN, int NOUT, int MODE>
+__global__ __launch_bounds__(512, 1) void conv_halo16_kernel(const ConvHaloParams p) {
+    typedef typename TR::V8 V8;
+    constexpr int TH = TERMS == 1 ? 8 : 4, TW = 32, XH = TH + 2, XWV = TW + 2, XW = 36;
+    constexpr int PITCH = CIN * 2 + 16;               // bytes per pixel and plane (padded)
+    constexpr int XPL = XH * XW * PITCH;
+    constexpr int KTOT = 9 * CIN;
+    constexpr int WROW = KTOT * 2 + 16;               // bytes per weight row and plane (padded)
+    constexpr int WPL = NOUT * WROW;
+    constexpr int NPL = TERMS == 3 ? 2 : 1;
+    constexpr int MT = TERMS == 1 ? 2 : 1;            // 16-pixel tiles per wave: a whole tile row, or half of one
+    constexpr int NT = NOUT / 16;
+    constexpr int NXL = (XH * XWV * (CIN / 4) + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) float ch16_smem[];
+    char* const xl = reinterpret_cast<char*>(ch16_smem);
+    char* const wl = xl + NPL * XPL;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int jrow = TERMS == 1 ? wid : wid >> 1;     // tile row of this wave
+    const int mcol0 = TERMS == 1 ? 0 : (wid & 1) * 16;
+
+    // the weight image -> LDS (once per workgroup): NOUT rows of KTOT 16-bit values, 16-byte chunks
+    for (int i = tid; i < NPL * NOUT * (KTOT / 8); i += 512) {
+        const int ch = i % (KTOT / 8), r2 = i / (KTOT / 8);
+        const int n = r2 % NOUT, pl = r2 / NOUT;
+        const uint4 v = *reinterpret_cast<const uint4*>(p.Wimg + (size_t)pl * p.w_lo_off + ((size_t)n * KTOT + ch * 8) * 2);
+        *reinterpret_cast<uint4*>(wl + pl * WPL + n * WROW + ch * 16) = v;
+    }
+
+    float4 rx[NXL];
+    auto load_tile = [&](long tile) {
+        const int tx = (int)(tile % p.tiles_x);
+        const long t2 = tile / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y);
+        const long img = t2 / p.tiles_y;
+        const float* xi = p.X + img * p.H * p.W * p.ldx;
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) {
+            const int i = tid + 512 * k;
+            const int c4 = i % (CIN / 4), pix = i / (CIN / 4);
+            const int row = pix / XWV, col = pix - row * XWV;
+            const int iy = ty * TH + row - 1, ix = tx * TW + col - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < XH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *reinterpret_cast<const float4*>(xi + ((long)iy * p.W + ix) * p.ldx + c4 * 4);
+            rx[k] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) {
+            const int i = tid + 512 * k;
+            const int c4 = i % (CIN / 4), pix = i / (CIN / 4);
+            const int row = pix / XWV, col = pix - row * XWV;
+            if (row < XH) {
+                const int off = (row * XW + col) * PITCH + c4 * 8;
+                uint2 hi, lo;
+                split4<TR>(rx[k], hi, lo);
+                *reinterpret_cast<uint2*>(xl + off) = hi;
+                if (TERMS == 3) *reinterpret_cast<uint2*>(xl + XPL + off) = lo;
+            }
+        }
+    };
+
+    f32x4 s1[NT], s2[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) s1[n] = s2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+        bv[n] = (MODE == 0 && p.bias) ? *reinterpret_cast<const f32x4*>(p.bias + n * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int a_base = (jrow * XW + mcol0 + li) * PITCH + g * 16;       // + ((r * XW + s + 16 m) * PITCH + chunk * 64)
+    const int b_base = li * WROW + g * 16;                              // + (nt * 16 * WROW + (tap * CIN + chunk * 32) * 2)
+
+    long tile = blockIdx.x;
+    if (tile < p.tiles) load_tile(tile);
+    for (; tile < p.tiles; tile += gridDim.x) {
+        __syncthreads();                               // everyone has finished reading the previous tile (and the weights landed)
+        store_tile();
+        __syncthreads();
+        const int tx = (int)(tile % p.tiles_x);
+        const long t2 = tile / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y);
+        const long img = t2 / p.tiles_y;
+        if (tile + gridDim.x < p.tiles) load_tile(tile + gridDim.x);     // in flight while this tile is multiplied
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+                for (int ck = 0; ck < CIN / 32; ++ck) {
+                    V8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const int off = a_base + (r * XW + s_ + 16 * m) * PITCH + ck * 64;
+                        ah[m] = *reinterpret_cast<const V8*>(xl + off);
+                        if (TERMS == 3) al[m] = *reinterpret_cast<const V8*>(xl + XPL + off);
+                    }
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        const int off = b_base + n * 16 * WROW + ((r * 3 + s_) * CIN + ck * 32) * 2;
+                        bh[n] = *reinterpret_cast<const V8*>(wl + off);
+                        if (TERMS == 3) bl[n] = *reinterpret_cast<const V8*>(wl + WPL + off);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            if (TERMS == 3) {
+                                acc[m][n] = TR::mfma(bl[n], ah[m], acc[m][n]);
+                                acc[m][n] = TR::mfma(bh[n], al[m], acc[m][n]);
+                            }
+                            acc[m][n] = TR::mfma(bh[n], ah[m], acc[m][n]);
+                        }
+                }
+        // lane (li, g) of acc[m][n] holds output pixel (row jrow, column mcol0 + 16 m + li), channels 16 n + 4 g .. + 3
+        const int oy = ty * TH + jrow;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int ox = tx * TW + mcol0 + 16 * m + li;
+            if (oy < p.H && ox < p.W) {
+                const long pix = (img * p.H + oy) * p.W + ox;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    f32x4 v = acc[m][n] * TR::OUTSCALE + bv[n];
+                    if (MODE == 1) {
+                        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n * 16 + 4 * g);
+                        if (p.mask) {
+                            const f32x4 k = *reinterpret_cast<const f32x4*>(p.mask + pix * p.ldmask + n * 16 + 4 * g);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) v[c] = k[c] > 0.f ? v[c] : 0.f;
+                        }
+                    } else {
+                        s1[n] += v;
+                        s2[n] += v * v;
+                    }
+                    *reinterpret_cast<f32x4*>(p.Y + pix * p.ldy + n * 16 + 4 * g) = v;
+                }
+            }
+        }
+    }
+    if (MODE == 0 && p.stats) {
+        // the workgroup's statistics row: 16 pixel lanes by DPP, 8 waves through LDS, in wave order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(xl);     // [8][2][NOUT]
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float a = row16_sum(s1[n][c]), b = row16_sum(s2[n][c]);
+                if (li == 0) {
+                    red[(wid * 2 + 0) * NOUT + n * 16 + 4 * g + c] = a;
+                    red[(wid * 2 + 1) * NOUT + n * 16 + 4 * g + c] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < 2 * NOUT) {
+            const int which = tid / NOUT, n = tid % NOUT;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += red[(w * 2 + which) * NOUT + n];
+            p.stats[((long)blockIdx.x * 2 + which) * p.stats_ld + n] = t;
+        }
+    }
+}
+
+// shapes the halo forward / data-gradient kernel takes: 3x3, stride 1, one pixel of padding, (reduction, output) channels
+// (32 | 64, 32) forward and (32, 32 | 64) backward, from 65536 pixels on
+static bool conv_halo16_fwd_shape(const AcimgConvDesc* d) {
+    return d->R == 3 && d->S == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->OH == d->H && d->OW == d->W &&
+           (d->C == 32 || d->C == 64) && d->K == 32 && (long)d->N * d->H * d->W >= 65536 && d->act == ACIMG_ACT_NONE &&
+           g_cfg.wgrad_halo;
+}
+static bool conv_halo16_dgrad_shape(const AcimgConvDesc* d) {
+    return d->R == 3 && d->S == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->OH == d->H && d->OW == d->W &&
+           (d->C == 32 || d->C == 64) && d->K == 32 && (long)d->N * d->H * d->W >= 65536 && g_cfg.wgrad_halo;
+}
+static constexpr int CONV_HALO16_WGS = 256;          // one workgroup per CU = statistics rows of the forward form
+
+template <typename TR, int TERMS, int CIN, int NOUT, int MODE>
+static int launch_conv_halo16(ConvHaloParams q, int N, hipStream_t st) {
+    constexpr int TH = TERMS == 1 ? 8 : 4, NPL = TERMS == 3 ? 2 : 1;
+    constexpr int lds = NPL * ((TH + 2) * 36 * (CIN * 2 + 16) + NOUT * (9 * CIN * 2 + 16));
+    static_assert(lds <= 160 * 1024 && 8 * 2 * NOUT * 4 <= lds, "LDS budget");
+    q.tiles_x = cdiv(q.W, 32); q.tiles_y = cdiv(q.H, TH);
+    q.tiles = (long)N * q.tiles_x * q.tiles_y;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo16_kernel<TR, TERMS, CIN, NOUT, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_halo16_kernel<TR, TERMS, CIN, NOUT, MODE>), dim3(CONV_HALO16_WGS), dim3(512), lds, st, q);
+    return check_launch("conv_halo16");
+}
+}  // extern "C++"
+
 int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d) {
     const int M = d->N * d->OH * d->OW;
+    if (conv_halo16_fwd_shape(d)) return CONV_HALO16_WGS;      // the halo form leaves one row per workgroup
     return cdiv(M, pick_split3(M, d->K).bm);
 }
 
@@ -2102,6 +2328,21 @@ static int fwd_split_onthefly(const AcimgConvDesc* d, const float* x, const void
     if (d->C % 32) return fail(ACIMG_EINVAL, "conv2d_fwd_split3: C=%d must be a multiple of 32", d->C);
     if (d->ldw < d->K || !aligned16(x) || !aligned16(wsplit))
         return fail(ACIMG_EINVAL, "conv2d_fwd_split3: ldw<K or unaligned operands");
+    if (conv_halo16_fwd_shape(d)) {
+        // (acimg_conv2d_fwd_split3_stats_rows already told the caller this shape leaves CONV_HALO16_WGS rows: no fallback)
+        if (in_scale || in_shift || !aligned16(y) || (d->ldy & 3) || (d->ldx & 3) || (bias && !aligned16(bias)))
+            return fail(ACIMG_EINVAL, "conv2d_fwd_split3: the halo form of this shape takes no input affine and needs 16-byte "
+                                      "aligned y / bias and ldx, ldy multiples of 4");
+        ConvHaloParams q{};
+        q.X = x; q.H = d->H; q.W = d->W; q.ldx = d->ldx; q.Wimg = static_cast<const char*>(wsplit);
+        q.w_lo_off = (unsigned)((size_t)d->ldw * d->R * d->S * d->C * 2);
+        q.Y = y; q.ldy = d->ldy; q.bias = bias; q.stats = stats; q.stats_ld = d->ldw;
+        hipStream_t st = (hipStream_t)stream;
+        if (bf16) return d->C == 64 ? launch_conv_halo16<SplitBF16, 1, 64, 32, 0>(q, d->N, st)
+                                    : launch_conv_halo16<SplitBF16, 1, 32, 32, 0>(q, d->N, st);
+        return d->C == 64 ? launch_conv_halo16<SplitF16, 3, 64, 32, 0>(q, d->N, st)
+                          : launch_conv_halo16<SplitF16, 3, 32, 32, 0>(q, d->N, st);
+    }
     IgemmParams p{};
     p.A = x; p.H = d->H; p.W = d->W; p.C = d->C; p.lda = d->ldx;
     p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride;
@@ -2150,6 +2391,19 @@ static int dgrad_split_onthefly(const AcimgConvDesc* d, const float* gy, int ldg
     if (d->stride != 1 || d->K % 32 || d->K > ldgy || (ldgy & 3))
         return fail(ACIMG_EINVAL, "conv2d_dgrad_split3: needs stride 1 and K %% 32 == 0 (K=%d)", d->K);
     if (lddx <= 0) lddx = d->ldx;
+    if (conv_halo16_dgrad_shape(d) && aligned16(gy) && aligned16(wsplit_t) && aligned16(dx) && (lddx & 3) == 0 &&
+        (!residual || (aligned16(residual) && (ldres & 3) == 0)) && (!mask || (aligned16(mask) && (ldmask & 3) == 0))) {
+        // a forward SAME conv of gy (32 channels) with the flipped / transposed image: rows = the layer's input channels
+        ConvHaloParams q{};
+        q.X = gy; q.H = d->H; q.W = d->W; q.ldx = ldgy; q.Wimg = static_cast<const char*>(wsplit_t);
+        q.w_lo_off = (unsigned)((size_t)d->C * d->R * d->S * d->K * 2);
+        q.Y = dx; q.ldy = lddx; q.res = residual; q.ldres = ldres; q.mask = mask; q.ldmask = ldmask;
+        hipStream_t st = (hipStream_t)stream;
+        if (terms == 1) return d->C == 64 ? launch_conv_halo16<SplitBF16, 1, 32, 64, 1>(q, d->N, st)
+                                          : launch_conv_halo16<SplitBF16, 1, 32, 32, 1>(q, d->N, st);
+        return d->C == 64 ? launch_conv_halo16<SplitBF16, 3, 32, 64, 1>(q, d->N, st)
+                          : launch_conv_halo16<SplitBF16, 3, 32, 32, 1>(q, d->N, st);
+    }
     IgemmParams p{};
     p.A = gy; p.H = d->OH; p.W = d->OW; p.C = d->K; p.lda = ldgy;
     p.OH = d->H; p.OW = d->W; p.R = d->R; p.S = d->S; p.stride = 1;

@@ -1132,6 +1132,66 @@ def test_two_pass_conv3_equals_conv_then_bn_pass(device, case):
     close(got, r64.reshape(rows, K), tol=2e-6, what="two-pass conv3 vs fp64 %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(4, 112, 149, 32), (5, 112, 149, 64), (9, 85, 90, 64), (17, 61, 67, 32), (40, 56, 74, 64)])
+@pytest.mark.parametrize("bf16", [True, False])
+def test_conv_halo16_fwd_dgrad_match_fp64(device, case, bf16):
+    """The halo form of the forward conv and of the data gradient of the 3x3 / stride-1 / SAME layers with 32 or 64 input and
+    32 output channels (round 4, conv_halo16_kernel behind acimg_conv2d_fwd_split3 / _bf16 and acimg_conv2d_dgrad_split3 /
+    _bf16 from 65536 pixels on): the input tile with its halo staged once as 16-bit planes, the whole weight image in LDS.
+    Forward: bias, raw output into a channel slice of a wider buffer, batch-norm partials (one row per workgroup) of conv +
+    bias; data gradient: residual + ReLU mask, dx into a slice.  bf16 = one MFMA per product on ROUNDED operands (against
+    fp64 of the rounded operands), else f16x3 forward / bf16x3 backward (against fp64 of the unrounded ones).  Heights and
+    widths off the 8 x 32 (4 x 32) tile grid; two runs, the same bits."""
+    from acimg import ops
+
+    N, H, W, Cc = case
+    K = 32
+    g = torch.Generator().manual_seed(9 + N + Cc + int(bf16))
+    x = torch.randn(N, H, W, Cc, generator=g).requires_grad_(True)
+    w = (torch.randn(3, 3, Cc, K, generator=g) * (2.0 / (9 * Cc)) ** 0.5).requires_grad_(True)
+    b = (torch.randn(K, generator=g) * 0.1).requires_grad_(True)
+    gy = torch.randn(N, H, W, K, generator=g) * 1e-3
+    res = torch.randn(N, H, W, Cc, generator=g) * 1e-3
+    maskt = torch.randn(N, H, W, Cc, generator=g)
+    d = ops.conv_desc(N, H, W, Cc, K, 3, 3, 1, "SAME", ldy=K + 32)
+    rows = ops.conv2d_fwd_split3_stats_rows(d)
+    assert rows == 256                                   # the halo form's statistics rows: one per workgroup
+    plan = ops.Plan(device, eager=True)
+    wd = w.detach().to(device)
+    wimg = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=device)
+    ops.conv2d_split3_prepare(plan, d, wd, wimg, bf16=bf16)
+    wt = torch.zeros(ops.conv2d_split3_dgrad_weight_bytes(d), dtype=torch.uint8, device=device)
+    ops.conv2d_split3_prepare_dgrad(plan, d, wd, wt)
+    xd, gyd, bd = x.detach().to(device), gy.to(device), b.detach().to(device)
+    outs = []
+    for _ in range(2):
+        ybuf = torch.zeros(N, H, W, K + 32, device=device)
+        st = torch.full((rows, 2, K), float("nan"), device=device)
+        ops.conv2d_fwd_split3(plan, d, xd, wimg, ops.Ptr(ybuf, 32), stats=st, bias=bd, bf16=bf16)
+        dxbuf = torch.zeros(N, H, W, Cc + 16, device=device)
+        ops.conv2d_dgrad_split3(plan, d, gyd, K, wt, ops.Ptr(dxbuf, 16), res.to(device), Cc, maskt.to(device), Cc, bf16=bf16,
+                                lddx=Cc + 16)
+        torch.cuda.synchronize()
+        outs.append((ybuf.cpu(), st.cpu(), dxbuf.cpu()))
+    for a, bb in zip(outs[0], outs[1]):
+        assert torch.equal(a, bb)
+    ybuf, st, dxbuf = outs[0]
+    assert float(ybuf[..., :32].abs().max()) == 0.0 and float(dxbuf[..., :16].abs().max()) == 0.0
+    rnd_ = (lambda t: t.float().to(torch.bfloat16).double()) if bf16 else (lambda t: t.double())
+    xr = rnd_(x.detach()).permute(0, 3, 1, 2).requires_grad_(True)
+    wr = rnd_(w.detach()).permute(3, 2, 0, 1)
+    yr = torch.nn.functional.conv2d(xr, wr, b.detach().double(), padding=1)
+    gr = rnd_(gy).permute(0, 3, 1, 2)
+    (gx,) = torch.autograd.grad(yr, (xr,), gr)
+    yref = yr.detach().permute(0, 2, 3, 1)
+    close(ybuf[..., 32:], yref, tol=2e-5 if bf16 else 2e-6, what="halo16 forward %s bf16=%s" % (case, bf16))
+    flat = yref.reshape(-1, K)
+    close(st[:, 0].sum(0), flat.sum(0), tol=2e-4, what="halo16 stats sum")
+    close(st[:, 1].sum(0), (flat * flat).sum(0), tol=2e-4, what="halo16 stats sumsq")
+    dref = (gx.permute(0, 2, 3, 1) + res.double()) * (maskt > 0).double()
+    close(dxbuf[..., 16:], dref, tol=2e-5 if bf16 else 3e-5, what="halo16 data gradient %s bf16=%s" % (case, bf16))
+
+
 @pytest.mark.parametrize("case", [(4, 112, 149, 32, 0), (5, 112, 149, 64, 0), (9, 85, 90, 64, 32), (17, 61, 67, 32, 8),
                                   (40, 56, 74, 64, 0)])
 @pytest.mark.parametrize("bf16", [True, False])
