@@ -1279,9 +1279,13 @@ int acimg_clip_softmax_ce(const float* logits, int ldl, int clips, int F, int K,
     return check_launch("clip_softmax_ce");
 }
 
+// partial-sum workgroups of the reduce pass: one per CU (round 4 measured four per CU: 22 launches 1133 -> 1223 us, the
+// finalize walks four times the partials)
+static constexpr long BN_BWD_BLOCKS = 256;
+
 size_t acimg_bn_bwd_workspace(long rows, int C) {
     long blocks = (rows + 255) / 256;
-    if (blocks > 256) blocks = 256;
+    if (blocks > BN_BWD_BLOCKS) blocks = BN_BWD_BLOCKS;
     if (blocks < 1) blocks = 1;
     return (size_t)(blocks + 1) * 2 * C * sizeof(float);
 }
@@ -1294,7 +1298,7 @@ int acimg_bn_bwd(const float* x, int ldx, const float* gy, int ldgy, const float
         return fail(ACIMG_EINVAL, "bn_bwd: C=%d must be a multiple of 4 (<= 1024), buffers 16-byte aligned", C);
     if (ws_bytes < acimg_bn_bwd_workspace(rows, C) || !ws) return fail(ACIMG_EWORKSPACE, "bn_bwd: workspace too small");
     long blocks = (rows + 255) / 256;
-    if (blocks > 256) blocks = 256;       // one workgroup per CU; the finalize pass walks the partials 8 at a time
+    if (blocks > BN_BWD_BLOCKS) blocks = BN_BWD_BLOCKS;   // the finalize pass walks the partials 8 at a time
     if (blocks < 1) blocks = 1;
     const long rpb = (rows + blocks - 1) / blocks;
     float* partial = static_cast<float*>(ws);
