@@ -816,7 +816,7 @@ static size_t wgrad_ws_bytes(int M, int KK, int Ngemm, int ldo) {
     wgrad_tile(Ngemm, bmo, bn);
     int s = std::max(pick_wgrad_splits(M, KK, Ngemm, bmo, bn), pick_wgrad_splits(M, KK, Ngemm, bmo, wgrad_split3_bn(Ngemm)));
     // the halo form of the 3x3 32- / 64-channel -> 32-column layers (wgrad_halo16_kernel) leaves one slab per CU
-    if (Ngemm == 32 && (KK == 9 * 32 || KK == 9 * 64) && M >= 65536 && s < 256) s = 256;
+    if (Ngemm <= 32 && KK % 9 == 0 && KK <= 9 * 64 && M >= 65536 && s < (KK <= 9 * 16 ? 512 : 256)) s = KK <= 9 * 16 ? 512 : 256;
     return s > 1 ? (size_t)(s + 1) * ((size_t)KK + 1) * ldo * sizeof(float) : 0;
 }
 
@@ -1049,26 +1049,32 @@ struct WgradHalo16Params {
     const float* X; int H, W, ldx;
     const float* G; int ldg;
     int tiles_x, tiles_y; long tiles;
-    float* out; float* db_out; int ldo;      // slabs [gridDim.x][9 C][ldo], [gridDim.x][ldo]
+    float* out; float* db_out; int ldo;      // slabs [gridDim.x][9 creal][ldo], [gridDim.x][ldo]
+    int creal, nreal;                        // channels really there (multiples of 4; the rest of the C x 32 tile is zeros)
 };
 
-template <int C, int TERMS>
-__global__ __launch_bounds__(512, 1) void wgrad_halo16_kernel(const WgradHalo16Params p) {
-    constexpr int TH = TERMS == 1 ? 8 : 4, TW = 32, XH = TH + 2, XWV = TW + 2, XW = 36;
+// C: channel width of the x image (64, 32, or 16 for the few-channel layers: fewer real channels are zero padded);
+// NNT: 16-column tiles of gy (2, or 1 for <= 16 output channels: the waves that would multiply padding take tile rows instead)
+template <int C, int TERMS, int NNT = 2>
+__global__ __launch_bounds__(512, C == 16 ? 2 : 1) void wgrad_halo16_kernel(const WgradHalo16Params p) {
+    constexpr int TH = (TERMS == 1 || C == 16) ? 8 : 4, TW = 32, XH = TH + 2, XWV = TW + 2, XW = 36;
     constexpr int PITCH = C * 2;                      // bytes per pixel and plane
     constexpr int XPL = XH * XW * PITCH;              // one x plane
     constexpr int GPL = TH * TW * 64;                 // one gy plane (32 columns of bf16)
     constexpr int NCT = C / 16;                       // 16-channel tiles
-    constexpr int NJ = 8 / (NCT * 2);                 // row groups: waves with the same (channel tile, column tile)
+    constexpr int NJ = 8 / (NCT * NNT);               // row groups: waves with the same (channel tile, column tile)
     constexpr int NXL = (XH * XWV * (C / 4) + 511) / 512, NGL = TH * TW * 8 / 512;     // float4 loads per thread and tile
-    static_assert((C == 64 || C == 32) && TH % NJ == 0 && TH * TW * 8 % 512 == 0, "shape");
+    static_assert((C == 64 || C == 32 || C == 16) && TH % NJ == 0 && TH * TW * 8 % 512 == 0, "shape");
     extern __shared__ __attribute__((aligned(16))) float wh16_smem[];
     char* const lds = reinterpret_cast<char*>(wh16_smem);
     char* const gl = lds + (TERMS == 3 ? 2 : 1) * XPL;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
-    const int ct = wid % NCT, nt = (wid / NCT) & 1, jh = wid / (NCT * 2);
-    auto swx = [](int col) { return C == 64 ? 2 * (((col >> 1) & 1) | (((col >> 3) & 1) << 1)) : 2 * ((col >> 3) & 1); };
+    const int ct = wid % NCT, nt = (wid / NCT) % NNT, jh = wid / (NCT * NNT);
+    // (C = 16: 32-byte pixels, no room to swizzle: pixels 8 apart share banks, a 2-way conflict the HBM-bound kernel absorbs)
+    auto swx = [](int col) {
+        return C == 64 ? 2 * (((col >> 1) & 1) | (((col >> 3) & 1) << 1)) : (C == 32 ? 2 * ((col >> 3) & 1) : 0);
+    };
     auto swg = [](int col) { return 2 * ((col >> 3) & 1); };
 
     // fragment read addresses: lane (q, pp) of group g supplies pixel column s + 8 g + 4 h + q, channels 4 pp .. + 3 of its
@@ -1101,7 +1107,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo16_kernel(const WgradHalo16P
             const int row = pix / XWV, col = pix - row * XWV;
             const int iy = ty * TH + row - 1, ix = tx * TW + col - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < XH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            if (row < XH && c4 * 4 < p.creal && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
                 v = *reinterpret_cast<const float4*>(xi + ((long)iy * p.W + ix) * p.ldx + c4 * 4);
             rx[k] = v;
         }
@@ -1112,7 +1118,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo16_kernel(const WgradHalo16P
             const int row = pix / TW, col = pix - row * TW;
             const int oy = ty * TH + row, ox = tx * TW + col;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (oy < p.H && ox < p.W) v = *reinterpret_cast<const float4*>(gi + ((long)oy * p.W + ox) * p.ldg + c4 * 4);
+            if (oy < p.H && ox < p.W && c4 * 4 < p.nreal) v = *reinterpret_cast<const float4*>(gi + ((long)oy * p.W + ox) * p.ldg + c4 * 4);
             rg[k] = v;
         }
     };
@@ -1192,30 +1198,45 @@ __global__ __launch_bounds__(512, 1) void wgrad_halo16_kernel(const WgradHalo16P
     // the row groups of one (channel tile, column tile) meet through LDS (C = 32), then lane (li, g) of acc[tap] holds
     // dW[tap * C + 16 ct + li][16 nt + 4 g .. + 3]
     if (NJ > 1) {
-        __syncthreads();
+        // one round per row group (in group order: deterministic): its waves park their sums, group 0 adds them
         f32x4* red = reinterpret_cast<f32x4*>(lds);
-        if (jh == 1) {
+        const int w0 = wid % (NCT * NNT);            // this wave's (channel tile, column tile) slot
+        for (int r = 1; r < NJ; ++r) {
+            __syncthreads();
+            if (jh == r) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) red[((wid - NCT * 2) * 10 + t) * 64 + lane] = acc[t];
-            red[((wid - NCT * 2) * 10 + 9) * 64 + lane] = accb;
+                for (int t = 0; t < 9; ++t) red[(w0 * 10 + t) * 64 + lane] = acc[t];
+                red[(w0 * 10 + 9) * 64 + lane] = accb;
+            }
+            __syncthreads();
+            if (jh == 0) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[t] += red[(w0 * 10 + t) * 64 + lane];
+                accb += red[(w0 * 10 + 9) * 64 + lane];
+            }
         }
-        __syncthreads();
-        if (jh == 1) return;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] += red[(wid * 10 + t) * 64 + lane];
-        accb += red[(wid * 10 + 9) * 64 + lane];
+        if (jh != 0) return;
     }
-    float* out = p.out + (long)blockIdx.x * (9 * C) * p.ldo;
+    float* out = p.out + (long)blockIdx.x * (9 * p.creal) * p.ldo;
+    const bool nok = nt * 16 + 4 * g < p.nreal;
+    if (nok && ct * 16 + li < p.creal) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-        *reinterpret_cast<f32x4*>(out + (long)(t * C + ct * 16 + li) * p.ldo + nt * 16 + 4 * g) = acc[t];
-    if (p.db_out && ct == 0 && li == 0)
+        for (int t = 0; t < 9; ++t)
+            *reinterpret_cast<f32x4*>(out + (long)(t * p.creal + ct * 16 + li) * p.ldo + nt * 16 + 4 * g) = acc[t];
+    }
+    if (p.db_out && ct == 0 && li == 0 && nok)
         *reinterpret_cast<f32x4*>(p.db_out + (long)blockIdx.x * p.ldo + nt * 16 + 4 * g) = accb;
 }
 
+// split3: the caller asked for 16-bit matrix-core arithmetic (acimg_conv2d_wgrad_split3 / _bf16).  The FEW-CHANNEL layers
+// (fewer than 32 input channels: the full-resolution layers of the RGB / spectrogram U-Nets, which arrive through the fp32
+// entry acimg_conv2d_wgrad) take the same kernel in its three-term form - fp32-class results (5e-6) - on a zero-padded
+// 32 x 32 channel tile: 224x298 16->8 189 -> ~60 us against the exact-f32 halo kernel (round 4)
 static bool wgrad_halo16_ok(const WgradParams& p, bool split3) {
-    return split3 && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 && (p.C == 32 || p.C == 64) &&
-           p.Ngemm == 32 && p.Nld == 32 && p.OH == p.H && p.OW == p.W && p.ldo >= 32 && (long)p.M >= 65536 && g_cfg.wgrad_halo;
+    const bool few = p.C < 32;
+    return (split3 || few) && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad_t == 1 && p.pad_l == 1 &&
+           (p.C == 64 || (p.C <= 32 && p.C % 4 == 0)) && p.Ngemm <= 32 && p.Ngemm % 4 == 0 && p.Nld == p.Ngemm && p.OH == p.H &&
+           p.OW == p.W && p.ldo >= p.Ngemm && (long)p.M >= 65536 && g_cfg.wgrad_halo;
 }
 
 static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws_bytes, hipStream_t st,
@@ -1229,19 +1250,23 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
     if (wgrad_halo16_ok(p, split3)) {
         WgradHalo16Params q{};
         q.X = p.X; q.H = p.H; q.W = p.W; q.ldx = p.ldx; q.G = p.G; q.ldg = p.ldg; q.ldo = p.ldo;
-        const int th = terms == 1 ? 8 : 4;
+        q.creal = p.C; q.nreal = p.Ngemm;
+        if (p.C < 32) terms = 3;                                       // few-channel layers: always the fp32-class form
+        const int cpad = p.C == 64 ? 64 : (p.C > 16 ? 32 : 16);
+        const int nnt = (cpad == 16 && p.Ngemm <= 16) ? 1 : 2;
+        const int th = (terms == 1 || cpad == 16) ? 8 : 4;
         q.tiles_x = cdiv(p.W, 32); q.tiles_y = cdiv(p.H, th);
         q.tiles = (long)(p.M / (p.H * p.W)) * q.tiles_x * q.tiles_y;
-        int nb = 256;                                                 // one workgroup per CU
-        if (nb > q.tiles) nb = (int)q.tiles;
+        int nb = p.C <= 16 ? 512 : 256;     // one workgroup per CU; two for the few-channel instances (56 KiB of LDS, tiny slabs:
+        if (nb > q.tiles) nb = (int)q.tiles;       // their load / store / multiply phases overlap across workgroups)
         const size_t need = (size_t)nb * ((size_t)p.KK + 1) * p.ldo * sizeof(float);
         if (ws != nullptr && ws_bytes >= need) {      // (the sizing query covers it: pick_wgrad_splits gives these shapes >= 256 slabs)
             q.out = static_cast<float*>(ws);
             float* db_slab = q.out + (size_t)nb * p.KK * p.ldo;
             q.db_out = db ? db_slab : nullptr;
             const int xh = th + 2, planes = terms == 3 ? 2 : 1;
-            int lds = planes * (xh * 36 * p.C * 2 + th * 32 * 64);
-            if (p.C == 32 && lds < 4 * 10 * 64 * 16) lds = 4 * 10 * 64 * 16;      // the row groups' final sum through LDS
+            int lds = planes * (xh * 36 * cpad * 2 + th * 32 * 64);
+            if (lds < 4 * 10 * 64 * 16) lds = 4 * 10 * 64 * 16;                   // the row groups' final sums through LDS
 #define ACIMG_WH16(Cv, Tv)                                                                                              \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
@@ -1252,10 +1277,20 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
         }                                                                                                               \
         hipLaunchKernelGGL((wgrad_halo16_kernel<Cv, Tv>), dim3(nb), dim3(512), lds, st, q);                             \
     } while (0)
-            if (p.C == 64 && terms == 1) ACIMG_WH16(64, 1);
-            else if (p.C == 64) ACIMG_WH16(64, 3);
-            else if (terms == 1) ACIMG_WH16(32, 1);
-            else ACIMG_WH16(32, 3);
+            if (cpad == 64 && terms == 1) ACIMG_WH16(64, 1);
+            else if (cpad == 64) ACIMG_WH16(64, 3);
+            else if (cpad == 32 && terms == 1) ACIMG_WH16(32, 1);
+            else if (cpad == 32) ACIMG_WH16(32, 3);
+            else if (nnt == 2) ACIMG_WH16(16, 3);
+            else {
+                static bool attr16 = false;
+                if (!attr16) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_halo16_kernel<16, 3, 1>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+                    attr16 = true;
+                }
+                hipLaunchKernelGGL((wgrad_halo16_kernel<16, 3, 1>), dim3(nb), dim3(512), lds, st, q);
+            }
 #undef ACIMG_WH16
             int rc = check_launch("wgrad_halo16");
             if (rc) return rc;

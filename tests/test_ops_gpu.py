@@ -1232,6 +1232,36 @@ def test_wgrad_halo16_matches_fp64(device, case, bf16):
     close(outs[0][1], gr.sum((0, 2, 3)), tol=2e-5 if bf16 else 4e-5, what="halo16 bias gradient %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(3, 150, 160, 8, 8), (3, 150, 161, 16, 8), (3, 147, 160, 4, 8), (3, 150, 160, 8, 32),
+                                  (3, 150, 160, 16, 16)])
+def test_few_channel_wgrad_on_the_halo16_kernel(device, case):
+    """The FEW-CHANNEL 3x3 weight gradients (fewer than 32 input channels: the full-resolution layers of the RGB / spectrogram
+    U-Nets) reach the fp32 entry acimg_conv2d_wgrad and, from 65536 pixels on, run on the bf16x3 halo kernel over a
+    zero-padded 32 x 32 channel tile (round 4): fp32-class results against fp64, bias gradient, pad rows / columns of dw
+    untouched, two runs the same bits"""
+    from acimg import ops
+
+    N, H, W, Cc, K = case
+    g = torch.Generator().manual_seed(3 + Cc + K)
+    x = torch.randn(N, H, W, Cc, generator=g)
+    gy = torch.randn(N, H, W, K, generator=g) * 1e-2
+    d = ops.conv_desc(N, H, W, Cc, K, 3, 3, 1, "SAME")
+    plan = ops.Plan(device, eager=True)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((3, 3, Cc, K), float("nan"), device=device)
+        db = torch.full((K,), float("nan"), device=device)
+        ops.conv2d_wgrad(plan, d, x.to(device), gy.to(device), K, dw, db)
+        torch.cuda.synchronize()
+        outs.append((dw.cpu(), db.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    wz = torch.zeros(K, Cc, 3, 3, dtype=torch.float64, requires_grad=True)
+    yr = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wz, padding=1)
+    (gw,) = torch.autograd.grad(yr, (wz,), gy.double().permute(0, 3, 1, 2))
+    close(outs[0][0], gw.permute(2, 3, 1, 0), tol=2e-5, what="few-channel halo16 wgrad %s" % (case,))
+    close(outs[0][1], gy.double().sum((0, 1, 2)), tol=2e-5, what="few-channel halo16 bias gradient %s" % (case,))
+
+
 @pytest.mark.parametrize("case", [(134400, 64, 256), (34048, 256, 1024), (20011, 128, 512), (8512, 512, 2048), (37, 64, 100),
                                   (4099, 128, 136), (50, 256, 256)])
 def test_gram_statistics_match_fp64(device, case):
