@@ -184,7 +184,9 @@ def load_traffic_profile(kernel_name, tag=None):
     import re
     files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic_*.txt"))
              if (("hbm_traffic_%s_" % tag) in f if tag else not any(("hbm_traffic_%s_" % t) in f for t in TRAFFIC_TAGS))]
-    files = sorted(files, key=lambda f: (int(re.search(r"profiles/r(\d+)/", f).group(1)), os.path.getmtime(f), f))
+    # newest = highest round, then the name (files are named in commit order: r04j < r04z); never the mtime - a fresh
+    # clone gives every file the same one
+    files = sorted(files, key=lambda f: (int(re.search(r"profiles/r(\d+)/", f).group(1)), os.path.basename(f)))
     if not files:
         return None
     f = files[-1]
