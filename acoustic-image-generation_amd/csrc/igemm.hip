@@ -20,6 +20,7 @@
 #include "skinny_kernel.hpp"
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 
 namespace acimg {
 
@@ -1468,6 +1469,249 @@ static int launch_direct(const DirectParams& q, void* ws, size_t ws_bytes, hipSt
     return check_launch("direct_conv");
 }
 
+extern "C++" {
+// ------------------------------------------------------------------------------------------
+// MFMA form of the FEW-CHANNEL 3x3 / stride-1 / SAME layers (8 or 16 channels in, up to 32 out: the full-resolution
+// layers of the RGB / spectrogram U-Nets; round 4).  The direct kernel above does these with packed fp32 FMAs at ~2x its
+// VALU bound (224x298 8->8: 61 us for 27 us of bytes), every input value fetched nine times through the L1.  Here the taps
+// are the GEMM's K axis: a pixel's CIN channels are one 16- or 32-byte run of a 16-bit plane, so the 8 k-values a lane
+// holds of a 16x16x32 MFMA operand are ONE tap's channels of ONE pixel - a single ds_read_b128 at the tap's shift, four
+// (two) taps per MFMA, 9 taps in 3 (5) MFMAs per term with the spare tap slots multiplied by zero weights.  A workgroup
+// stages a 16 x 32 pixel tile WITH ITS HALO once (fp32 -> hi / lo planes on the way), keeps the whole weight image in
+// registers (weights in the A slot: a lane's 4 accumulators are 4 consecutive output channels of one pixel, 16-byte
+// stores), 3-term split product (fp32-class: f16 hi/lo forward, bf16 hi/lo for gradients).  MODE 0: forward - bias, raw
+// output, batch-norm partials of conv + bias: one statistics row per workgroup; MODE 1: data gradient as a forward conv of
+// gy with the flipped / transposed image, residual added.  Persistent workgroups, two per CU; XCD j walks the contiguous
+// tile range [j * per, (j + 1) * per) so that neighbouring tiles share an L2; the next tile's loads are held in registers
+// while the current one is multiplied.
+// ------------------------------------------------------------------------------------------
+struct FewParams {
+    const float* X; int H, W, ldx;
+    const char* Wimg; unsigned w_lo_off;         // 16-bit image [NOUTP][KTOT] (k = tap slot * CIN + c), hi plane; lo plane w_lo_off bytes on
+    float* Y; int ldy, nout;                     // nout: real output channels (multiple of 4)
+    const float* bias; const float* res; int ldres;
+    float* stats; int stats_ld;                  // [gridDim.x][2][stats_ld] or null
+    int tiles_x, tiles_y; long tiles, per;
+    // weight preparation
+    const float* w; int ldw, wrows, cin, mode;
+};
+constexpr int FEW16_WGS = 512;
+constexpr int few16_ktot(int cin) { return ((9 + 32 / cin - 1) / (32 / cin)) * 32; }
+
+// w (fp32 HWIO, possibly the flipped / transposed view of a data gradient) -> the [NOUTP][KTOT] hi / lo image
+template <typename TR>
+__global__ __launch_bounds__(256) void few16_prepare_kernel(const FewParams p, int CIN, int NOUTP, typename TR::T* img) {
+    typedef typename TR::T T;
+    const int KTOT = few16_ktot(CIN);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NOUTP * KTOT) return;
+    const int row = i / KTOT, k = i - row * KTOT;
+    const int slot = k / CIN, c = k - slot * CIN;
+    float v = 0.f;
+    if (slot < 9 && row < p.nout && c < p.cin)
+        v = p.mode == 0 ? p.w[((long)slot * p.wrows + c) * p.ldw + row] : p.w[((long)(8 - slot) * p.wrows + row) * p.ldw + c];
+    v *= TR::WSCALE;
+    const T h = (T)v;
+    img[i] = h;
+    img[(size_t)NOUTP * KTOT + i] = (T)(v - (float)h);
+}
+
+template <typename TR, int CIN, int NOUTP, int MODE>
+__global__ __launch_bounds__(512, (NOUTP == 32 && MODE == 0) ? 2 : 4) void conv_few16_kernel(const FewParams p) {
+    typedef typename TR::V8 V8;
+    constexpr int TH = 16, TW = 32, XH = TH + 2, XWV = TW + 2, XW = 36;
+    constexpr int PB = CIN * 2;                        // bytes per pixel and plane
+    constexpr int XPL = XH * XW * PB;
+    constexpr int TPK = 32 / CIN;                      // taps per 32-deep MFMA
+    constexpr int NKB = (9 + TPK - 1) / TPK;           // MFMAs per term and tile
+    constexpr int KTOT = NKB * 32;
+    constexpr int NT = NOUTP / 16;
+    constexpr int NXL = (XH * XWV * (CIN / 4) + 511) / 512;
+    static_assert(CIN == 8 || CIN == 16, "few-channel instance");
+    static_assert(2 * XPL >= 8 * 2 * NOUTP * 4, "statistics scratch");
+    __shared__ __attribute__((aligned(16))) char xl[2 * XPL];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, g = lane >> 4;
+
+    // the weight image -> registers (once per workgroup): lane (li, g) of (n, kb) holds row 16 n + li, k = 32 kb + 8 g .. + 7
+    V8 wh[NT][NKB], wlo[NT][NKB];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            const size_t off = ((size_t)(n * 16 + li) * KTOT + kb * 32 + g * 8) * 2;
+            wh[n][kb] = *reinterpret_cast<const V8*>(p.Wimg + off);
+            wlo[n][kb] = *reinterpret_cast<const V8*>(p.Wimg + p.w_lo_off + off);
+        }
+    // this lane's tap shift of each MFMA: slot = kb * TPK + g / (4 / TPK); spare slots read tap 0 (their weights are zero)
+    int boff[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        int slot = kb * TPK + (CIN == 8 ? g : g >> 1);
+        if (slot > 8) slot = 0;
+        const int r = slot / 3, q = slot - 3 * r;
+        boff[kb] = (r * XW + q) * PB + (CIN == 8 ? 0 : (g & 1) * 16);
+    }
+
+    float4 rx[NXL];
+    auto load_tile = [&](long tile) {
+        const int tx = (int)(tile % p.tiles_x);
+        const long t2 = tile / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y);
+        const long img = t2 / p.tiles_y;
+        const float* xi = p.X + img * p.H * p.W * p.ldx;
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) {
+            const int i = tid + 512 * k;
+            const int c4 = i % (CIN / 4), pix = i / (CIN / 4);
+            const int row = pix / XWV, col = pix - row * XWV;
+            const int iy = ty * TH + row - 1, ix = tx * TW + col - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < XH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *reinterpret_cast<const float4*>(xi + ((long)iy * p.W + ix) * p.ldx + c4 * 4);
+            rx[k] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) {
+            const int i = tid + 512 * k;
+            const int c4 = i % (CIN / 4), pix = i / (CIN / 4);
+            const int row = pix / XWV, col = pix - row * XWV;
+            if (row < XH) {
+                const int off = (row * XW + col) * PB + c4 * 8;
+                uint2 hi, lo;
+                split4<TR>(rx[k], hi, lo);
+                *reinterpret_cast<uint2*>(xl + off) = hi;
+                *reinterpret_cast<uint2*>(xl + XPL + off) = lo;
+            }
+        }
+    };
+
+    f32x4 s1[NT], s2[NT], bv[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        s1[n] = s2[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[n] = (MODE == 0 && p.bias && n * 16 + 4 * g < p.nout) ? *reinterpret_cast<const f32x4*>(p.bias + n * 16 + 4 * g)
+                                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // XCD j = blockIdx.x % 8 walks tiles [j * per, (j + 1) * per), its gridDim.x / 8 workgroups interleaved
+    const int xcd = blockIdx.x & 7, nslot = gridDim.x >> 3;
+    const long t_end = min((long)(xcd + 1) * p.per, p.tiles);
+    long tile = (long)xcd * p.per + (blockIdx.x >> 3);
+    if (tile < t_end) load_tile(tile);
+    for (; tile < t_end; tile += nslot) {
+        __syncthreads();                               // everyone has finished reading the previous tile
+        store_tile();
+        __syncthreads();
+        const int tx = (int)(tile % p.tiles_x);
+        const long t2 = tile / p.tiles_x;
+        const int ty = (int)(t2 % p.tiles_y);
+        const long img = t2 / p.tiles_y;
+        if (tile + nslot < t_end) load_tile(tile + nslot);     // in flight while this tile is multiplied
+        // wave wid: tile rows 2 wid, 2 wid + 1, both 16-pixel halves
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int urow = 2 * wid + (u >> 1), ucol = (u & 1) * 16;
+            const int base = (urow * XW + ucol + li) * PB;
+            f32x4 acc[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const V8 xh = *reinterpret_cast<const V8*>(xl + base + boff[kb]);
+                const V8 xlo = *reinterpret_cast<const V8*>(xl + XPL + base + boff[kb]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    acc[n] = TR::mfma(wlo[n][kb], xh, acc[n]);
+                    acc[n] = TR::mfma(wh[n][kb], xlo, acc[n]);
+                    acc[n] = TR::mfma(wh[n][kb], xh, acc[n]);
+                }
+            }
+            // lane (li, g) of acc[n] holds output pixel (row urow, column ucol + li), channels 16 n + 4 g .. + 3
+            const int oy = ty * TH + urow, ox = tx * TW + ucol + li;
+            if (oy < p.H && ox < p.W) {
+                const long pix = (img * p.H + oy) * p.W + ox;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if (n * 16 + 4 * g < p.nout) {
+                        f32x4 v = acc[n] * TR::OUTSCALE + bv[n];
+                        if (MODE == 1) {
+                            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n * 16 + 4 * g);
+                        } else {
+                            s1[n] += v;
+                            s2[n] += v * v;
+                        }
+                        *reinterpret_cast<f32x4*>(p.Y + pix * p.ldy + n * 16 + 4 * g) = v;
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == 0 && p.stats) {
+        // the workgroup's statistics row: 16 pixel lanes by DPP, 8 waves through LDS, in wave order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(xl);     // [8][2][NOUTP]
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float a = row16_sum(s1[n][c]), b = row16_sum(s2[n][c]);
+                if (li == 0) {
+                    red[(wid * 2 + 0) * NOUTP + n * 16 + 4 * g + c] = a;
+                    red[(wid * 2 + 1) * NOUTP + n * 16 + 4 * g + c] = b;
+                }
+            }
+        __syncthreads();
+        if (tid < 2 * NOUTP) {
+            const int which = tid / NOUTP, n = tid % NOUTP;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t += red[(w * 2 + which) * NOUTP + n];
+            if (n < p.nout) p.stats[((long)blockIdx.x * 2 + which) * p.stats_ld + n] = t;
+        }
+    }
+}
+
+// shapes the few-channel MFMA kernel takes (cin = channels of the tensor that is convolved, nout = channels written)
+static bool few16_shape(int R, int S, int stride, int pad_t, int pad_l, int H, int W, int OH, int OW, int cin, int nout, long pixels) {
+    return R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == H && OW == W && (cin == 8 || cin == 16) &&
+           nout >= 4 && nout <= 32 && (nout & 3) == 0 && !(cin == 16 && nout > 16) && pixels >= 65536 && g_cfg.wgrad_halo;
+}
+static bool few16_fwd_shape(const AcimgConvDesc* d) {
+    return few16_shape(d->R, d->S, d->stride, d->pad_t, d->pad_l, d->H, d->W, d->OH, d->OW, d->C, d->K,
+                       (long)d->N * d->OH * d->OW) && d->act == ACIMG_ACT_NONE && d->ldx >= d->C;
+}
+// the data gradient of a 3x3 / stride-1 / SAME conv is the same conv of gy (K channels, padded to 4) into C channels
+static bool few16_dgrad_shape(const AcimgConvDesc* d) {
+    return few16_shape(d->R, d->S, d->stride, d->R - 1 - d->pad_t, d->S - 1 - d->pad_l, d->OH, d->OW, d->H, d->W,
+                       (d->K + 3) & ~3, d->C, (long)d->N * d->H * d->W);
+}
+static size_t few16_ws_bytes(int cin, int nout) { return ((size_t)2 * (nout <= 16 ? 16 : 32) * few16_ktot(cin) * 2 + 255) & ~(size_t)255; }
+
+template <typename TR, int CIN, int NOUTP, int MODE>
+static int launch_few16(FewParams q, int N, void* ws, hipStream_t st) {
+    constexpr int KTOT = few16_ktot(CIN);
+    q.tiles_x = cdiv(q.W, 32); q.tiles_y = cdiv(q.H, 16);
+    q.tiles = (long)N * q.tiles_x * q.tiles_y;
+    q.per = (q.tiles + 7) / 8;
+    typename TR::T* img = static_cast<typename TR::T*>(ws);
+    q.Wimg = static_cast<const char*>(ws); q.w_lo_off = NOUTP * KTOT * 2;
+    hipLaunchKernelGGL((few16_prepare_kernel<TR>), dim3(cdiv(NOUTP * KTOT, 256)), dim3(256), 0, st, q, CIN, NOUTP, img);
+    hipLaunchKernelGGL((conv_few16_kernel<TR, CIN, NOUTP, MODE>), dim3(FEW16_WGS), dim3(512), 0, st, q);
+    return check_launch("conv_few16");
+}
+// forward (MODE 0, f16 hi / lo) or data gradient (MODE 1, bf16 hi / lo) on the few-channel MFMA kernel
+template <int MODE>
+static int dispatch_few16(const FewParams& q, int N, int cin, int nout, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!ws || ws_bytes < few16_ws_bytes(cin, nout) || !aligned16(ws)) return fail(ACIMG_EWORKSPACE, "conv_few16: workspace too small");
+    typedef typename std::conditional<MODE == 0, SplitF16, SplitBF16>::type TR;
+    if (cin == 8) return nout <= 16 ? launch_few16<TR, 8, 16, MODE>(q, N, ws, st) : launch_few16<TR, 8, 32, MODE>(q, N, ws, st);
+    return launch_few16<TR, 16, 16, MODE>(q, N, ws, st);
+}
+}  // extern "C++"
+
 static int fwd_kiters(const AcimgConvDesc* d) {
     const bool rowrun = d->S > 1 && d->ldx == d->C;
     const int L = rowrun ? d->S * d->C : d->C;
@@ -1481,6 +1725,7 @@ static int stats_block_rows(const AcimgConvDesc* d) {
     return pick_splits(M, d->K, c, fwd_kiters(d)) > 1 ? 256 : c.bm;
 }
 int acimg_conv2d_stats_rows(const AcimgConvDesc* d) {
+    if (few16_fwd_shape(d)) return FEW16_WGS;        // the few-channel MFMA kernel leaves one row per workgroup
     return cdiv((long)d->N * d->OH * d->OW, stats_block_rows(d));
 }
 
@@ -1536,7 +1781,8 @@ size_t acimg_conv2d_fwd_workspace(const AcimgConvDesc* d) {
     const size_t a = igemm_ws_bytes(d->N * d->OH * d->OW, d->K, fwd_kiters(d));
     const size_t b = d->C <= 16 && d->K <= 32 ? direct_ws_bytes(d->R, d->S, d->C, (d->K + 7) & ~7) : 0;
     const size_t c = skinny_fwd_ws_bytes(d);
-    return std::max(a, std::max(b, c));
+    const size_t f = few16_fwd_shape(d) ? few16_ws_bytes(d->C, d->K) : 0;
+    return std::max(std::max(a, f), std::max(b, c));
 }
 
 int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,
@@ -1563,6 +1809,17 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
         if (rc) return rc;
         hipLaunchKernelGGL(skinny_fwd_reduce_kernel, dim3(cdiv(d->N * (d->K / 4), 256)), dim3(256), 0, (hipStream_t)stream, q);
         return check_launch("conv2d_fwd (skinny reduce)");
+    }
+    if (few16_fwd_shape(d)) {
+        // acimg_conv2d_stats_rows(d) promised one statistics row per workgroup of this kernel: no silent fallback
+        if (in_scale || in_shift || in_relu || !aligned16(x) || !aligned16(y) || (d->ldy & 3) || d->ldy < d->K ||
+            (bias && !aligned16(bias)))
+            return fail(ACIMG_EINVAL, "conv2d_fwd: few-channel MFMA shape with an input affine or unaligned operands");
+        FewParams q{};
+        q.X = x; q.H = d->H; q.W = d->W; q.ldx = d->ldx; q.Y = y; q.ldy = d->ldy; q.nout = d->K; q.bias = bias;
+        q.stats = stats; q.stats_ld = d->ldw;
+        q.w = w; q.ldw = d->ldw; q.wrows = d->C; q.cin = d->C; q.mode = 0;
+        return dispatch_few16<0>(q, d->N, d->C, d->K, ws, ws_bytes, (hipStream_t)stream);
     }
     if (direct_ok(d->C, d->K, d->ldy, 0, y, bias, nullptr, in_scale != nullptr, nullptr) &&
         (long)d->N * d->OH * d->OW >= 65536) {
@@ -1653,11 +1910,11 @@ size_t acimg_conv2d_dgrad_workspace(const AcimgConvDesc* d) {
         return dilated_bytes(d->N, d->OH, d->OW, ca, d->stride) +
                igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * d->S * cdiv(ca, 32)) +
                igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * cdiv(d->S * ca, 32)) +
-               (ca <= 16 && d->C <= 32 ? direct_ws_bytes(d->R, d->S, ca, (d->C + 7) & ~7) : 0);
+               (ca <= 16 && d->C <= 32 ? std::max(direct_ws_bytes(d->R, d->S, ca, (d->C + 7) & ~7), few16_ws_bytes(ca, d->C)) : 0);
     // rowrun depends on ldgy, unknown here: per-tap kiters is the larger bound for splits
     return igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * d->S * cdiv(ca, 32)) +
            igemm_ws_bytes(d->N * d->H * d->W, d->C, d->R * cdiv(d->S * ca, 32)) +
-           (ca <= 16 && d->C <= 32 ? direct_ws_bytes(d->R, d->S, ca, (d->C + 7) & ~7) : 0);
+           (ca <= 16 && d->C <= 32 ? std::max(direct_ws_bytes(d->R, d->S, ca, (d->C + 7) & ~7), few16_ws_bytes(ca, d->C)) : 0);
 }
 
 int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w,
@@ -1710,6 +1967,14 @@ int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
         d1.stride = 1; d1.OH = OH1; d1.OW = OW1;
         return acimg_conv2d_dgrad(&d1, static_cast<const float*>(ws), ca, w, dx, lddx, residual, ldres, mask, ldmask,
                                   static_cast<char*>(ws) + db, ws_bytes - db, tickets, stream);
+    }
+    if (few16_dgrad_shape(d) && !mask && aligned16(gy) && aligned16(dx) && (lddx & 3) == 0 && ws && aligned16(ws) &&
+        ws_bytes >= few16_ws_bytes(ca, d->C) && (!residual || ((ldres & 3) == 0 && aligned16(residual)))) {
+        FewParams q{};
+        q.X = gy; q.H = d->OH; q.W = d->OW; q.ldx = ldgy; q.Y = dx; q.ldy = lddx; q.nout = d->C;
+        q.res = residual; q.ldres = ldres;
+        q.w = w; q.ldw = d->ldw; q.wrows = d->C; q.cin = d->K; q.mode = 1;
+        return dispatch_few16<1>(q, d->N, ca, d->C, ws, ws_bytes, (hipStream_t)stream);
     }
     if (d->stride == 1 && direct_ok(ca, d->C, lddx, ldres, dx, nullptr, residual, false, mask) &&
         (long)d->N * d->H * d->W >= 65536) {

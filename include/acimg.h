@@ -69,6 +69,9 @@ typedef struct AcimgConvDesc {
  * is given (deferred batch-norm of the producer, zero padding applied AFTER the affine), else x.
  * stats (optional, [grid_m][2][ldw] floats, grid_m = acimg_conv2d_stats_rows(d)) receives per
  * row-block partial sums / sums of squares of the raw conv output for batch-norm statistics.
+ * The row count belongs to THIS descriptor, `act` included (the few-channel 3x3 / stride-1 layers from 65536
+ * pixels on run on an MFMA kernel that leaves one row per workgroup - 512 - when act is ACIMG_ACT_NONE, and on
+ * the direct kernel with one row per 256 pixels otherwise): size the buffer from the descriptor that is launched.
  * Replaces: tf.layers.conv2d   models/unet_acresnet.py:159-168,173-182,82,89-94
  *           slim layers.conv2d / resnet_utils.conv2d_same   models/resnet50.py:109-121,205-209 */
 int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, const float* bias,

@@ -765,7 +765,7 @@ def test_few_channel_direct_conv(device, case):
     close(y, torch.relu(raw.detach()), what="direct fwd %s" % (case,))
     # (statistics are those of the stored tensor = conv + bias with the activation applied here; BN layers use act NONE)
     d0 = ops.conv_desc(N, H, W, Cc, K, R, S, stride, padding, act=0)
-    stats.zero_()
+    stats = torch.zeros(ops.conv2d_stats_rows(d0), 2, K, device=device)      # (the MFMA form has its own row count)
     ops.conv2d_fwd(plan, d0, dev(x.detach(), device), wd, dev(b, device), y, stats=stats)
     torch.cuda.synchronize()
     flat = raw.detach().reshape(-1, K)
@@ -778,7 +778,8 @@ def test_few_channel_direct_conv(device, case):
     if Cc % 8 == 0:
         ops.conv2d_dgrad(plan, d0, dev(gy, device), K, wd, dx, dev(res, device), Cc)
         torch.cuda.synchronize()
-        close(dx, x.grad + res, what="direct dgrad %s" % (case,))
+        # (the 3x3 / stride-1 cases take the bf16x3 MFMA form from 65536 pixels on: 16 mantissa bits per operand)
+        close(dx, x.grad + res, tol=3e-5, what="direct dgrad %s" % (case,))
 
 
 def test_tapconv_matches_valid_conv(device):
@@ -1260,6 +1261,57 @@ def test_few_channel_wgrad_on_the_halo16_kernel(device, case):
     (gw,) = torch.autograd.grad(yr, (wz,), gy.double().permute(0, 3, 1, 2))
     close(outs[0][0], gw.permute(2, 3, 1, 0), tol=2e-5, what="few-channel halo16 wgrad %s" % (case,))
     close(outs[0][1], gy.double().sum((0, 1, 2)), tol=2e-5, what="few-channel halo16 bias gradient %s" % (case,))
+
+
+@pytest.mark.parametrize("case", [(3, 150, 160, 8, 8), (3, 147, 161, 8, 32), (3, 150, 161, 16, 8), (3, 151, 170, 8, 16),
+                                  (1, 224, 298, 8, 8), (1, 224, 298, 16, 16)])
+def test_few_channel_mfma_conv_matches_fp64(device, case):
+    """The MFMA form of the few-channel 3x3 / stride-1 / SAME layers (round 4, conv_few16_kernel behind acimg_conv2d_fwd and
+    acimg_conv2d_dgrad from 65536 pixels on, 8 or 16 channels convolved, up to 32 written): taps along the GEMM's K axis, the
+    tile with its halo staged once as hi / lo planes, 3-term split product (f16 hi/lo forward, bf16 hi/lo backward).
+    Forward: bias, raw output into a channel slice of a wider buffer, the input a channel slice of a wider buffer,
+    batch-norm partials (one row per workgroup) of conv + bias; data gradient: residual, dx into a slice, gy with a wider
+    pixel stride.  Heights / widths off the 16 x 32 tile grid; two runs, the same bits."""
+    from acimg import ops
+
+    N, H, W, Cc, K = case
+    g = torch.Generator().manual_seed(31 + N + Cc + K)
+    x = torch.randn(N, H, W, Cc, generator=g)
+    w = torch.randn(3, 3, Cc, K, generator=g) * (2.0 / (9 * Cc)) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1
+    gy = torch.randn(N, H, W, K, generator=g) * 1e-3
+    res = torch.randn(N, H, W, Cc, generator=g) * 1e-3
+    d = ops.conv_desc(N, H, W, Cc, K, 3, 3, 1, "SAME", ldx=Cc + 8, ldy=K + 4)
+    rows = ops.conv2d_stats_rows(d)
+    assert rows == 512                                   # one statistics row per workgroup of the MFMA form
+    plan = ops.Plan(device, eager=True)
+    wd, bd = w.to(device), b.to(device)
+    xbuf = torch.full((N, H, W, Cc + 8), 7.0, device=device)
+    xbuf[..., 8:] = x.to(device)
+    gybuf = torch.full((N, H, W, K + 4), -3.0, device=device)
+    gybuf[..., :K] = gy.to(device)
+    outs = []
+    for _ in range(2):
+        ybuf = torch.zeros(N, H, W, K + 4, device=device)
+        st = torch.full((rows, 2, K), float("nan"), device=device)
+        ops.conv2d_fwd(plan, d, ops.Ptr(xbuf, 8), wd, bd, ops.Ptr(ybuf, 4), stats=st)
+        dxbuf = torch.zeros(N, H, W, Cc + 16, device=device)
+        ops.conv2d_dgrad(plan, d, gybuf, K + 4, wd, ops.Ptr(dxbuf, 16), res.to(device), Cc, None, 0, lddx=Cc + 16)
+        torch.cuda.synchronize()
+        outs.append((ybuf.cpu(), st.cpu(), dxbuf.cpu()))
+    for a, bb in zip(outs[0], outs[1]):
+        assert torch.equal(a, bb)
+    ybuf, st, dxbuf = outs[0]
+    assert float(ybuf[..., :4].abs().max()) == 0.0 and float(dxbuf[..., :16].abs().max()) == 0.0
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, w.double().permute(3, 2, 0, 1), b.double(), padding=1)
+    (gx,) = torch.autograd.grad(yr, (xr,), gy.double().permute(0, 3, 1, 2))
+    yref = yr.detach().permute(0, 2, 3, 1)
+    close(ybuf[..., 4:], yref, tol=2e-6, what="few-channel MFMA forward %s" % (case,))
+    flat = yref.reshape(-1, K)
+    close(st[:, 0].sum(0), flat.sum(0), tol=2e-4, what="few-channel MFMA stats sum")
+    close(st[:, 1].sum(0), (flat * flat).sum(0), tol=2e-4, what="few-channel MFMA stats sumsq")
+    close(dxbuf[..., 16:], gx.permute(0, 2, 3, 1) + res.double(), tol=3e-5, what="few-channel MFMA data gradient %s" % (case,))
 
 
 @pytest.mark.parametrize("case", [(134400, 64, 256), (34048, 256, 1024), (20011, 128, 512), (8512, 512, 2048), (37, 64, 100),
