@@ -1486,7 +1486,8 @@ extern "C++" {
 // while the current one is multiplied.
 // ------------------------------------------------------------------------------------------
 struct FewParams {
-    const float* X; int H, W, ldx;
+    const float* X; int H, W, ldx;               // H, W: the OUTPUT grid (tiles); the tensor that is convolved:
+    int Hin, Win, SH, SW, dil, pad_t, pad_l;     //   Hin x Win pixels, stored SH x SW (dil 2: zero-inserted view of a stride-2 gy)
     const char* Wimg; unsigned w_lo_off;         // 16-bit image [NOUTP][KTOT] (k = tap slot * CIN + c), hi plane; lo plane w_lo_off bytes on
     float* Y; int ldy, nout;                     // nout: real output channels (multiple of 4)
     const float* bias; const float* res; int ldres;
@@ -1516,7 +1517,7 @@ __global__ __launch_bounds__(256) void few16_prepare_kernel(const FewParams p, i
     img[(size_t)NOUTP * KTOT + i] = (T)(v - (float)h);
 }
 
-template <typename TR, int CIN, int NOUTP, int MODE>
+template <typename TR, int CIN, int NOUTP, int MODE, int CLOAD = CIN>
 __global__ __launch_bounds__(512, (NOUTP == 32 && MODE == 0) ? 2 : 4) void conv_few16_kernel(const FewParams p) {
     typedef typename TR::V8 V8;
     constexpr int TH = 16, TW = 32, XH = TH + 2, XWV = TW + 2, XW = 36;
@@ -1526,8 +1527,8 @@ __global__ __launch_bounds__(512, (NOUTP == 32 && MODE == 0) ? 2 : 4) void conv_
     constexpr int NKB = (9 + TPK - 1) / TPK;           // MFMAs per term and tile
     constexpr int KTOT = NKB * 32;
     constexpr int NT = NOUTP / 16;
-    constexpr int NXL = (XH * XWV * (CIN / 4) + 511) / 512;
-    static_assert(CIN == 8 || CIN == 16, "few-channel instance");
+    constexpr int NXL = (XH * XWV * (CLOAD / 4) + 511) / 512;
+    static_assert((CIN == 8 || CIN == 16) && (CLOAD == CIN || (CIN == 8 && CLOAD == 4)), "few-channel instance");
     static_assert(2 * XPL >= 8 * 2 * NOUTP * 4, "statistics scratch");
     __shared__ __attribute__((aligned(16))) char xl[2 * XPL];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1559,16 +1560,21 @@ __global__ __launch_bounds__(512, (NOUTP == 32 && MODE == 0) ? 2 : 4) void conv_
         const long t2 = tile / p.tiles_x;
         const int ty = (int)(t2 % p.tiles_y);
         const long img = t2 / p.tiles_y;
-        const float* xi = p.X + img * p.H * p.W * p.ldx;
+        const float* xi = p.X + img * p.SH * p.SW * p.ldx;
 #pragma unroll
         for (int k = 0; k < NXL; ++k) {
             const int i = tid + 512 * k;
-            const int c4 = i % (CIN / 4), pix = i / (CIN / 4);
+            const int c4 = i % (CLOAD / 4), pix = i / (CLOAD / 4);
             const int row = pix / XWV, col = pix - row * XWV;
-            const int iy = ty * TH + row - 1, ix = tx * TW + col - 1;
+            const int iy = ty * TH + row - p.pad_t, ix = tx * TW + col - p.pad_l;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < XH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                v = *reinterpret_cast<const float4*>(xi + ((long)iy * p.W + ix) * p.ldx + c4 * 4);
+            bool ok = row < XH && (unsigned)iy < (unsigned)p.Hin && (unsigned)ix < (unsigned)p.Win;
+            int sy = iy, sx = ix;
+            if (p.dil == 2) {               // the zero-inserted view: only the even positions hold data
+                ok = ok && !((iy | ix) & 1);
+                sy >>= 1; sx >>= 1;
+            }
+            if (ok) v = *reinterpret_cast<const float4*>(xi + ((long)sy * p.SW + sx) * p.ldx + c4 * 4);
             rx[k] = v;
         }
     };
@@ -1576,7 +1582,7 @@ __global__ __launch_bounds__(512, (NOUTP == 32 && MODE == 0) ? 2 : 4) void conv_
 #pragma unroll
         for (int k = 0; k < NXL; ++k) {
             const int i = tid + 512 * k;
-            const int c4 = i % (CIN / 4), pix = i / (CIN / 4);
+            const int c4 = i % (CLOAD / 4), pix = i / (CLOAD / 4);
             const int row = pix / XWV, col = pix - row * XWV;
             if (row < XH) {
                 const int off = (row * XW + col) * PB + c4 * 8;
@@ -1587,6 +1593,10 @@ __global__ __launch_bounds__(512, (NOUTP == 32 && MODE == 0) ? 2 : 4) void conv_
             }
         }
     };
+    if (CLOAD < CIN) {                      // 4 real channels in an 8-channel image: the upper half stays zero
+        for (int i = tid; i < 2 * XH * XW; i += 512)
+            *reinterpret_cast<uint2*>(xl + (i / (XH * XW)) * XPL + (i % (XH * XW)) * PB + 8) = make_uint2(0u, 0u);
+    }
 
     f32x4 s1[NT], s2[NT], bv[NT];
 #pragma unroll
@@ -1675,22 +1685,27 @@ __global__ __launch_bounds__(512, (NOUTP == 32 && MODE == 0) ? 2 : 4) void conv_
 }
 
 // shapes the few-channel MFMA kernel takes (cin = channels of the tensor that is convolved, nout = channels written)
-static bool few16_shape(int R, int S, int stride, int pad_t, int pad_l, int H, int W, int OH, int OW, int cin, int nout, long pixels) {
-    return R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && OH == H && OW == W && (cin == 8 || cin == 16) &&
-           nout >= 4 && nout <= 32 && (nout & 3) == 0 && !(cin == 16 && nout > 16) && pixels >= 65536 && g_cfg.wgrad_halo;
+// cin = channels of the tensor that is convolved (4 forward only: an 8-channel image with a zero upper half), nout = written
+static bool few16_channels(int cin, int nout, long pixels) {
+    return (cin == 4 || cin == 8 || cin == 16) && nout >= 4 && nout <= 32 && (nout & 3) == 0 && !(cin != 8 && nout > 16) &&
+           pixels >= 65536 && g_cfg.wgrad_halo;
 }
 static bool few16_fwd_shape(const AcimgConvDesc* d) {
-    return few16_shape(d->R, d->S, d->stride, d->pad_t, d->pad_l, d->H, d->W, d->OH, d->OW, d->C, d->K,
-                       (long)d->N * d->OH * d->OW) && d->act == ACIMG_ACT_NONE && d->ldx >= d->C;
+    return d->R == 3 && d->S == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->OH == d->H && d->OW == d->W &&
+           few16_channels(d->C, d->K, (long)d->N * d->OH * d->OW) && d->act == ACIMG_ACT_NONE && d->ldx >= d->C;
 }
-// the data gradient of a 3x3 / stride-1 / SAME conv is the same conv of gy (K channels, padded to 4) into C channels
+// the data gradient of a 3x3 conv is a 3x3 / stride-1 conv of gy (K channels, padded to 4) into C channels: of gy itself
+// (stride 1) or of its zero-inserted view (stride 2: the view is formed while the tile is staged, no copy)
 static bool few16_dgrad_shape(const AcimgConvDesc* d) {
-    return few16_shape(d->R, d->S, d->stride, d->R - 1 - d->pad_t, d->S - 1 - d->pad_l, d->OH, d->OW, d->H, d->W,
-                       (d->K + 3) & ~3, d->C, (long)d->N * d->H * d->W);
+    const int ca = (d->K + 3) & ~3;
+    return d->R == 3 && d->S == 3 && (d->stride == 1 || d->stride == 2) && ca != 4 && d->pad_t <= 2 && d->pad_l <= 2 &&
+           few16_channels(ca, d->C, (long)d->N * d->H * d->W);
 }
-static size_t few16_ws_bytes(int cin, int nout) { return ((size_t)2 * (nout <= 16 ? 16 : 32) * few16_ktot(cin) * 2 + 255) & ~(size_t)255; }
+static size_t few16_ws_bytes(int cin, int nout) {
+    return ((size_t)2 * (nout <= 16 ? 16 : 32) * few16_ktot(cin == 4 ? 8 : cin) * 2 + 255) & ~(size_t)255;
+}
 
-template <typename TR, int CIN, int NOUTP, int MODE>
+template <typename TR, int CIN, int NOUTP, int MODE, int CLOAD = CIN>
 static int launch_few16(FewParams q, int N, void* ws, hipStream_t st) {
     constexpr int KTOT = few16_ktot(CIN);
     q.tiles_x = cdiv(q.W, 32); q.tiles_y = cdiv(q.H, 16);
@@ -1699,7 +1714,7 @@ static int launch_few16(FewParams q, int N, void* ws, hipStream_t st) {
     typename TR::T* img = static_cast<typename TR::T*>(ws);
     q.Wimg = static_cast<const char*>(ws); q.w_lo_off = NOUTP * KTOT * 2;
     hipLaunchKernelGGL((few16_prepare_kernel<TR>), dim3(cdiv(NOUTP * KTOT, 256)), dim3(256), 0, st, q, CIN, NOUTP, img);
-    hipLaunchKernelGGL((conv_few16_kernel<TR, CIN, NOUTP, MODE>), dim3(FEW16_WGS), dim3(512), 0, st, q);
+    hipLaunchKernelGGL((conv_few16_kernel<TR, CIN, NOUTP, MODE, CLOAD>), dim3(FEW16_WGS), dim3(512), 0, st, q);
     return check_launch("conv_few16");
 }
 // forward (MODE 0, f16 hi / lo) or data gradient (MODE 1, bf16 hi / lo) on the few-channel MFMA kernel
@@ -1707,6 +1722,7 @@ template <int MODE>
 static int dispatch_few16(const FewParams& q, int N, int cin, int nout, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!ws || ws_bytes < few16_ws_bytes(cin, nout) || !aligned16(ws)) return fail(ACIMG_EWORKSPACE, "conv_few16: workspace too small");
     typedef typename std::conditional<MODE == 0, SplitF16, SplitBF16>::type TR;
+    if (cin == 4) return launch_few16<TR, 8, 16, MODE, 4>(q, N, ws, st);
     if (cin == 8) return nout <= 16 ? launch_few16<TR, 8, 16, MODE>(q, N, ws, st) : launch_few16<TR, 8, 32, MODE>(q, N, ws, st);
     return launch_few16<TR, 16, 16, MODE>(q, N, ws, st);
 }
@@ -1817,6 +1833,7 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
             return fail(ACIMG_EINVAL, "conv2d_fwd: few-channel MFMA shape with an input affine or unaligned operands");
         FewParams q{};
         q.X = x; q.H = d->H; q.W = d->W; q.ldx = d->ldx; q.Y = y; q.ldy = d->ldy; q.nout = d->K; q.bias = bias;
+        q.Hin = q.SH = d->H; q.Win = q.SW = d->W; q.dil = 1; q.pad_t = 1; q.pad_l = 1;
         q.stats = stats; q.stats_ld = d->ldw;
         q.w = w; q.ldw = d->ldw; q.wrows = d->C; q.cin = d->C; q.mode = 0;
         return dispatch_few16<0>(q, d->N, d->C, d->K, ws, ws_bytes, (hipStream_t)stream);
@@ -1901,7 +1918,18 @@ static size_t dilated_bytes(int N, int H, int W, int C, int s) {
     return ((size_t)N * ((H - 1) * s + 1) * ((W - 1) * s + 1) * C * 4 + 255) & ~(size_t)255;
 }
 
+// data gradient of a 3x3 / stride-1 / SAME layer with 32 output and 4 - 16 input channels (configs[1]: 112x149 8 -> 32) through
+// the fp32 entry: a conv of the 32-channel gy on the 16-row instance of the halo kernel (defined with conv_halo16_kernel)
+static bool dgrad_halo16_narrow_shape(const AcimgConvDesc* d) {
+    return d->R == 3 && d->S == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 && d->OH == d->H && d->OW == d->W &&
+           d->K == 32 && d->C <= 16 && (d->C & 3) == 0 && (long)d->N * d->H * d->W >= 65536 && g_cfg.wgrad_halo;
+}
+static constexpr size_t DGRAD_HALO16_NARROW_WS = 2 * 16 * 288 * 2;
+static int dgrad_halo16_narrow(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w, float* dx, int lddx,
+                               const float* residual, int ldres, const float* mask, int ldmask, void* ws, hipStream_t st);
+
 size_t acimg_conv2d_dgrad_workspace(const AcimgConvDesc* d) {
+    if (dgrad_halo16_narrow_shape(d)) return DGRAD_HALO16_NARROW_WS + 256;
     if (dgrad_is_patch(d)) return igemm_ws_bytes(d->N * d->OH * d->OW, d->R * d->S * d->C, cdiv(up4(d->K), 32));
     const int ca = up4(d->K);
     if (subpixel_ok(d->stride, d->C, ca))   // sub-pixel form: combined weights + the GEMM's own split-K slabs
@@ -1951,6 +1979,23 @@ int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
         return launch_subpixel(gy, d->N, d->OH, d->OW, ca, ldgy, w, d->R, d->S, d->ldw, d->C, dx, lddx, d->H, d->W, -d->pad_t,
                                -d->pad_l, nullptr, residual, ldres, mask, ldmask, ACIMG_ACT_NONE, ws, ws_bytes, tickets,
                                (hipStream_t)stream, "conv2d_dgrad");
+    if (dgrad_halo16_narrow_shape(d) && aligned16(gy) && aligned16(dx) && (lddx & 3) == 0 && ws && aligned16(ws) &&
+        ws_bytes >= DGRAD_HALO16_NARROW_WS && (!residual || ((ldres & 3) == 0 && aligned16(residual))) &&
+        (!mask || ((ldmask & 3) == 0 && aligned16(mask))))
+        return dgrad_halo16_narrow(d, gy, ldgy, w, dx, lddx, residual, ldres, mask, ldmask, ws, (hipStream_t)stream);
+    if (few16_dgrad_shape(d) && !subpixel_ok(d->stride, d->C, ca) && !mask && aligned16(gy) && aligned16(dx) && (lddx & 3) == 0 &&
+        ws && aligned16(ws) && ws_bytes >= few16_ws_bytes(ca, d->C) && (!residual || ((ldres & 3) == 0 && aligned16(residual)))) {
+        // dx[h][w][c] = sum gy1[h - (2 - pad_t) + r'][w - (2 - pad_l) + s'][k] W[2 - r'][2 - s'][c][k], gy1 = gy (stride 1) or
+        // its zero-inserted view (stride 2), zero outside
+        FewParams q{};
+        q.X = gy; q.ldx = ldgy; q.SH = d->OH; q.SW = d->OW; q.dil = d->stride;
+        q.Hin = (d->OH - 1) * d->stride + 1; q.Win = (d->OW - 1) * d->stride + 1;
+        q.pad_t = 2 - d->pad_t; q.pad_l = 2 - d->pad_l;
+        q.H = d->H; q.W = d->W; q.Y = dx; q.ldy = lddx; q.nout = d->C;
+        q.res = residual; q.ldres = ldres;
+        q.w = w; q.ldw = d->ldw; q.wrows = d->C; q.cin = d->K; q.mode = 1;
+        return dispatch_few16<1>(q, d->N, ca, d->C, ws, ws_bytes, (hipStream_t)stream);
+    }
     if (d->stride > 1 && !dgrad_is_patch(d)) {
         // general stride: the strided conv is a subsampled stride-1 conv, so its data gradient is the stride-1
         // data gradient of the zero-inserted gy
@@ -1967,14 +2012,6 @@ int acimg_conv2d_dgrad(const AcimgConvDesc* d, const float* gy, int ldgy, const 
         d1.stride = 1; d1.OH = OH1; d1.OW = OW1;
         return acimg_conv2d_dgrad(&d1, static_cast<const float*>(ws), ca, w, dx, lddx, residual, ldres, mask, ldmask,
                                   static_cast<char*>(ws) + db, ws_bytes - db, tickets, stream);
-    }
-    if (few16_dgrad_shape(d) && !mask && aligned16(gy) && aligned16(dx) && (lddx & 3) == 0 && ws && aligned16(ws) &&
-        ws_bytes >= few16_ws_bytes(ca, d->C) && (!residual || ((ldres & 3) == 0 && aligned16(residual)))) {
-        FewParams q{};
-        q.X = gy; q.H = d->OH; q.W = d->OW; q.ldx = ldgy; q.Y = dx; q.ldy = lddx; q.nout = d->C;
-        q.res = residual; q.ldres = ldres;
-        q.w = w; q.ldw = d->ldw; q.wrows = d->C; q.cin = d->K; q.mode = 1;
-        return dispatch_few16<1>(q, d->N, ca, d->C, ws, ws_bytes, (hipStream_t)stream);
     }
     if (d->stride == 1 && direct_ok(ca, d->C, lddx, ldres, dx, nullptr, residual, false, mask) &&
         (long)d->N * d->H * d->W >= 65536) {
@@ -2200,7 +2237,7 @@ extern "C++" {
 struct ConvHaloParams {
     const float* X; int H, W, ldx;
     const char* Wimg; unsigned w_lo_off;         // 16-bit image [rows][9 CIN], hi plane; lo plane w_lo_off bytes further
-    float* Y; int ldy;
+    float* Y; int ldy, nout;                     // nout: channels written (0 = all NOUT; the image's further rows are zero)
     const float* bias; const float* res; int ldres; const float* mask; int ldmask;
     float* stats; int stats_ld;                  // [gridDim.x][2][stats_ld] or null
     int tiles_x, tiles_y; long tiles;
@@ -2336,6 +2373,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo16_kernel(const ConvHaloParam
                 const long pix = (img * p.H + oy) * p.W + ox;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
+                    if (NOUT == 16 && n * 16 + 4 * g >= p.nout) continue;      // (the 16-row instance serves 4 - 16 channels)
                     f32x4 v = acc[m][n] * TR::OUTSCALE + bv[n];
                     if (MODE == 1) {
                         if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + n * 16 + 4 * g);
@@ -2398,6 +2436,7 @@ static int launch_conv_halo16(ConvHaloParams q, int N, hipStream_t st) {
     static_assert(lds <= 160 * 1024 && 8 * 2 * NOUT * 4 <= lds, "LDS budget");
     q.tiles_x = cdiv(q.W, 32); q.tiles_y = cdiv(q.H, TH);
     q.tiles = (long)N * q.tiles_x * q.tiles_y;
+    if (!q.nout) q.nout = NOUT;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo16_kernel<TR, TERMS, CIN, NOUT, MODE>),
@@ -2408,6 +2447,19 @@ static int launch_conv_halo16(ConvHaloParams q, int N, hipStream_t st) {
     return check_launch("conv_halo16");
 }
 }  // extern "C++"
+
+static int dgrad_halo16_narrow(const AcimgConvDesc* d, const float* gy, int ldgy, const float* w, float* dx, int lddx,
+                               const float* residual, int ldres, const float* mask, int ldmask, void* ws, hipStream_t st) {
+    // the flipped / transposed image [16 rows = input channels, zero beyond C][k = tap * 32 + gy channel], bf16 hi / lo
+    FewParams f{};
+    f.w = w; f.ldw = d->ldw; f.wrows = d->C; f.cin = d->K; f.mode = 1; f.nout = d->C;
+    hipLaunchKernelGGL((few16_prepare_kernel<SplitBF16>), dim3(cdiv(16 * 288, 256)), dim3(256), 0, st, f, 32, 16,
+                       static_cast<__bf16*>(ws));
+    ConvHaloParams q{};
+    q.X = gy; q.H = d->H; q.W = d->W; q.ldx = ldgy; q.Wimg = static_cast<const char*>(ws); q.w_lo_off = 16 * 288 * 2;
+    q.Y = dx; q.ldy = lddx; q.nout = d->C; q.res = residual; q.ldres = ldres; q.mask = mask; q.ldmask = ldmask;
+    return launch_conv_halo16<SplitBF16, 3, 32, 16, 1>(q, d->N, st);
+}
 
 int acimg_conv2d_fwd_split3_stats_rows(const AcimgConvDesc* d) {
     const int M = d->N * d->OH * d->OW;

@@ -50,11 +50,12 @@ def test_host_side_queries_need_no_gpu(lib):
     rows, tiled = splits * 32 * 12 * 16 * 12 * 4, splits * 24 * 256 * 16 * 4
     assert lib.acimg_conv2d_fwd_workspace(__import__("ctypes").byref(d)) == max(rows, tiled)
     # few-channel 3x3 / stride-1 / SAME layers from 65536 pixels on: the MFMA form leaves one statistics row per workgroup;
-    # with an activation, 4 channels in, or below the size rule the direct kernel's 256-pixel blocks remain
+    # with an activation, a stride, or below the size rule the direct kernel's 256-pixel blocks remain
     assert ops.conv2d_stats_rows(ops.conv_desc(32, 224, 298, 8, 8, 3, 3, 1, "SAME")) == 512
     assert ops.conv2d_stats_rows(ops.conv_desc(32, 224, 298, 16, 8, 3, 3, 1, "SAME")) == 512
     assert ops.conv2d_stats_rows(ops.conv_desc(32, 112, 149, 8, 32, 3, 3, 1, "SAME")) == 512
-    assert ops.conv2d_stats_rows(ops.conv_desc(32, 224, 298, 4, 8, 3, 3, 1, "SAME")) == 32 * 224 * 298 // 256
+    assert ops.conv2d_stats_rows(ops.conv_desc(32, 224, 298, 4, 8, 3, 3, 1, "SAME")) == 512
+    assert ops.conv2d_stats_rows(ops.conv_desc(32, 224, 298, 8, 8, 3, 3, 2, "SAME")) == 32 * 112 * 149 // 256
     assert ops.conv2d_stats_rows(ops.conv_desc(32, 224, 298, 8, 8, 3, 3, 1, "SAME", act=1)) == 32 * 224 * 298 // 256
     assert ops.conv2d_stats_rows(ops.conv_desc(2, 100, 100, 8, 8, 3, 3, 1, "SAME")) != 512
 

@@ -741,7 +741,8 @@ def test_error_reporting(device):
 
 @pytest.mark.parametrize("case", [(2, 200, 180, 8, 8, 3, 3, 1, "SAME"), (2, 190, 200, 4, 8, 3, 3, 1, "SAME"),
                                   (2, 200, 190, 16, 8, 3, 3, 1, "SAME"), (3, 224, 298, 8, 8, 3, 3, 2, "SAME"),
-                                  (2, 150, 240, 8, 32, 2, 3, 2, "VALID"), (2, 180, 200, 8, 16, 3, 3, 1, "SAME")])
+                                  (2, 150, 240, 8, 32, 2, 3, 2, "VALID"), (2, 180, 200, 8, 16, 3, 3, 1, "SAME"),
+                                  (2, 225, 299, 8, 8, 3, 3, 2, "SAME"), (2, 200, 190, 8, 16, 3, 3, 2, "SAME")])
 def test_few_channel_direct_conv(device, case):
     """the direct few-channel path (>= 65536 output pixels, C*K <= 512): forward with bias + ReLU + BN statistics,
     and the data gradient with a residual, vs fp64"""
@@ -778,7 +779,8 @@ def test_few_channel_direct_conv(device, case):
     if Cc % 8 == 0:
         ops.conv2d_dgrad(plan, d0, dev(gy, device), K, wd, dx, dev(res, device), Cc)
         torch.cuda.synchronize()
-        # (the 3x3 / stride-1 cases take the bf16x3 MFMA form from 65536 pixels on: 16 mantissa bits per operand)
+        # (the 3x3 cases take the bf16x3 MFMA form from 65536 pixels on - 16 mantissa bits per operand; with stride 2 the
+        # zero-inserted view of gy is formed while the tile is staged: even and odd sizes = leading padding 0 and 1)
         close(dx, x.grad + res, tol=3e-5, what="direct dgrad %s" % (case,))
 
 
@@ -1264,11 +1266,13 @@ def test_few_channel_wgrad_on_the_halo16_kernel(device, case):
 
 
 @pytest.mark.parametrize("case", [(3, 150, 160, 8, 8), (3, 147, 161, 8, 32), (3, 150, 161, 16, 8), (3, 151, 170, 8, 16),
-                                  (1, 224, 298, 8, 8), (1, 224, 298, 16, 16)])
+                                  (1, 224, 298, 8, 8), (1, 224, 298, 16, 16), (3, 147, 160, 4, 8), (2, 190, 181, 4, 16)])
 def test_few_channel_mfma_conv_matches_fp64(device, case):
     """The MFMA form of the few-channel 3x3 / stride-1 / SAME layers (round 4, conv_few16_kernel behind acimg_conv2d_fwd and
     acimg_conv2d_dgrad from 65536 pixels on, 8 or 16 channels convolved, up to 32 written): taps along the GEMM's K axis, the
-    tile with its halo staged once as hi / lo planes, 3-term split product (f16 hi/lo forward, bf16 hi/lo backward).
+    tile with its halo staged once as hi / lo planes, 3-term split product (f16 hi/lo forward, bf16 hi/lo backward);
+    4 input channels ride the 8-channel image with a zero upper half; the data gradient of the 8 -> 32 layer (32-channel gy,
+    8 channels written) takes the 16-row instance of the halo kernel.
     Forward: bias, raw output into a channel slice of a wider buffer, the input a channel slice of a wider buffer,
     batch-norm partials (one row per workgroup) of conv + bias; data gradient: residual, dx into a slice, gy with a wider
     pixel stride.  Heights / widths off the 16 x 32 tile grid; two runs, the same bits."""
