@@ -89,6 +89,8 @@ PROTOTYPES = {
     "acimg_conv2d_wgrad_workspace": (_SZ, [_DP]),
     "acimg_conv2d_wgrad_split3": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),
     "acimg_conv2d_wgrad_bf16": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),
+    "acimg_conv2d_affine_input_ok": (_I, [_DP, _I]),
+    "acimg_conv2d_wgrad_affine": (_I, [_DP, _I, _P, _P, _P, _I, _P, _I, _P, _P, _P, _SZ, _P]),
     "acimg_deconv_fwd": (_I, [_DP, _P, _P, _P, _P, _P, _SZ, _P, _P]),
     "acimg_deconv_dgrad": (_I, [_DP, _P, _I, _P, _P, _P, _I, _P, _SZ, _P, _P]),
     "acimg_deconv_wgrad": (_I, [_DP, _P, _P, _I, _P, _P, _P, _SZ, _P]),

@@ -591,6 +591,20 @@ def conv2d_wgrad_split3(plan, d, x, gy, ldgy, dw, db=None, bf16=False, side=Fals
              _WsPtr(ws), _WsBytes(ws), side=side)
 
 
+def conv2d_affine_input_ok(d, precision):
+    """precision 0 / 1 / 2 = fp32-class / split3 / bf16 entries: do the forward AND the weight gradient of this layer apply a
+    producer's batch-norm affine + ReLU while they stage their input (the halo kernels)?"""
+    return bool(_L().acimg_conv2d_affine_input_ok(C.byref(d), int(precision)))
+
+
+def conv2d_wgrad_affine(plan, d, precision, x, in_scale, in_shift, gy, ldgy, dw, db=None, in_relu=True):
+    """the weight gradient with x' = relu(x * in_scale + in_shift) formed on load (see include/acimg.h)"""
+    L = _L()
+    plan.ws.require(L.acimg_conv2d_wgrad_workspace(C.byref(d)))
+    plan.add("conv2d_wgrad_affine", L.acimg_conv2d_wgrad_affine, C.byref(d), int(precision), x, in_scale, in_shift,
+             int(bool(in_relu)), gy, int(ldgy), dw, db, _WsPtr(plan.ws), _WsBytes(plan.ws))
+
+
 def deconv_fwd(plan, d, x, w, bias, y):
     L = _L()
     plan.ws.require(L.acimg_deconv_workspace(C.byref(d)))

@@ -31,7 +31,16 @@ BN_MOMENTUM, BN_EPS = 0.99, 1e-3   # tf.layers.batch_normalization defaults (SUR
 
 class _CBR(object):
     """one conv + BN + ReLU layer: descriptor, buffers, variable names"""
-    pass
+    deferred = False
+
+    def relu_output(self):
+        """the layer's normalised, rectified output [N, H, W, C]: the buffer the normalise + ReLU pass wrote, or - when the
+        layer's consumers form it on load and no pass ever wrote it (`deferred`) - the same values from the raw output"""
+        y = self.y
+        v = y.t.view(y.N, y.H, y.W, -1)[..., y.off:y.off + y.C]
+        if self.deferred:
+            v = torch.relu(v * self.scale[:y.C] + self.shift[:y.C])
+        return v
 
 
 class UNetVAE(object):
@@ -56,6 +65,10 @@ class UNetVAE(object):
         assert precision in ("split", "f32", "bf16")
         self.precision = precision
         self._bf16 = precision == "bf16"
+        # a conv-BN-ReLU layer whose only consumer is the next 3x3 conv (conv_1 of a block, a "pool" conv) skips its normalise +
+        # ReLU pass when that conv and its weight gradient apply the affine while they stage their tiles
+        # (ops.conv2d_affine_input_ok: the halo kernels); False = every layer materialises its output
+        self.defer_bn = True
         self.scope = self.SCOPE
         self.height, self.width, self.channels = input_shape
         assert self.channels == self.CIN
@@ -65,6 +78,18 @@ class UNetVAE(object):
     def _use_split(self, d):
         return (self.precision in ("split", "bf16") and d.stride == 1 and d.C % 32 == 0 and d.K % 32 == 0 and
                 d.N * d.OH * d.OW >= 16384)
+
+    def _prec(self, d):
+        """precision code of a layer's entry points (include/acimg.h): 0 fp32-class, 1 split3, 2 bf16"""
+        return (2 if self._bf16 else 1) if self._use_split(d) else 0
+
+    def _next_takes_affine(self, N, h, w, cin, K):
+        """does a 3x3 / stride-1 / SAME conv-BN-ReLU layer [N, h, w, cin] -> K read a RAW producer output through the
+        producer's batch-norm affine (forward and weight gradient both)?"""
+        if not self.defer_bn:
+            return False
+        d = ops.conv_desc(N, h, w, up4(cin), K, 3, 3, 1, "SAME", ldx=up4(cin), ldy=up4(K), ldw=up4(K), act=ACT_NONE)
+        return ops.conv2d_affine_input_ok(d, self._prec(d))
 
     def _wsplit(self, name, nbytes, kind):
         key = (name, kind)
@@ -235,11 +260,15 @@ class UNetVAE(object):
         self.train_vars = [n for n in sess.store.tf_names() if n.startswith(self.scope + "/") and
                            not n.endswith(("moving_mean", "moving_variance"))]
 
-    def _cbr(self, plan, name, bn, x, K, R, S, stride, padding, out):
-        """conv + bias -> raw (+ BN statistics) ; bn_finalize ; out = relu(raw*scale + shift)"""
+    def _cbr(self, plan, name, bn, x, K, R, S, stride, padding, out, defer=False):
+        """conv + bias -> raw (+ BN statistics) ; bn_finalize ; out = relu(raw*scale + shift).
+        defer: no normalise + ReLU pass - the layer's output IS its raw tensor with `.affine = (scale, shift)` attached, and
+        the one consumer applies it on load; an input `x` that carries `.affine` is read that way here"""
         z = self.session.zeros
         L = _CBR()
         L.name, L.bn, L.x, L.y = name, bn, x, out
+        aff = getattr(x, "affine", None)
+        in_scale, in_shift = aff if aff is not None else (None, None)
         L.d = ops.conv_desc(x.N, x.H, x.W, x.Cp if x.off == 0 and x.ld == x.Cp else x.C, K, R, S, stride, padding,
                             ldx=x.ld, ldy=up4(K), ldw=up4(K), act=ACT_NONE)
         assert (L.d.OH, L.d.OW) == (out.H, out.W), (name, L.d.OH, L.d.OW, out.H, out.W)
@@ -253,16 +282,23 @@ class UNetVAE(object):
             L.stats = z(L.rows, 2, kp)
             ws = self._wsplit(name, ops.conv2d_split3_weight_bytes(L.d), "fwd")
             ops.conv2d_split3_prepare(plan, L.d, self._P(name + "/kernel"), ws, bf16=self._bf16)     # the kernel changes every step
-            ops.conv2d_fwd_split3(plan, L.d, x.ptr, ws, L.raw.ptr, stats=L.stats if self.training else None,
+            ops.conv2d_fwd_split3(plan, L.d, x.ptr, ws, L.raw.ptr, in_scale=in_scale, in_shift=in_shift,
+                                  in_relu=1 if aff is not None else 0, stats=L.stats if self.training else None,
                                   bias=self._P(name + "/bias"), bf16=self._bf16)
         else:
             ops.conv2d_fwd(plan, L.d, x.ptr, self._P(name + "/kernel"), self._P(name + "/bias"), L.raw.ptr,
+                           in_scale=in_scale, in_shift=in_shift, in_relu=1 if aff is not None else 0,
                            stats=L.stats if self.training else None)
         ops.bn_finalize(plan, L.stats if self.training else None, L.rows if self.training else 0, K, kp,
                         out.pixels if self.training else 0, self._P(bn + "/gamma"), self._P(bn + "/beta"),
                         self._P(bn + "/moving_mean"), self._P(bn + "/moving_variance"), L.scale, L.shift,
                         BN_MOMENTUM, BN_EPS, self.training, L.save_mean, L.save_invstd)
-        ops.bn_relu(plan, L.raw.ptr, L.scale, L.shift, out.ptr, out.pixels, K, kp, out.ld)
+        if defer:
+            L.deferred = True
+            L.y = Act(L.raw.t, x.N, out.H, out.W, K)
+            L.y.affine = (L.scale, L.shift)
+        else:
+            ops.bn_relu(plan, L.raw.ptr, L.scale, L.shift, out.ptr, out.pixels, K, kp, out.ld)
         self.layers[name] = L
         return L
 
@@ -279,10 +315,14 @@ class UNetVAE(object):
         ops.pad_channels(plan, self.images, self.xpad.t, N * H * W, self.CIN, self.xpad.Cp)
         net = self.xpad
         self.skips = {}
-        for name, F_, pool, pad in self.ENC:
+        for li, (name, F_, pool, pad) in enumerate(self.ENC):
             h, w, _ = sizes[name]
-            mid = Act(z(N, h, w, F_), N, h, w, F_)
-            self._cbr(plan, "layer%s/conv_1" % name, "layer%s/bn_1" % name, net, F_, 3, 3, 1, "SAME", mid)
+            if self._next_takes_affine(N, h, w, F_, F_):       # conv_2 reads conv_1's raw output through its batch norm
+                mid = self._cbr(plan, "layer%s/conv_1" % name, "layer%s/bn_1" % name, net, F_, 3, 3, 1, "SAME",
+                                Act(None, N, h, w, F_), defer=True).y
+            else:
+                mid = Act(z(N, h, w, F_), N, h, w, F_)
+                self._cbr(plan, "layer%s/conv_1" % name, "layer%s/bn_1" % name, net, F_, 3, 3, 1, "SAME", mid)
             if name in self.cat:    # the skip tensor is written into its slice of the decoder concat buffer
                 buf, fup, fs = self.cat[name]
                 out = Act(buf, N, h, w, F_, fup + fs, fup)
@@ -296,9 +336,14 @@ class UNetVAE(object):
                     ph, pw = -(-h // 2), -(-w // 2)
                 else:
                     ph, pw = (h - pool[0]) // 2 + 1, (w - pool[1]) // 2 + 1
-                po = Act(z(N, ph, pw, F_), N, ph, pw, F_)
-                self._cbr(plan, "layer%s/pool_2" % name, "layer%s/bn_pool_2" % name, net, F_, pool[0], pool[1], 2,
-                          pad, po)
+                nxt = self.ENC[li + 1][1] if li + 1 < len(self.ENC) else None
+                if nxt is not None and self._next_takes_affine(N, ph, pw, F_, nxt):   # the next block's conv_1 is its only reader
+                    po = self._cbr(plan, "layer%s/pool_2" % name, "layer%s/bn_pool_2" % name, net, F_, pool[0], pool[1], 2,
+                                   pad, Act(None, N, ph, pw, F_), defer=True).y
+                else:
+                    po = Act(z(N, ph, pw, F_), N, ph, pw, F_)
+                    self._cbr(plan, "layer%s/pool_2" % name, "layer%s/bn_pool_2" % name, net, F_, pool[0], pool[1], 2,
+                              pad, po)
                 net = po
         self.conv5 = net
         hh, hw = self.HEAD
@@ -341,8 +386,12 @@ class UNetVAE(object):
                            up.ptr)
             self.ups[name] = (d, net, up)
             catin = Act(buf, N, sh, sw, fup + fs)
-            mid = Act(z(N, sh, sw, F_), N, sh, sw, F_)
-            self._cbr(plan, "layer%s/conv_1" % name, "layer%s/bn_1" % name, catin, F_, 3, 3, 1, "SAME", mid)
+            if self._next_takes_affine(N, sh, sw, F_, F_):
+                mid = self._cbr(plan, "layer%s/conv_1" % name, "layer%s/bn_1" % name, catin, F_, 3, 3, 1, "SAME",
+                                Act(None, N, sh, sw, F_), defer=True).y
+            else:
+                mid = Act(z(N, sh, sw, F_), N, sh, sw, F_)
+                self._cbr(plan, "layer%s/conv_1" % name, "layer%s/bn_1" % name, catin, F_, 3, 3, 1, "SAME", mid)
             out = Act(z(N, sh, sw, F_), N, sh, sw, F_)
             self._cbr(plan, "layer%s/conv_2" % name, "layer%s/bn_2" % name, mid, F_, 3, 3, 1, "SAME", out)
             net = out
@@ -366,7 +415,11 @@ class UNetVAE(object):
         ops.bn_bwd(plan, L.raw.ptr, L.raw.ld, gy.ptr, gy.ld, L.scale, L.shift, L.save_mean, L.save_invstd,
                    self._P(L.bn + "/gamma"), L.y.pixels, up4(K), gy.ptr, gy.ld, self._G(L.bn + "/gamma"),
                    self._G(L.bn + "/beta"))
-        if self._use_split(L.d):
+        aff = getattr(L.x, "affine", None)
+        if aff is not None:      # the input was never normalised in memory: the weight gradient forms it on load, like the forward
+            ops.conv2d_wgrad_affine(plan, L.d, self._prec(L.d), L.x.ptr, aff[0], aff[1], gy.ptr, gy.ld,
+                                    self._G(name + "/kernel"), self._G(name + "/bias"))
+        elif self._use_split(L.d):
             ops.conv2d_wgrad_split3(plan, L.d, L.x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"),
                                     self._G(name + "/bias"), bf16=self._bf16)
         else:

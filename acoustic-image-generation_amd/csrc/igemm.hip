@@ -1057,18 +1057,29 @@ static bool wgrad_halo_ok(const WgradParams& p) {
 // tiles grid-stride and keep their sums in registers: one partial slab each, then the deterministic slab reduce.
 // Waves: C = 64: 4 channel tiles x 2 column tiles; C = 32: 2 x 2 x the tile's even / odd rows (summed through LDS at the end).
 // ------------------------------------------------------------------------------------------
+// the producer's batch norm + ReLU on a staged item (after ALL of a tile's loads were issued: applied inside the load loop it
+// made every load wait for the one before it - 224x298 8->8 weight gradient 68 -> 132 us)
+__device__ __forceinline__ float4 affine_relu4(float4 v, const float4 sc, const float4 sh, const bool relu) {
+    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return v;
+}
+
 struct WgradHalo16Params {
     const float* X; int H, W, ldx;
     const float* G; int ldg;
     int tiles_x, tiles_y; long tiles;
     float* out; float* db_out; int ldo;      // slabs [gridDim.x][9 creal][ldo], [gridDim.x][ldo]
     int creal, nreal;                        // channels really there (multiples of 4; the rest of the C x 32 tile is zeros)
+    // the producer's deferred batch norm on load: x' = relu(x * a_scale[c] + a_shift[c]) for pixels INSIDE the image (the
+    // conv's zero padding applies after the affine); null = x as stored
+    const float* a_scale; const float* a_shift; int a_relu;
 };
 
 // C: channel width of the x image (64, 32, or 16 for the few-channel layers: fewer real channels are zero padded);
 // NNT: 16-column tiles of gy (2, or 1 for <= 16 output channels: the waves that would multiply padding take tile rows instead)
 template <int C, int TERMS, int NNT = 2>
-__global__ __launch_bounds__(512, C == 16 ? 2 : 1) void wgrad_halo16_kernel(const WgradHalo16Params p) {
+__global__ __launch_bounds__(512, C == 16 ? 4 : 1) void wgrad_halo16_kernel(const WgradHalo16Params p) {
     constexpr int TH = (TERMS == 1 || C == 16) ? 8 : 4, TW = 32, XH = TH + 2, XWV = TW + 2, XW = 36;
     constexpr int PITCH = C * 2;                      // bytes per pixel and plane
     constexpr int XPL = XH * XW * PITCH;              // one x plane
@@ -1105,7 +1116,13 @@ __global__ __launch_bounds__(512, C == 16 ? 2 : 1) void wgrad_halo16_kernel(cons
 
     // this thread's items of a tile: x float4 (pixel of the XH x 34 window, 4 channels), gy float4 (pixel, 4 columns)
     float4 rx[NXL], rg[NGL];
+    unsigned okm = 0;                          // which of rx[] came from inside the image (the affine applies to those only)
+    // (a thread's x items are always the same four channels: 512 is a multiple of C / 4)
+    const bool aff_ch = p.a_scale != nullptr && (tid % (C / 4)) * 4 < p.creal;
+    const float4 asc = aff_ch ? *reinterpret_cast<const float4*>(p.a_scale + (tid % (C / 4)) * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 ash = aff_ch ? *reinterpret_cast<const float4*>(p.a_shift + (tid % (C / 4)) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_tile = [&](long tile) {
+        okm = 0;
         const int tx = (int)(tile % p.tiles_x);
         const long t2 = tile / p.tiles_x;
         const int ty = (int)(t2 % p.tiles_y);
@@ -1119,8 +1136,10 @@ __global__ __launch_bounds__(512, C == 16 ? 2 : 1) void wgrad_halo16_kernel(cons
             const int row = pix / XWV, col = pix - row * XWV;
             const int iy = ty * TH + row - 1, ix = tx * TW + col - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < XH && c4 * 4 < p.creal && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            if (row < XH && c4 * 4 < p.creal && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
                 v = *reinterpret_cast<const float4*>(xi + ((long)iy * p.W + ix) * p.ldx + c4 * 4);
+                okm |= 1u << k;
+            }
             rx[k] = v;
         }
 #pragma unroll
@@ -1143,7 +1162,7 @@ __global__ __launch_bounds__(512, C == 16 ? 2 : 1) void wgrad_halo16_kernel(cons
             if (row < XH) {
                 const int off = (row * XW + col) * PITCH + (((c4 >> 1) ^ swx(col)) << 4) + 8 * (c4 & 1);
                 uint2 hi, lo;
-                split4<SplitBF16>(rx[k], hi, lo);
+                split4<SplitBF16>(p.a_scale && ((okm >> k) & 1u) ? affine_relu4(rx[k], asc, ash, p.a_relu != 0) : rx[k], hi, lo);
                 *reinterpret_cast<uint2*>(lds + off) = hi;
                 if (TERMS == 3) *reinterpret_cast<uint2*>(lds + XPL + off) = lo;
             }
@@ -1257,12 +1276,17 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
         return fail(ACIMG_EINVAL, "wgrad: C=%d ldx=%d ldg=%d ldo=%d must be multiples of 4", p.C, p.ldx, p.ldg, p.ldo);
     if (!aligned16(p.X) || !aligned16(p.G) || !aligned16(dw))
         return fail(ACIMG_EINVAL, "wgrad: operands must be 16-byte aligned");
+    if (p.a_scale && !wgrad_halo16_ok(p, split3))
+        return fail(ACIMG_EINVAL, "wgrad: an input affine is only taken by the halo form (3x3 / stride 1 / SAME, <= 32 columns, >= 65536 pixels)");
+    if (p.a_scale && (!p.a_shift || !aligned16(p.a_scale) || !aligned16(p.a_shift)))
+        return fail(ACIMG_EINVAL, "wgrad: the input affine needs scale and shift, 16-byte aligned");
     int bmo, bn;
     wgrad_tile(p.Ngemm, bmo, bn);
     if (wgrad_halo16_ok(p, split3)) {
         WgradHalo16Params q{};
         q.X = p.X; q.H = p.H; q.W = p.W; q.ldx = p.ldx; q.G = p.G; q.ldg = p.ldg; q.ldo = p.ldo;
         q.creal = p.C; q.nreal = p.Ngemm;
+        q.a_scale = p.a_scale; q.a_shift = p.a_shift; q.a_relu = p.a_relu;
         if (p.C < 32) terms = 3;                                       // few-channel layers: always the fp32-class form
         const int cpad = p.C == 64 ? 64 : (p.C > 16 ? 32 : 16);
         const int nnt = (cpad == 16 && p.Ngemm <= 16) ? 1 : 2;
@@ -1313,6 +1337,7 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
             return check_launch("wgrad_reduce");
         }
     }
+    if (p.a_scale) return fail(ACIMG_EWORKSPACE, "wgrad: workspace too small for the halo form, which the input affine needs");
     if (wgrad_halo_ok(p)) {
         WgradHaloParams q{};
         q.X = p.X; q.H = p.H; q.W = p.W; q.C = p.C; q.ldx = p.ldx;
@@ -1493,6 +1518,9 @@ struct FewParams {
     const float* bias; const float* res; int ldres;
     float* stats; int stats_ld;                  // [gridDim.x][2][stats_ld] or null
     int tiles_x, tiles_y; long tiles, per;
+    // the producer's deferred batch norm on load: x' = relu(x * a_scale[c] + a_shift[c]) for pixels INSIDE the image (the
+    // conv's zero padding applies after the affine); null = x as stored
+    const float* a_scale; const float* a_shift; int a_relu;
     // weight preparation
     const float* w; int ldw, wrows, cin, mode;
 };
@@ -1555,7 +1583,12 @@ __global__ __launch_bounds__(512, (NOUTP == 32 && MODE == 0) ? 2 : 4) void conv_
     }
 
     float4 rx[NXL];
+    unsigned okm = 0;                          // which of rx[] came from inside the image (the affine applies to those only)
+    // (a thread's items are always the same four channels: 512 is a multiple of CLOAD / 4)
+    const float4 asc = p.a_scale ? *reinterpret_cast<const float4*>(p.a_scale + (tid % (CLOAD / 4)) * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 ash = p.a_scale ? *reinterpret_cast<const float4*>(p.a_shift + (tid % (CLOAD / 4)) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_tile = [&](long tile) {
+        okm = 0;
         const int tx = (int)(tile % p.tiles_x);
         const long t2 = tile / p.tiles_x;
         const int ty = (int)(t2 % p.tiles_y);
@@ -1574,7 +1607,10 @@ __global__ __launch_bounds__(512, (NOUTP == 32 && MODE == 0) ? 2 : 4) void conv_
                 ok = ok && !((iy | ix) & 1);
                 sy >>= 1; sx >>= 1;
             }
-            if (ok) v = *reinterpret_cast<const float4*>(xi + ((long)sy * p.SW + sx) * p.ldx + c4 * 4);
+            if (ok) {
+                v = *reinterpret_cast<const float4*>(xi + ((long)sy * p.SW + sx) * p.ldx + c4 * 4);
+                okm |= 1u << k;
+            }
             rx[k] = v;
         }
     };
@@ -1587,7 +1623,7 @@ __global__ __launch_bounds__(512, (NOUTP == 32 && MODE == 0) ? 2 : 4) void conv_
             if (row < XH) {
                 const int off = (row * XW + col) * PB + c4 * 8;
                 uint2 hi, lo;
-                split4<TR>(rx[k], hi, lo);
+                split4<TR>(p.a_scale && ((okm >> k) & 1u) ? affine_relu4(rx[k], asc, ash, p.a_relu != 0) : rx[k], hi, lo);
                 *reinterpret_cast<uint2*>(xl + off) = hi;
                 *reinterpret_cast<uint2*>(xl + XPL + off) = lo;
             }
@@ -1828,10 +1864,11 @@ int acimg_conv2d_fwd(const AcimgConvDesc* d, const float* x, const float* w, con
     }
     if (few16_fwd_shape(d)) {
         // acimg_conv2d_stats_rows(d) promised one statistics row per workgroup of this kernel: no silent fallback
-        if (in_scale || in_shift || in_relu || !aligned16(x) || !aligned16(y) || (d->ldy & 3) || d->ldy < d->K ||
-            (bias && !aligned16(bias)))
-            return fail(ACIMG_EINVAL, "conv2d_fwd: few-channel MFMA shape with an input affine or unaligned operands");
+        if ((in_scale != nullptr) != (in_shift != nullptr) || (in_relu && !in_scale) || !aligned16(x) || !aligned16(y) || (d->ldy & 3) ||
+            d->ldy < d->K || (bias && !aligned16(bias)) || (in_scale && (!aligned16(in_scale) || !aligned16(in_shift))))
+            return fail(ACIMG_EINVAL, "conv2d_fwd: few-channel MFMA shape with half an input affine or unaligned operands");
         FewParams q{};
+        q.a_scale = in_scale; q.a_shift = in_shift; q.a_relu = in_relu;
         q.X = x; q.H = d->H; q.W = d->W; q.ldx = d->ldx; q.Y = y; q.ldy = d->ldy; q.nout = d->K; q.bias = bias;
         q.Hin = q.SH = d->H; q.Win = q.SW = d->W; q.dil = 1; q.pad_t = 1; q.pad_l = 1;
         q.stats = stats; q.stats_ld = d->ldw;
@@ -2237,6 +2274,9 @@ extern "C++" {
 struct ConvHaloParams {
     const float* X; int H, W, ldx;
     const char* Wimg; unsigned w_lo_off;         // 16-bit image [rows][9 CIN], hi plane; lo plane w_lo_off bytes further
+    // the producer's deferred batch norm on load: x' = relu(x * a_scale[c] + a_shift[c]) for pixels INSIDE the image (the
+    // conv's zero padding applies after the affine); null = x as stored
+    const float* a_scale; const float* a_shift; int a_relu;
     float* Y; int ldy, nout;                     // nout: channels written (0 = all NOUT; the image's further rows are zero)
     const float* bias; const float* res; int ldres; const float* mask; int ldmask;
     float* stats; int stats_ld;                  // [gridDim.x][2][stats_ld] or null
@@ -2273,7 +2313,12 @@ __global__ __launch_bounds__(512, 1) void conv_halo16_kernel(const ConvHaloParam
     }
 
     float4 rx[NXL];
+    unsigned okm = 0;                          // which of rx[] came from inside the image (the affine applies to those only)
+    // (a thread's items are always the same four channels: 512 is a multiple of CIN / 4)
+    const float4 asc = p.a_scale ? *reinterpret_cast<const float4*>(p.a_scale + (tid % (CIN / 4)) * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 ash = p.a_scale ? *reinterpret_cast<const float4*>(p.a_shift + (tid % (CIN / 4)) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_tile = [&](long tile) {
+        okm = 0;
         const int tx = (int)(tile % p.tiles_x);
         const long t2 = tile / p.tiles_x;
         const int ty = (int)(t2 % p.tiles_y);
@@ -2286,8 +2331,10 @@ __global__ __launch_bounds__(512, 1) void conv_halo16_kernel(const ConvHaloParam
             const int row = pix / XWV, col = pix - row * XWV;
             const int iy = ty * TH + row - 1, ix = tx * TW + col - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < XH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            if (row < XH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
                 v = *reinterpret_cast<const float4*>(xi + ((long)iy * p.W + ix) * p.ldx + c4 * 4);
+                okm |= 1u << k;
+            }
             rx[k] = v;
         }
     };
@@ -2300,7 +2347,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo16_kernel(const ConvHaloParam
             if (row < XH) {
                 const int off = (row * XW + col) * PITCH + c4 * 8;
                 uint2 hi, lo;
-                split4<TR>(rx[k], hi, lo);
+                split4<TR>(p.a_scale && ((okm >> k) & 1u) ? affine_relu4(rx[k], asc, ash, p.a_relu != 0) : rx[k], hi, lo);
                 *reinterpret_cast<uint2*>(xl + off) = hi;
                 if (TERMS == 3) *reinterpret_cast<uint2*>(xl + XPL + off) = lo;
             }
@@ -2694,10 +2741,12 @@ static int fwd_split_onthefly(const AcimgConvDesc* d, const float* x, const void
         return fail(ACIMG_EINVAL, "conv2d_fwd_split3: ldw<K or unaligned operands");
     if (conv_halo16_fwd_shape(d)) {
         // (acimg_conv2d_fwd_split3_stats_rows already told the caller this shape leaves CONV_HALO16_WGS rows: no fallback)
-        if (in_scale || in_shift || !aligned16(y) || (d->ldy & 3) || (d->ldx & 3) || (bias && !aligned16(bias)))
-            return fail(ACIMG_EINVAL, "conv2d_fwd_split3: the halo form of this shape takes no input affine and needs 16-byte "
-                                      "aligned y / bias and ldx, ldy multiples of 4");
+        if ((in_scale != nullptr) != (in_shift != nullptr) || (in_relu && !in_scale) || !aligned16(y) || (d->ldy & 3) || (d->ldx & 3) ||
+            (bias && !aligned16(bias)) || (in_scale && (!aligned16(in_scale) || !aligned16(in_shift))))
+            return fail(ACIMG_EINVAL, "conv2d_fwd_split3: the halo form of this shape needs scale AND shift of an input affine, "
+                                      "16-byte aligned y / bias / affine and ldx, ldy multiples of 4");
         ConvHaloParams q{};
+        q.a_scale = in_scale; q.a_shift = in_shift; q.a_relu = in_relu;
         q.X = x; q.H = d->H; q.W = d->W; q.ldx = d->ldx; q.Wimg = static_cast<const char*>(wsplit);
         q.w_lo_off = (unsigned)((size_t)d->ldw * d->R * d->S * d->C * 2);
         q.Y = y; q.ldy = d->ldy; q.bias = bias; q.stats = stats; q.stats_ld = d->ldw;
@@ -3169,6 +3218,36 @@ static int wgrad_split_onthefly(const AcimgConvDesc* d, const float* x, const fl
     p.M = d->N * d->OH * d->OW; p.KK = d->R * d->S * d->C;
     p.G = gy; p.ldg = ldgy; p.Ngemm = kp; p.Nld = kp; p.ldo = d->ldw;
     return launch_wgrad(p, dw, db, ws, ws_bytes, (hipStream_t)stream, true, terms);
+}
+
+/* precision of a conv layer's entry points: 0 = acimg_conv2d_fwd / _wgrad (fp32-class), 1 = _split3, 2 = _bf16 */
+int acimg_conv2d_affine_input_ok(const AcimgConvDesc* d, int precision) {
+    if (!d || precision < 0 || precision > 2 || check_desc(d, "conv2d_affine_input_ok")) return 0;
+    WgradParams p{};
+    p.H = d->H; p.W = d->W; p.C = d->C; p.ldx = d->ldx;
+    p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.M = d->N * d->OH * d->OW; p.KK = d->R * d->S * d->C;
+    p.Ngemm = up4(d->K); p.Nld = p.Ngemm; p.ldo = d->ldw;
+    const bool fwd = precision == 0 ? few16_fwd_shape(d) : conv_halo16_fwd_shape(d);
+    return fwd && wgrad_halo16_ok(p, precision != 0) ? 1 : 0;
+}
+
+int acimg_conv2d_wgrad_affine(const AcimgConvDesc* d, int precision, const float* x, const float* in_scale, const float* in_shift,
+                              int in_relu, const float* gy, int ldgy, float* dw, float* db, void* ws, size_t ws_bytes,
+                              void* stream) {
+    int rc = check_desc(d, "conv2d_wgrad_affine");
+    if (rc) return rc;
+    if (precision < 0 || precision > 2 || !in_scale || !in_shift)
+        return fail(ACIMG_EINVAL, "conv2d_wgrad_affine: precision 0 / 1 / 2 and both halves of the affine");
+    const int kp = up4(d->K);
+    if (kp > ldgy || kp > d->ldw) return fail(ACIMG_EINVAL, "conv2d_wgrad_affine: padded K exceeds ldgy/ldw");
+    WgradParams p{};
+    p.X = x; p.H = d->H; p.W = d->W; p.C = d->C; p.ldx = d->ldx;
+    p.OH = d->OH; p.OW = d->OW; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+    p.M = d->N * d->OH * d->OW; p.KK = d->R * d->S * d->C;
+    p.G = gy; p.ldg = ldgy; p.Ngemm = kp; p.Nld = kp; p.ldo = d->ldw;
+    p.a_scale = in_scale; p.a_shift = in_shift; p.a_relu = in_relu;
+    return launch_wgrad(p, dw, db, ws, ws_bytes, (hipStream_t)stream, precision != 0, precision == 2 ? 1 : 3);
 }
 
 }  // extern "C"

@@ -101,6 +101,9 @@ struct WgradParams {
     // optional fused bias gradient: an implicit all-ones im2col column at row KK, i.e.
     // db[n] = sum_m G[m][n]; written to db_out[blockIdx.z * ldo + n] (slab when splits > 1)
     float* db_out;
+    // x' = relu(x * a_scale[c] + a_shift[c]) on load (the producer's deferred batch norm; zero padding after the affine):
+    // honoured by the halo weight-gradient kernel only - launch_wgrad refuses it on every other path
+    const float* a_scale; const float* a_shift; int a_relu;
 };
 
 }  // namespace acimg

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ACIMG_VERSION 206
+#define ACIMG_VERSION 207
 
 #define ACIMG_OK 0
 #define ACIMG_EINVAL (-1)     /* bad descriptor / shape / alignment */
@@ -291,6 +291,20 @@ int acimg_conv2d_wgrad_split3(const AcimgConvDesc* d, const float* x, const floa
                               float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
 int acimg_conv2d_wgrad_bf16(const AcimgConvDesc* d, const float* x, const float* gy, int ldgy,
                             float* dw, float* db, void* ws, size_t ws_bytes, void* stream);
+/* A batch-norm + ReLU between two convs without a pass of its own (round 4): the consumer applies the producer's
+ * (scale, shift) and the ReLU while it stages its input tile - x' = relu(x * in_scale[c] + in_shift[c]) inside the
+ * image, zero padding after the affine - so the normalised activation is never written.  The forward entries above
+ * already carry in_scale / in_shift / in_relu; this is the weight gradient of the same layer with the same view of
+ * its input.  precision: 0 = the acimg_conv2d_fwd / _wgrad arithmetic, 1 = _split3, 2 = _bf16.  Only the halo
+ * kernels stage through registers and can do this: acimg_conv2d_affine_input_ok(d, precision) is 1 when BOTH the
+ * forward and the weight gradient of this layer take the affine (3x3 / stride 1 / SAME, <= 32 output channels, from
+ * 65536 pixels on); acimg_conv2d_wgrad_affine fails loudly on any other shape.  Workspace: acimg_conv2d_wgrad_workspace.
+ * Replaces: the read side of tf.layers.batch_normalization + tf.nn.relu between two tf.layers.conv2d
+ * (models/unet_architecture.py:55-60). */
+int acimg_conv2d_affine_input_ok(const AcimgConvDesc* d, int precision);
+int acimg_conv2d_wgrad_affine(const AcimgConvDesc* d, int precision, const float* x, const float* in_scale,
+                              const float* in_shift, int in_relu, const float* gy, int ldgy, float* dw, float* db,
+                              void* ws, size_t ws_bytes, void* stream);
 
 /* Transposed convolution, VALID (TF output = in*stride + max(kernel - stride, 0)):
  *   x : [N,H,W,C] low-res input, y : [N,OH,OW,K], w : [R][S][K][ldw>=C].

@@ -172,7 +172,7 @@ def test_conv_associator_audio_step():
     ma, md = tr.modelassociator, tr.modelac
     masks_a = {}
     for name, L in ma.layers.items():
-        masks_a[name] = (L.y.t[..., L.y.off:L.y.off + L.y.C] > 0).cpu()
+        masks_a[name] = (L.relu_output() > 0).cpu()
     free = om.step_loss_audio(pa, pd, spec, x, eps)
     flips = sum(int((free["masks_a"][k] != masks_a[k].reshape(free["masks_a"][k].shape)).sum()) for k in masks_a)
     total = sum(v.numel() for v in masks_a.values())

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
     exported = set(re.findall(r" T (acimg_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
-    assert lib.acimg_version() == 206
+    assert lib.acimg_version() == 207
 
 
 def test_host_side_queries_need_no_gpu(lib):

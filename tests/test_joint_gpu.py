@@ -30,7 +30,7 @@ def _device_masks(tr):
         mm = OrderedDict()
         if hasattr(m, "layers"):                       # conv-BN-ReLU models: every layer's output buffer
             for name, L in m.layers.items():
-                mm[name] = (L.y.t.view(L.y.N, L.y.H, L.y.W, -1)[..., L.y.off:L.y.off + L.y.C] > 0).cpu()
+                mm[name] = (L.relu_output() > 0).cpu()
             mm["dense"] = (m.dns1 > 0).cpu()
             mm["conv2d"] = (m.c2d.t > 0).cpu()
         else:                                          # the acoustic model: plain conv + ReLU

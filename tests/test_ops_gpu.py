@@ -1318,6 +1318,65 @@ def test_few_channel_mfma_conv_matches_fp64(device, case):
     close(dxbuf[..., 16:], gx.permute(0, 2, 3, 1) + res.double(), tol=3e-5, what="few-channel MFMA data gradient %s" % (case,))
 
 
+@pytest.mark.parametrize("case", [(3, 150, 160, 8, 8, 0), (3, 147, 161, 4, 8, 0), (2, 190, 181, 16, 8, 0), (4, 112, 149, 32, 32, 1),
+                                  (4, 112, 149, 32, 32, 2), (4, 113, 150, 64, 32, 1), (4, 113, 150, 64, 32, 2)])
+def test_batch_norm_affine_applied_while_staging(device, case):
+    """A batch norm + ReLU between two convs without a pass of its own (round 4, include/acimg.h `acimg_conv2d_affine_input_ok`):
+    the consumer's forward (few-channel MFMA kernel / halo kernel) and its weight gradient (halo kernel) read the producer's
+    RAW output and apply relu(x * scale + shift) while they stage their tiles - zero padding after the affine.  Against the
+    same entry points fed the materialised tensor; precision 0 / 1 / 2 = fp32-class / split3 / bf16 entries."""
+    from acimg import _lib, ops
+
+    N, H, W, Cc, K, prec = case
+    g = torch.Generator().manual_seed(77 + N + Cc + prec)
+    raw = torch.randn(N, H, W, Cc, generator=g)
+    scale = torch.rand(Cc, generator=g) + 0.5
+    shift = torch.randn(Cc, generator=g) * 0.5           # (a shift: the padding ring must stay 0, not relu(shift))
+    w = torch.randn(3, 3, Cc, K, generator=g) * (2.0 / (9 * Cc)) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1
+    gy = torch.randn(N, H, W, K, generator=g) * 1e-3
+    d = ops.conv_desc(N, H, W, Cc, K, 3, 3, 1, "SAME")
+    assert ops.conv2d_affine_input_ok(d, prec)
+    assert not ops.conv2d_affine_input_ok(ops.conv_desc(2, 60, 60, Cc, K, 3, 3, 1, "SAME"), prec)        # below the size rule
+    assert not ops.conv2d_affine_input_ok(ops.conv_desc(N, H, W, Cc, K, 3, 3, 2, "SAME"), prec)          # strided
+    plan = ops.Plan(device, eager=True)
+    rawd, scd, shd, wd, bd, gyd = (t.to(device) for t in (raw, scale, shift, w, b, gy))
+    xmat = torch.relu(rawd * scd + shd)
+    bf16 = prec == 2
+    rows = ops.conv2d_stats_rows(d) if prec == 0 else ops.conv2d_fwd_split3_stats_rows(d)
+    if prec:
+        wimg = torch.zeros(ops.conv2d_split3_weight_bytes(d), dtype=torch.uint8, device=device)
+        ops.conv2d_split3_prepare(plan, d, wd, wimg, bf16=bf16)
+    outs = []
+    for aff in (False, True):
+        y = torch.zeros(N, H, W, K, device=device)
+        st = torch.zeros(rows, 2, K, device=device)
+        dw = torch.zeros(3, 3, Cc, K, device=device)
+        db = torch.zeros(K, device=device)
+        x = rawd if aff else xmat
+        kw = dict(in_scale=scd, in_shift=shd, in_relu=1) if aff else {}
+        if prec:
+            ops.conv2d_fwd_split3(plan, d, x, wimg, y, stats=st, bias=bd, bf16=bf16, **kw)
+        else:
+            ops.conv2d_fwd(plan, d, x, wd, bd, y, stats=st, **kw)
+        if aff:
+            ops.conv2d_wgrad_affine(plan, d, prec, x, scd, shd, gyd, K, dw, db)
+        elif prec:
+            ops.conv2d_wgrad_split3(plan, d, x, gyd, K, dw, db, bf16=bf16)
+        else:
+            ops.conv2d_wgrad(plan, d, x, gyd, K, dw, db)
+        torch.cuda.synchronize()
+        outs.append((y.cpu(), st.sum(0).cpu(), dw.cpu(), db.cpu()))
+    tol = 4e-3 if bf16 else 2e-5       # bf16: an fma-vs-two-roundings difference of one ulp flips a bf16 rounding of the operand
+    for a, bb, what in zip(outs[0], outs[1], ("forward", "statistics", "weight gradient", "bias gradient")):
+        close(bb, a, tol=tol if what != "statistics" else max(tol, 2e-4), what="affine on load, %s %s" % (what, case))
+    with pytest.raises(_lib.AcimgError):      # a shape off the halo kernels has no way to apply it: refused, not ignored
+        d2 = ops.conv_desc(2, 36, 48, 128, 128, 3, 3, 1, "SAME")
+        ops.conv2d_wgrad_affine(plan, d2, 1, torch.zeros(2, 36, 48, 128, device=device), torch.ones(128, device=device),
+                                torch.zeros(128, device=device), torch.zeros(2, 36, 48, 128, device=device), 128,
+                                torch.zeros(3, 3, 128, 128, device=device), None)
+
+
 @pytest.mark.parametrize("case", [(134400, 64, 256), (34048, 256, 1024), (20011, 128, 512), (8512, 512, 2048), (37, 64, 100),
                                   (4099, 128, 136), (50, 256, 256)])
 def test_gram_statistics_match_fp64(device, case):

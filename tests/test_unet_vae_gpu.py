@@ -49,7 +49,7 @@ def test_unet_vae_train_step(model, precision):
     # oracle itself show it); forward values are compared independently of that below.
     masks = {}
     for name, L in m.layers.items():
-        masks[name] = (L.y.t[..., L.y.off:L.y.off + L.y.C] > 0).cpu()
+        masks[name] = (L.relu_output() > 0).cpu()
     masks["dense"] = (m.dns1 > 0).cpu()
     masks["conv2d"] = (m.c2d.t > 0).cpu()
     free = orc.train_step(x, eps, apply=False)
@@ -214,7 +214,7 @@ def test_unet_vae_bf16_train_step():
     m = tr.model
     nsplit = sum(1 for L in m.layers.values() if m._use_split(L.d))
     assert nsplit >= 7, nsplit                       # the bf16 kernels really carry the model's large convs
-    masks = {name: (L.y.t[..., L.y.off:L.y.off + L.y.C] > 0).cpu() for name, L in m.layers.items()}
+    masks = {name: (L.relu_output() > 0).cpu() for name, L in m.layers.items()}
     masks["dense"] = (m.dns1 > 0).cpu()
     masks["conv2d"] = (m.c2d.t > 0).cpu()
     free = orc.train_step(x, eps, apply=False)
