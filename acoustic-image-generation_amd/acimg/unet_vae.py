@@ -57,7 +57,7 @@ class UNetVAE(object):
     HEAD_NAMES = ("mean", "variance")
     ENCODER_ONLY = False
 
-    def __init__(self, input_shape=None, precision="split"):
+    def __init__(self, input_shape=None, precision="split", defer_bn=True):
         """precision: "split" = layers with >= 32 channels on both sides run on the split-MFMA kernels (forward
         f16x3, gradients bf16x3: fp32-class results at 5x the fp32-MFMA rate), "f32" = exact-f32 MFMA everywhere,
         "bf16" = BASELINE configs[1]: the same layers with both GEMM operands ROUNDED to bf16 (one MFMA per product,
@@ -68,7 +68,7 @@ class UNetVAE(object):
         # a conv-BN-ReLU layer whose only consumer is the next 3x3 conv (conv_1 of a block, a "pool" conv) skips its normalise +
         # ReLU pass when that conv and its weight gradient apply the affine while they stage their tiles
         # (ops.conv2d_affine_input_ok: the halo kernels); False = every layer materialises its output
-        self.defer_bn = True
+        self.defer_bn = bool(defer_bn)
         self.scope = self.SCOPE
         self.height, self.width, self.channels = input_shape
         assert self.channels == self.CIN
@@ -523,8 +523,8 @@ class UNet(UNetVAE):
            ("4", 64, (2, 3), "VALID"), ("5", 128, None, None)]
     DEC = [("6", 64, (2, 3), "4"), ("7", 32, (2, 2), "3"), ("8", 32, (2, 3), "2"), ("9", 8, (2, 2), "1")]
 
-    def __init__(self, input_shape=None, precision="split"):
-        super(UNet, self).__init__(input_shape or [224, 298, 3], precision)
+    def __init__(self, input_shape=None, precision="split", defer_bn=True):
+        super(UNet, self).__init__(input_shape or [224, 298, 3], precision, defer_bn)
 
 
 class UNetSound(UNetVAE):
@@ -534,8 +534,8 @@ class UNetSound(UNetVAE):
            ("4", 64, (3, 3), "SAME"), ("5", 128, None, None)]
     DEC = [("6", 64, (2, 2), "4"), ("7", 32, (2, 2), "3"), ("8", 8, (3, 2), "2"), ("9", 8, (3, 3), "1")]
 
-    def __init__(self, input_shape=None, precision="split"):
-        super(UNetSound, self).__init__(input_shape or [99, 257, 1], precision)
+    def __init__(self, input_shape=None, precision="split", defer_bn=True):
+        super(UNetSound, self).__init__(input_shape or [99, 257, 1], precision, defer_bn)
 
 
 class AssociatorAudio(UNetVAE):
@@ -553,8 +553,8 @@ class AssociatorAudio(UNetVAE):
     ENCODER_ONLY = True
     IMAGE_INPUT = True
 
-    def __init__(self, input_shape=None, precision="split"):
-        super(AssociatorAudio, self).__init__(input_shape or [193, 257, 1], precision)
+    def __init__(self, input_shape=None, precision="split", defer_bn=True):
+        super(AssociatorAudio, self).__init__(input_shape or [193, 257, 1], precision, defer_bn)
 
     def _build_model(self, inputs, session=None, training=True):
         """inputs: device buffer [N,193,257,1] (the STFT-magnitude spectrogram)"""

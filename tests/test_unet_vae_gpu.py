@@ -253,3 +253,41 @@ def test_unet_vae_bf16_train_step():
     # it is bf16 arithmetic: the fp32-class oracle is NOT matched to 1e-3
     free32 = ouv.Oracle(model, learning_rate=1e-3, dtype=torch.float64, params=params).train_step(x, eps, apply=False)
     assert rel(out, free32["fw"]["output"]) > 1e-3
+
+
+def test_deferred_batch_norm_equals_the_materialised_one():
+    """`UNet(defer_bn=True)` (default, round 4): conv_1 / pool outputs read only by the next 3x3 conv are never normalised in
+    memory - the consumer's forward and weight gradient apply relu(x * scale + shift) while staging - against
+    `defer_bn=False` (every layer runs its normalise + ReLU pass) on the same parameters and batch: which layers deferred,
+    losses, output, every gradient.  Batch 4: the two full-resolution stages are over the halo kernels' size rule."""
+    from acimg.session import Session
+    from acimg.trainer_vae import TrainerVAE
+    from acimg import unet_vae
+    from oracle import unet_vae as ouv
+
+    dev = torch.device("cuda:0")
+    N = 4
+    params = ouv.init_params("UNet", seed=9, dtype=torch.float64, bias_std=0.05, bn_jitter=0.1)
+    x, eps = ouv.synthetic_batch("UNet", N, seed=13, dtype=torch.float64)
+    res = []
+    for defer in (False, True):
+        sess = Session(dev)
+        tr = TrainerVAE(unet_vae.UNet(precision="split", defer_bn=defer), learning_rate=1e-3, session=sess)
+        tr._build_functions(batch_size=N)
+        tr.model.initialize(state={k: v.float() for k, v in params.items()})
+        r = tr.train_step(x.float().to(dev), eps.float().to(dev), apply=False)
+        torch.cuda.synchronize()
+        m = tr.model
+        deferred = sorted(n for n, L in m.layers.items() if L.deferred)
+        res.append((r, m.output[..., :m.COUT].clone(), {k: v.clone() for k, v in sess.store.grad_dict().items()}, deferred,
+                    {n: L.relu_output().clone() for n, L in m.layers.items()}))
+    (r0, o0, g0, d0, y0), (r1, o1, g1, d1, y1) = res
+    assert d0 == [] and d1 == ["layer1/conv_1", "layer1/pool_2", "layer2/conv_1", "layer8/conv_1", "layer9/conv_1"], d1
+    for k in ("mse", "huber", "latent", "reg", "loss"):
+        assert abs(r0[k] - r1[k]) <= 1e-5 * abs(r0[k]) + 1e-9, (k, r0[k], r1[k])
+    assert rel(o1, o0) < 1e-5
+    for n in y0:
+        assert rel(y1[n], y0[n]) < 1e-5, n
+    worst = max((rel(g1[k], g0[k]), k) for k in g0)
+    print("deferred vs materialised batch norm: worst gradient %s %.2e" % (worst[1], worst[0]))
+    assert worst[0] < 2e-4, worst
