@@ -58,6 +58,16 @@ def test_host_side_queries_need_no_gpu(lib):
     assert ops.conv2d_stats_rows(ops.conv_desc(32, 224, 298, 8, 8, 3, 3, 2, "SAME")) == 32 * 112 * 149 // 256
     assert ops.conv2d_stats_rows(ops.conv_desc(32, 224, 298, 8, 8, 3, 3, 1, "SAME", act=1)) == 32 * 224 * 298 // 256
     assert ops.conv2d_stats_rows(ops.conv_desc(2, 100, 100, 8, 8, 3, 3, 1, "SAME")) != 512
+    # which layers read a producer's raw output through its batch norm (forward AND weight gradient stage through registers):
+    # precision 0 = fp32-class entries (few channels), 1 = split3, 2 = bf16 (32 / 64 channels in, 32 out)
+    assert ops.conv2d_affine_input_ok(ops.conv_desc(32, 224, 298, 8, 8, 3, 3, 1, "SAME"), 0)
+    assert ops.conv2d_affine_input_ok(ops.conv_desc(32, 112, 149, 8, 32, 3, 3, 1, "SAME"), 0)
+    assert ops.conv2d_affine_input_ok(ops.conv_desc(32, 112, 149, 32, 32, 3, 3, 1, "SAME"), 1)
+    assert ops.conv2d_affine_input_ok(ops.conv_desc(32, 112, 149, 64, 32, 3, 3, 1, "SAME"), 2)
+    assert not ops.conv2d_affine_input_ok(ops.conv_desc(32, 112, 149, 32, 32, 3, 3, 1, "SAME"), 0)     # 32 channels: not on the fp32 entries
+    assert not ops.conv2d_affine_input_ok(ops.conv_desc(32, 112, 149, 32, 64, 3, 3, 1, "SAME"), 1)     # 64 outputs: no halo weight gradient
+    assert not ops.conv2d_affine_input_ok(ops.conv_desc(32, 224, 298, 8, 8, 3, 3, 2, "SAME"), 0)       # strided
+    assert not ops.conv2d_affine_input_ok(ops.conv_desc(32, 28, 37, 64, 64, 3, 3, 1, "SAME"), 1)       # below the size rule
 
 
 def test_tf_padding_geometry():
