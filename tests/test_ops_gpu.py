@@ -960,23 +960,44 @@ def test_splitk_handoff_equals_reduce_launch(device):
 
 
 def test_deconv_dgrad_few_channels_direct(device):
-    """unet_architecture.py upsample_9 (32 -> 8, 2x2 / 2) at a size that takes the direct few-channel kernel: the data
-    gradient of the transposed conv is a strided conv of gy with the [kh][kw][out][in] kernel read as HWIO"""
+    """unet_architecture.py upsample_9 (32 -> 8, 2x2 / 2) at a size that takes the pointwise MFMA kernel (round 4,
+    patch2_32x8_kernel: one 32 x 32 product per input pixel, operands loaded from global memory in MFMA layout): forward with
+    bias into a wider pixel stride, data gradient with and without a ReLU mask and from a wider gy stride; f16x3 forward,
+    bf16x3 gradient; two runs, the same bits"""
     from acimg import ops
 
     N, H, W, Cc, K, R, S, s = 5, 112, 149, 32, 8, 2, 2, 2
     g = torch.Generator().manual_seed(78)
     x = rnd(g, N, H, W, Cc).requires_grad_(True)
     w = (rnd(g, R, S, K, Cc) * 0.1).requires_grad_(True)
-    y = F.conv_transpose2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), None, stride=s).permute(0, 2, 3, 1)
+    b = rnd(g, K)
+    y = F.conv_transpose2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, stride=s).permute(0, 2, 3, 1)
     gy = rnd(g, *y.shape)
     y.backward(gy)
-    d = ops.deconv_desc(N, H, W, Cc, K, R, S, s)
+    maskt = rnd(g, N, H, W, Cc)
+    d = ops.deconv_desc(N, H, W, Cc, K, R, S, s, ldy=2 * K)
     plan = ops.Plan(device, eager=True)
-    dx = torch.empty(N, H, W, Cc, device=device)
-    ops.deconv_dgrad(plan, d, dev(gy, device), K, dev(w.detach(), device), dx)
-    torch.cuda.synchronize()
-    close(dx, x.grad, what="deconv dgrad (direct)")
+    wd, xd, bd = dev(w.detach(), device), dev(x.detach(), device), dev(b, device)
+    gywide = torch.zeros(N, 2 * H, 2 * W, 2 * K, dtype=torch.float64)
+    gywide[..., :K] = gy
+    gyd, md = dev(gywide, device), dev(maskt, device)
+    outs = []
+    for _ in range(2):
+        ybuf = torch.zeros(N, 2 * H, 2 * W, 2 * K, device=device)
+        ops.deconv_fwd(plan, d, xd, wd, bd, ops.Ptr(ybuf, K))
+        dx = torch.empty(N, H, W, Cc, device=device)
+        ops.deconv_dgrad(plan, d, gyd, 2 * K, wd, dx)
+        dxm = torch.empty(N, H, W, Cc, device=device)
+        ops.deconv_dgrad(plan, d, gyd, 2 * K, wd, dxm, md, Cc)
+        torch.cuda.synchronize()
+        outs.append((ybuf.cpu(), dx.cpu(), dxm.cpu()))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+    ybuf, dx, dxm = outs[0]
+    close(ybuf[..., K:], y, tol=2e-6, what="deconv fwd (pointwise MFMA)")
+    assert float(ybuf[..., :K].abs().max()) == 0.0
+    close(dx, x.grad, tol=3e-5, what="deconv dgrad (pointwise MFMA)")
+    close(dxm, x.grad * (maskt > 0), tol=3e-5, what="deconv dgrad with mask (pointwise MFMA)")
 
 
 @pytest.mark.parametrize("case", [(32, 28, 38, 256, 1024, 1, 1, 1, "SAME"),     # 2128 tiles of 8 K steps: 4.16 rounds
