@@ -1861,6 +1861,115 @@ __global__ __launch_bounds__(256) void patch2_32x8_kernel(const Patch2Params p) 
     }
 }
 
+// Weight gradient of the same layer: dW[(tap, k)][c] = sum over input pixels of gy[n][2i + r][2j + s][k] x[n][i][j][c], a
+// 32 x 32 matrix reduced over all pixels.  The pixels are the MFMA's K axis here, so a lane's 8 k-values are the SAME
+// element of 8 consecutive pixels: 4-byte loads (16 lanes cover 64 contiguous bytes of a pixel, the texture addresser
+// coalesces them), bf16 hi / lo on the way, 12 MFMAs per 32 pixels, the 32 x 32 tile in 16 accumulators per wave; the
+// workgroup's sixteen waves are added through LDS in wave order into one slab per workgroup (slab_reduce_wide_kernel adds
+// those in slab order: deterministic).  No LDS staging, no transposing reads.  136 MB in 127 us before (gather GEMM).
+struct Patch2WgradParams {
+    const float* X; int ldx;       // x [N][H][W][32]
+    const float* G; int ldg;       // gy [N][2H][2W][8]
+    float* out; int ldo;           // slabs [gridDim.x][32][ldo]
+    float* db_part;                // [gridDim.x][8] partial bias gradients (sum of gy per channel) or null
+    int H, W; long pixels;
+};
+
+__global__ __launch_bounds__(1024) void patch2_wgrad_32x8_kernel(const Patch2WgradParams p) {
+    typedef SplitBF16 TR;
+    typedef TR::V8 V8;
+    typedef TR::T T;
+    constexpr int NW = 16;             // waves per workgroup: one workgroup per CU, few slabs for the reduce launch to walk
+    __shared__ float red[NW][32][33];
+    __shared__ float redb[NW][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, li = lane & 15, g = lane >> 4;
+    float sdb = 0.f;               // this lane's share of the bias gradient: every gy value it loads has channel li & 7
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // row m = 16 mt + li of gy' is (tap, k) = (2 mt + (li >> 3), li & 7): its offset from the pixel's top-left output position
+    long offa[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) offa[mt] = ((long)mt * 2 * p.W + (li >> 3)) * p.ldg + (li & 7);
+    const long blocks = (p.pixels + 31) >> 5;
+    const long nwaves = (long)gridDim.x * NW;
+    for (long blk = (long)blockIdx.x * NW + wid; blk < blocks; blk += nwaves) {
+        // this lane's eight pixels: blk * 32 + 8 g + t
+        const long pix0 = blk * 32 + 8 * g;
+        long pc = pix0 < p.pixels ? pix0 : p.pixels - 1;
+        int j = (int)(pc % p.W);
+        long t_ = pc / p.W;
+        int i = (int)(t_ % p.H);
+        long img = t_ / p.H;
+        float av[2][8], bvv[2][8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const bool live = pix0 + t < p.pixels;
+            const float* gb = p.G + ((img * 2 * p.H + 2 * i) * (2L * p.W) + 2 * j) * p.ldg;
+            const float* xb = p.X + ((img * p.H + i) * (long)p.W + j) * p.ldx;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) av[mt][t] = live ? gb[offa[mt]] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bvv[nt][t] = live ? xb[16 * nt + li] : 0.f;
+            if (live && pix0 + t + 1 < p.pixels) {       // the next pixel, by carry (no division)
+                if (++j == p.W) {
+                    j = 0;
+                    if (++i == p.H) { i = 0; ++img; }
+                }
+            }
+        }
+        V8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                sdb += av[q][t];
+                const T h = (T)av[q][t];
+                ah[q][t] = h;
+                al[q][t] = (T)(av[q][t] - (float)h);
+                const T hb = (T)bvv[q][t];
+                bh[q][t] = hb;
+                bl[q][t] = (T)(bvv[q][t] - (float)hb);
+            }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[mt][nt] = TR::mfma(al[mt], bh[nt], acc[mt][nt]);
+                acc[mt][nt] = TR::mfma(ah[mt], bl[nt], acc[mt][nt]);
+                acc[mt][nt] = TR::mfma(ah[mt], bh[nt], acc[mt][nt]);
+            }
+    }
+    // lane (li, g) of acc[mt][nt] holds rows 16 mt + 4 g .. + 3, column 16 nt + li
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wid][16 * mt + 4 * g + r][16 * nt + li] = acc[mt][nt][r];
+    redb[wid][lane] = sdb;
+    __syncthreads();
+    if (p.db_part && threadIdx.x < 8) {          // channel k: lanes k and k + 8 of every 16-lane row, every wave, in a fixed order
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) t += redb[w][16 * gg + threadIdx.x] + redb[w][16 * gg + 8 + threadIdx.x];
+        p.db_part[(long)blockIdx.x * 8 + threadIdx.x] = t;
+    }
+    float* slab = p.out + (long)blockIdx.x * 32 * p.ldo;
+    {
+        const int row = threadIdx.x >> 5, col = threadIdx.x & 31;      // 1024 threads = the 32 x 32 tile, waves added in order
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w][row][col];
+        slab[row * p.ldo + col] = t;
+    }
+}
+static constexpr int PATCH2_WGRAD_WGS = 256;
+
 static bool patch2_shape(const AcimgConvDesc* d) {
     return d->R == 2 && d->S == 2 && d->stride == 2 && d->C == 32 && d->K == 8 && d->OH == 2 * d->H && d->OW == 2 * d->W &&
            (long)d->N * d->H * d->W >= 65536 && g_cfg.wgrad_halo;
@@ -2232,6 +2341,10 @@ size_t acimg_deconv_workspace(const AcimgConvDesc* d) {
     size_t c = wgrad_ws_bytes(d->N * d->H * d->W, d->R * d->S * up4(d->K), d->C, d->ldw) + colsum_ws_bytes(up4(d->K));
     size_t m = a > b ? a : b;
     m = m > c ? m : c;
+    if (patch2_shape(d)) {                      // weight gradient of the pointwise form: one 32 x ldw slab per workgroup
+        const size_t pw = (size_t)PATCH2_WGRAD_WGS * (32 * d->ldw + 8) * sizeof(float);
+        m = m > pw ? m : pw;
+    }
     if (up4(d->K) <= 16 && d->C <= 32) {        // data gradient on the direct few-channel kernel
         const size_t dd = direct_ws_bytes(d->R, d->S, up4(d->K), (d->C + 7) & ~7);
         m = m > dd ? m : dd;
@@ -2354,6 +2467,27 @@ int acimg_deconv_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, 
     const int ca = up4(d->K);
     if (ca > ldgy || (ldgy & 3) || ca != d->K) return fail(ACIMG_EINVAL, "deconv_wgrad: K must be a multiple of 4 and <= ldgy");
     // dW[(r,s,k)][c] = sum_{n,h,w} gy[n,h*stride+r,w*stride+s,k] * x[n,h,w,c]
+    if (patch2_shape(d) && aligned16(dw) && (d->ldw & 3) == 0 && ws && aligned16(ws) &&
+        ws_bytes >= (size_t)PATCH2_WGRAD_WGS * (32 * d->ldw + 8) * sizeof(float) && (!db || aligned16(db))) {
+        Patch2WgradParams q{};
+        q.X = x; q.ldx = d->ldx; q.G = gy; q.ldg = ldgy; q.out = static_cast<float*>(ws); q.ldo = d->ldw;
+        q.db_part = db ? q.out + (size_t)PATCH2_WGRAD_WGS * 32 * d->ldw : nullptr;
+        q.H = d->H; q.W = d->W; q.pixels = (long)d->N * d->H * d->W;
+        hipLaunchKernelGGL(patch2_wgrad_32x8_kernel, dim3(PATCH2_WGRAD_WGS), dim3(1024), 0, (hipStream_t)stream, q);
+        rc = check_launch("patch2_wgrad");
+        if (rc) return rc;
+        hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(cdiv(32 * 32, 32)), dim3(256), 0, (hipStream_t)stream, q.out,
+                           PATCH2_WGRAD_WGS, 32L, 32, d->ldw, dw, cdiv(32 * 32, 32), nullptr, nullptr);
+        rc = check_launch("patch2_wgrad reduce");
+        if (rc) return rc;
+        // the transposed conv adds its bias at every output pixel, and every output pixel belongs to exactly one patch: the
+        // bias gradient is the sum of all the gy values the kernel has just read
+        if (db) {
+            hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, q.db_part, PATCH2_WGRAD_WGS, 8, db);
+            rc = check_launch("patch2_wgrad bias");
+        }
+        return rc;
+    }
     WgradParams p{};
     p.X = gy; p.H = d->OH; p.W = d->OW; p.C = ca; p.ldx = ldgy;
     p.OH = d->H; p.OW = d->W; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad_t = 0; p.pad_l = 0;

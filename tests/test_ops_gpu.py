@@ -962,8 +962,9 @@ def test_splitk_handoff_equals_reduce_launch(device):
 def test_deconv_dgrad_few_channels_direct(device):
     """unet_architecture.py upsample_9 (32 -> 8, 2x2 / 2) at a size that takes the pointwise MFMA kernel (round 4,
     patch2_32x8_kernel: one 32 x 32 product per input pixel, operands loaded from global memory in MFMA layout): forward with
-    bias into a wider pixel stride, data gradient with and without a ReLU mask and from a wider gy stride; f16x3 forward,
-    bf16x3 gradient; two runs, the same bits"""
+    bias into a wider pixel stride, data gradient with and without a ReLU mask and from a wider gy stride, weight gradient
+    (patch2_wgrad_32x8_kernel: the pixels are the MFMA's K axis, one slab per workgroup) and bias gradient; f16x3 forward,
+    bf16x3 gradients; two runs, the same bits"""
     from acimg import ops
 
     N, H, W, Cc, K, R, S, s = 5, 112, 149, 32, 8, 2, 2, 2
@@ -989,11 +990,16 @@ def test_deconv_dgrad_few_channels_direct(device):
         ops.deconv_dgrad(plan, d, gyd, 2 * K, wd, dx)
         dxm = torch.empty(N, H, W, Cc, device=device)
         ops.deconv_dgrad(plan, d, gyd, 2 * K, wd, dxm, md, Cc)
+        dw = torch.empty(R, S, K, Cc, device=device)
+        db = torch.empty(K, device=device)
+        ops.deconv_wgrad(plan, d, xd, gyd, 2 * K, dw, db)
         torch.cuda.synchronize()
-        outs.append((ybuf.cpu(), dx.cpu(), dxm.cpu()))
+        outs.append((ybuf.cpu(), dx.cpu(), dxm.cpu(), dw.cpu(), db.cpu()))
     for a_, b_ in zip(outs[0], outs[1]):
         assert torch.equal(a_, b_)
-    ybuf, dx, dxm = outs[0]
+    ybuf, dx, dxm, dw, db = outs[0]
+    close(dw, w.grad, tol=2e-5, what="deconv wgrad (pointwise MFMA, pixels along K)")
+    close(db, gy.sum((0, 1, 2)), tol=2e-5, what="deconv bias gradient")
     close(ybuf[..., K:], y, tol=2e-6, what="deconv fwd (pointwise MFMA)")
     assert float(ybuf[..., :K].abs().max()) == 0.0
     close(dx, x.grad, tol=3e-5, what="deconv dgrad (pointwise MFMA)")
