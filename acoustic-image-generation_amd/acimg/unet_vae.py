@@ -79,6 +79,16 @@ class UNetVAE(object):
         return (self.precision in ("split", "bf16") and d.stride == 1 and d.C % 32 == 0 and d.K % 32 == 0 and
                 d.N * d.OH * d.OW >= 16384)
 
+    def _begin_prepares(self, plan):
+        """the kernels change every step: TWO launches at the head of the forward plan re-split them all (16 jobs each at most:
+        the forward images, and - added while the backward is recorded - the flipped / transposed data-gradient images)
+        instead of one ~5 us launch in front of every conv"""
+        self._prep_fwd = self._prep_bwd = None
+        if self.precision in ("split", "bf16"):
+            self._prep_fwd, self._prep_bwd = ops.PrepareJobs(), ops.PrepareJobs()
+            ops.conv2d_split3_prepare_multi(plan, self._prep_fwd)
+            ops.conv2d_split3_prepare_multi(plan, self._prep_bwd)
+
     def _prec(self, d):
         """precision code of a layer's entry points (include/acimg.h): 0 fp32-class, 1 split3, 2 bf16"""
         return (2 if self._bf16 else 1) if self._use_split(d) else 0
@@ -249,6 +259,7 @@ class UNetVAE(object):
 
         self.layers = OrderedDict()
         self.plan_fwd = sess.new_plan()
+        self._begin_prepares(self.plan_fwd)
         self._record_forward(self.plan_fwd, sizes)
 
         Zn = self.Z
@@ -281,7 +292,11 @@ class UNetVAE(object):
             L.rows = ops.conv2d_fwd_split3_stats_rows(L.d)
             L.stats = z(L.rows, 2, kp)
             ws = self._wsplit(name, ops.conv2d_split3_weight_bytes(L.d), "fwd")
-            ops.conv2d_split3_prepare(plan, L.d, self._P(name + "/kernel"), ws, bf16=self._bf16)     # the kernel changes every step
+            jobs = getattr(self, "_prep_fwd", None)
+            if jobs is not None and len(jobs.jobs) < 16:
+                jobs.add(L.d, self._P(name + "/kernel"), ws, 2 if self._bf16 else 0)
+            else:
+                ops.conv2d_split3_prepare(plan, L.d, self._P(name + "/kernel"), ws, bf16=self._bf16)
             ops.conv2d_fwd_split3(plan, L.d, x.ptr, ws, L.raw.ptr, in_scale=in_scale, in_shift=in_shift,
                                   in_relu=1 if aff is not None else 0, stats=L.stats if self.training else None,
                                   bias=self._P(name + "/bias"), bf16=self._bf16)
@@ -426,7 +441,11 @@ class UNetVAE(object):
             ops.conv2d_wgrad(plan, L.d, L.x.ptr, gy.ptr, gy.ld, self._G(name + "/kernel"), self._G(name + "/bias"))
         if dx is not None and self._use_split(L.d):
             wt = self._wsplit(name, ops.conv2d_split3_dgrad_weight_bytes(L.d), "dgrad")
-            ops.conv2d_split3_prepare_dgrad(plan, L.d, self._P(name + "/kernel"), wt)
+            jobs = getattr(self, "_prep_bwd", None)
+            if jobs is not None and len(jobs.jobs) < 16:
+                jobs.add(L.d, self._P(name + "/kernel"), wt, 1)
+            else:
+                ops.conv2d_split3_prepare_dgrad(plan, L.d, self._P(name + "/kernel"), wt)
             ops.conv2d_dgrad_split3(plan, L.d, gy.ptr, gy.ld, wt, dx.ptr,
                                     res.ptr if res is not None else None, res.ld if res is not None else 0,
                                     None, 0, lddx=dx.ld, bf16=self._bf16)
@@ -577,6 +596,7 @@ class AssociatorAudio(UNetVAE):
         self.cat = {}
         self.layers = OrderedDict()
         p = sess.new_plan()
+        self._begin_prepares(p)
         self._record_encoder(p, sizes)
         Zn = self.Z
         self.ext = z(N, 2 * Zn)             # [mean | std = softplus(raw)]
