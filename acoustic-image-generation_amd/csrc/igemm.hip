@@ -254,13 +254,17 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int
     out[row * ld + col] = v;
 }
 
-// the same for many slabs (few-channel weight gradients use up to 2048 pixel splits): 32 outputs per workgroup,
-// 8 lane groups walk the slabs with four loads in flight each, fixed-order combine -> deterministic
+// the same for many slabs (few-channel weight gradients use up to 2048 pixel splits): OUTS outputs per workgroup, 256 / OUTS
+// lane groups walk the slabs with four loads in flight each, fixed-order combine -> deterministic.  OUTS = 32 for large
+// gradients; 8 when there are few outputs (a 9 x 8 x 8 kernel is 576 numbers: 18 workgroups of 32 outputs each walked 512
+// slabs in 16 dependent rounds - 8 to 20 us of pure latency per launch; 72 workgroups with 32 lane groups need 4 rounds)
+template <int OUTS>
 __global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float* slab, int splits, long rows,
                                                                int ncols, int ld, float* out, int nb1,
                                                                const float* slab2, float* out2) {
-    __shared__ float red[8][32];
-    const int ol = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    constexpr int NG = 256 / OUTS;
+    __shared__ float red[NG][OUTS];
+    const int ol = threadIdx.x % OUTS, rg = threadIdx.x / OUTS;
     long bid = blockIdx.x;
     if (bid >= nb1) {                  // second job: the one-row bias gradient
         bid -= nb1;
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float* slab
         out = out2;
         rows = 1;
     }
-    const long idx = bid * 32 + ol;
+    const long idx = bid * OUTS + ol;
     const bool ok = idx < rows * ncols;
     const long row = ok ? idx / ncols : 0;
     const int col = ok ? (int)(idx - row * ncols) : 0;
@@ -277,21 +281,35 @@ __global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float* slab
     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     if (ok) {
         int z = rg;
-        for (; z + 24 < splits; z += 32) {
+        for (; z + 3 * NG < splits; z += 4 * NG) {
             v0 += src[(long)z * zs];
-            v1 += src[(long)(z + 8) * zs];
-            v2 += src[(long)(z + 16) * zs];
-            v3 += src[(long)(z + 24) * zs];
+            v1 += src[(long)(z + NG) * zs];
+            v2 += src[(long)(z + 2 * NG) * zs];
+            v3 += src[(long)(z + 3 * NG) * zs];
         }
-        for (; z < splits; z += 8) v0 += src[(long)z * zs];
+        for (; z < splits; z += NG) v0 += src[(long)z * zs];
     }
     red[rg][ol] = (v0 + v1) + (v2 + v3);
     __syncthreads();
     if (rg == 0 && ok) {
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t += red[i][ol];
+        for (int i = 0; i < NG; ++i) t += red[i][ol];
         out[row * ld + col] = t;
+    }
+}
+// slab [splits][rows][ld] -> out [rows][ld] (ncols of them); optionally slab2 [splits][ld] -> out2 [ncols] (bias gradient)
+static void launch_slab_reduce_wide(const float* slab, int splits, long rows, int ncols, int ld, float* out, const float* slab2,
+                                    float* out2, hipStream_t st) {
+    const long total = rows * ncols;
+    if (total <= 4096) {
+        const int nb1 = (int)cdiv(total, 8), nb2 = out2 ? cdiv(ncols, 8) : 0;
+        hipLaunchKernelGGL(slab_reduce_wide_kernel<8>, dim3(nb1 + nb2), dim3(256), 0, st, slab, splits, rows, ncols, ld, out, nb1,
+                           slab2, out2);
+    } else {
+        const int nb1 = (int)cdiv(total, 32), nb2 = out2 ? cdiv(ncols, 32) : 0;
+        hipLaunchKernelGGL(slab_reduce_wide_kernel<32>, dim3(nb1 + nb2), dim3(256), 0, st, slab, splits, rows, ncols, ld, out, nb1,
+                           slab2, out2);
     }
 }
 
@@ -432,17 +450,30 @@ __global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* G, long
         for (int k = 0; k < 4; ++k) partial[(long)blockIdx.x * ncols + threadIdx.x * 4 + k] = t[k];
     }
 }
-// 256 threads = 4 part groups x 64 columns, fixed-order combine
+// 256 threads = 4 part groups x 64 columns - or, for up to 16 columns (where the 4-group form is 64 dependent loads per
+// thread, ~13 us of latency for a kilobyte of result), 16 part groups x 16 columns; fixed-order combine
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int parts, int ncols, float* out) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, pg = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cl;
-    float s = 0.f;
-    if (col < ncols)
-        for (int i = pg; i < parts; i += 4) s += partial[(long)i * ncols + col];
-    red[pg][cl] = s;
+    __shared__ float red[16][64];
+    const bool narrow = ncols <= 16;
+    const int cw = narrow ? 16 : 64, ng = 256 / cw;
+    const int cl = threadIdx.x % cw, pg = threadIdx.x / cw;
+    const int col = blockIdx.x * cw + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < ncols) {
+        int i = pg;
+        for (; i + ng < parts; i += 2 * ng) {
+            s0 += partial[(long)i * ncols + col];
+            s1 += partial[(long)(i + ng) * ncols + col];
+        }
+        if (i < parts) s0 += partial[(long)i * ncols + col];
+    }
+    red[pg][cl] = s0 + s1;
     __syncthreads();
-    if (pg == 0 && col < ncols) out[col] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (pg == 0 && col < ncols) {
+        float t = 0.f;
+        for (int g = 0; g < ng; ++g) t += red[g][cl];
+        out[col] = t;
+    }
 }
 
 // per-256-row-block column sums / sums of squares of y[M][K] (pixel stride ldy) -> stats[blk][2][ld]:
@@ -1330,10 +1361,7 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
 #undef ACIMG_WH16
             int rc = check_launch("wgrad_halo16");
             if (rc) return rc;
-            const long total = (long)p.KK * p.Ngemm;
-            const int nb1 = (int)cdiv(total, 32), nb2 = db ? cdiv(p.Ngemm, 32) : 0;
-            hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(nb1 + nb2), dim3(256), 0, st, q.out, nb, (long)p.KK, p.Ngemm,
-                               p.ldo, dw, nb1, db_slab, db);
+            launch_slab_reduce_wide(q.out, nb, (long)p.KK, p.Ngemm, p.ldo, dw, db ? db_slab : nullptr, db, st);
             return check_launch("wgrad_reduce");
         }
     }
@@ -1367,10 +1395,7 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
 #undef ACIMG_WH
         int rc = check_launch("wgrad_halo");
         if (rc) return rc;
-        const long total = (long)p.KK * p.Ngemm;
-        const int nb1 = (int)cdiv(total, 32), nb2 = db ? cdiv(p.Ngemm, 32) : 0;
-        hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(nb1 + nb2), dim3(256), 0, st, q.out, nb, (long)p.KK, p.Ngemm,
-                           p.ldo, dw, nb1, db_slab, db);
+        launch_slab_reduce_wide(q.out, nb, (long)p.KK, p.Ngemm, p.ldo, dw, db ? db_slab : nullptr, db, st);
         return check_launch("wgrad_reduce");
     }
     if (split3) bn = wgrad_split3_bn(p.Ngemm);
@@ -1408,9 +1433,7 @@ static int launch_wgrad(WgradParams p, float* dw, float* db, void* ws, size_t ws
     if (p.splits > 1) {
         const long total = (long)p.KK * p.Ngemm;
         if (p.splits > 32) {
-            const int nb1 = (int)cdiv(total, 32), nb2 = db ? cdiv(p.Ngemm, 32) : 0;
-            hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(nb1 + nb2), dim3(256), 0, st, p.out, p.splits,
-                               (long)p.KK, p.Ngemm, p.ldo, dw, nb1, db_slab, db);
+            launch_slab_reduce_wide(p.out, p.splits, (long)p.KK, p.Ngemm, p.ldo, dw, db ? db_slab : nullptr, db, st);
         } else {
             const int nb1 = (int)cdiv(total, 256), nb2 = db ? cdiv(p.Ngemm, 256) : 0;
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(nb1 + nb2), dim3(256), 0, st, p.out, p.splits,
@@ -2476,8 +2499,7 @@ int acimg_deconv_wgrad(const AcimgConvDesc* d, const float* x, const float* gy, 
         hipLaunchKernelGGL(patch2_wgrad_32x8_kernel, dim3(PATCH2_WGRAD_WGS), dim3(1024), 0, (hipStream_t)stream, q);
         rc = check_launch("patch2_wgrad");
         if (rc) return rc;
-        hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(cdiv(32 * 32, 32)), dim3(256), 0, (hipStream_t)stream, q.out,
-                           PATCH2_WGRAD_WGS, 32L, 32, d->ldw, dw, cdiv(32 * 32, 32), nullptr, nullptr);
+        launch_slab_reduce_wide(q.out, PATCH2_WGRAD_WGS, 32L, 32, d->ldw, dw, nullptr, nullptr, (hipStream_t)stream);
         rc = check_launch("patch2_wgrad reduce");
         if (rc) return rc;
         // the transposed conv adds its bias at every output pixel, and every output pixel belongs to exactly one patch: the
