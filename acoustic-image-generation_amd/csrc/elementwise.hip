@@ -273,20 +273,29 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* x, int 
 
 // one workgroup per 32 channels x {dbeta, dgamma}: 8 row groups of 32 lanes walk the blocks, fixed-order tree
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partial, int blocks, int C,
-                                                              float* dgamma, float* dbeta, float* sums) {
-    __shared__ float red[8][32];
-    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+                                                              float* dgamma, float* dbeta, float* sums, int cw) {
+    // 256 threads = cw channels x 256 / cw partial-row groups (cw = 8 / 16 / 32 by the channel count: with few channels more
+    // groups walk the <= 256 partial rows - 8 dependent loads per thread instead of 32; the kernel is pure latency, 22 launches
+    // per U-Net step); two sums in flight per thread; groups combined in order
+    __shared__ float red[32][32];
+    const int ng = 256 / cw;
+    const int cl = threadIdx.x % cw, rg = threadIdx.x / cw;
     const int which = blockIdx.y;                       // 0: sum g (dbeta), 1: sum g*xhat (dgamma)
-    const int c = blockIdx.x * 32 + cl;
-    float a = 0.f;
-    if (c < C)
-        for (int j = rg; j < blocks; j += 8) a += partial[(long)j * 2 * C + which * C + c];
-    red[rg][cl] = a;
+    const int c = blockIdx.x * cw + cl;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C) {
+        int j = rg;
+        for (; j + ng < blocks; j += 2 * ng) {
+            a0 += partial[(long)j * 2 * C + which * C + c];
+            a1 += partial[(long)(j + ng) * 2 * C + which * C + c];
+        }
+        if (j < blocks) a0 += partial[(long)j * 2 * C + which * C + c];
+    }
+    red[rg][cl] = a0 + a1;
     __syncthreads();
     if (rg == 0 && c < C) {
         float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) t += red[i][cl];
+        for (int i = 0; i < ng; ++i) t += red[i][cl];
         (which ? dgamma : dbeta)[c] = t;
         sums[which * C + c] = t;
     }
@@ -1306,7 +1315,8 @@ int acimg_bn_bwd(const float* x, int ldx, const float* gy, int ldgy, const float
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((int)blocks), dim3(256), 256 * 8 * sizeof(float), st, x, ldx, gy, ldgy,
                        scale, shift, save_mean, save_invstd, rows, C, rpb, partial);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32), 2), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta, sums);
+    const int cw = C <= 8 ? 8 : (C <= 16 ? 16 : 32);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, cw), 2), dim3(256), 0, st, partial, (int)blocks, C, dgamma, dbeta, sums, cw);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, st, x, ldx, gy, ldgy, scale, shift,
                        save_mean, save_invstd, gamma, sums, rows, C, gx, ldgx);
     return check_launch("bn_bwd");
