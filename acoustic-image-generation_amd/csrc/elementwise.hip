@@ -235,20 +235,51 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* x, int 
     if (tr < rstep) {
         const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
         const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+        const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
+        const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, iss[4] = {is.x, is.y, is.z, is.w};
         const long r0 = (long)blockIdx.x * rows_per_block;
         const long r1 = min(rows, r0 + rows_per_block);
-        for (long r = r0 + tr; r < r1; r += rstep) {
+        // four rows per trip with sums of their own: eight 16-byte loads in flight per thread (one row per trip streamed the
+        // two largest U-Net shapes at 2.5 TB/s - 54 us for 137 MB - while the apply pass, more bytes, took 33 us)
+        float t1[4][4], t2[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t1[u][k] = t2[u][k] = 0.f;
+        long r = r0 + tr;
+        for (; r + 3L * rstep < r1; r += 4L * rstep) {
+            float4 xv[4], gv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv[u] = *reinterpret_cast<const float4*>(x + (r + (long)u * rstep) * ldx + c);
+                gv[u] = *reinterpret_cast<const float4*>(gy + (r + (long)u * rstep) * ldgy + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float g = xs[k] * scs[k] + shs[k] > 0.f ? gs[k] : 0.f;
+                    t1[u][k] += g;
+                    t2[u][k] += g * (xs[k] - mus[k]) * iss[k];
+                }
+            }
+        }
+        for (; r < r1; r += rstep) {
             const float4 xv = *reinterpret_cast<const float4*>(x + r * ldx + c);
             const float4 gv = *reinterpret_cast<const float4*>(gy + r * ldgy + c);
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
-            const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
-            const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, iss[4] = {is.x, is.y, is.z, is.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float g = xs[k] * scs[k] + shs[k] > 0.f ? gs[k] : 0.f;
-                s1[k] += g;
-                s2[k] += g * (xs[k] - mus[k]) * iss[k];
+                t1[0][k] += g;
+                t2[0][k] += g * (xs[k] - mus[k]) * iss[k];
             }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s1[k] = (t1[0][k] + t1[1][k]) + (t1[2][k] + t1[3][k]);
+            s2[k] = (t2[0][k] + t2[1][k]) + (t2[2][k] + t2[3][k]);
         }
     }
 #pragma unroll
