@@ -433,10 +433,25 @@ __global__ __launch_bounds__(256) void colsum_narrow_kernel(const float* G, long
     if (tr < rstep) {
         const long r0 = (long)blockIdx.x * rows_per_block;
         const long r1 = min(rows, r0 + rows_per_block);
-        for (long r = r0 + tr; r < r1; r += rstep) {
+        // four rows in flight per thread, sums of their own, combined in a fixed order
+        float b[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        long r = r0 + tr;
+        for (; r + 3L * rstep < r1; r += 4L * rstep) {
+            const float4 v0 = *reinterpret_cast<const float4*>(G + r * ld + tc * 4);
+            const float4 v1 = *reinterpret_cast<const float4*>(G + (r + rstep) * ld + tc * 4);
+            const float4 v2 = *reinterpret_cast<const float4*>(G + (r + 2L * rstep) * ld + tc * 4);
+            const float4 v3 = *reinterpret_cast<const float4*>(G + (r + 3L * rstep) * ld + tc * 4);
+            a[0] += v0.x; a[1] += v0.y; a[2] += v0.z; a[3] += v0.w;
+            b[0][0] += v1.x; b[0][1] += v1.y; b[0][2] += v1.z; b[0][3] += v1.w;
+            b[1][0] += v2.x; b[1][1] += v2.y; b[1][2] += v2.z; b[1][3] += v2.w;
+            b[2][0] += v3.x; b[2][1] += v3.y; b[2][2] += v3.z; b[2][3] += v3.w;
+        }
+        for (; r < r1; r += rstep) {
             const float4 v = *reinterpret_cast<const float4*>(G + r * ld + tc * 4);
             a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
         }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = (a[k] + b[0][k]) + (b[1][k] + b[2][k]);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) sm[threadIdx.x * 4 + k] = a[k];
@@ -487,12 +502,26 @@ __global__ __launch_bounds__(256) void partial_stats_kernel(const float* y, int 
     for (int cb = 0; cb < K; cb += 32) {
         const int c = cb + cl;
         float s1 = 0.f, s2 = 0.f;
-        if (c < K)
-            for (int r = r0 + rg; r < r1; r += 8) {
-                const float v = y[(long)r * ldy + c];
-                s1 += v;
-                s2 += v * v;
+        if (c < K) {
+            // four rows in flight per thread (one at a time this pass streamed 17 MB in 33 us)
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+            int r = r0 + rg;
+            for (; r + 24 < r1; r += 32) {
+                const float v0 = y[(long)r * ldy + c], v1 = y[(long)(r + 8) * ldy + c];
+                const float v2 = y[(long)(r + 16) * ldy + c], v3 = y[(long)(r + 24) * ldy + c];
+                a0 += v0; b0 += v0 * v0;
+                a1 += v1; b1 += v1 * v1;
+                a2 += v2; b2 += v2 * v2;
+                a3 += v3; b3 += v3 * v3;
             }
+            for (; r < r1; r += 8) {
+                const float v = y[(long)r * ldy + c];
+                a0 += v;
+                b0 += v * v;
+            }
+            s1 = (a0 + a1) + (a2 + a3);
+            s2 = (b0 + b1) + (b2 + b3);
+        }
         red[0][rg][cl] = s1;
         red[1][rg][cl] = s2;
         __syncthreads();
