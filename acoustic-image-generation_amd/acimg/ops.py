@@ -437,8 +437,16 @@ def conv2d_fwd_tiling(d):
     return out[0], out[1], out[2]
 
 
+def _check_stats_rows(stats, rows, what):
+    """the C side writes `rows` rows of 2 x ldw floats and cannot see the buffer: a tensor sized from ANOTHER descriptor (the
+    row count depends on the kernel the shape takes, activation included) would be overrun silently"""
+    if isinstance(stats, torch.Tensor) and stats.dim() >= 1 and stats.shape[0] < rows:
+        raise ValueError("%s: statistics buffer has %d rows, this descriptor writes %d" % (what, stats.shape[0], rows))
+
+
 def conv2d_fwd(plan, d, x, w, bias, y, in_scale=None, in_shift=None, in_relu=0, stats=None):
     L = _L()
+    _check_stats_rows(stats, L.acimg_conv2d_stats_rows(C.byref(d)), "conv2d_fwd")
     plan.ws.require(L.acimg_conv2d_fwd_workspace(C.byref(d)))
     plan.add("conv2d_fwd", L.acimg_conv2d_fwd, C.byref(d), x, w, bias, y, in_scale, in_shift,
              int(in_relu), stats, _WsPtr(plan.ws), _WsBytes(plan.ws), _Tickets(plan.ws))
@@ -481,6 +489,7 @@ def conv2d_split3_prepare_multi(plan, jobs):
 def conv2d_fwd_split3(plan, d, x, wsplit, y, in_scale=None, in_shift=None, in_relu=0, stats=None, bias=None, bf16=False):
     """bf16: both operands rounded to bf16, one MFMA per product (acimg_conv2d_fwd_bf16; wsplit from the bf16 prepare)"""
     fn = _L().acimg_conv2d_fwd_bf16 if bf16 else _L().acimg_conv2d_fwd_split3
+    _check_stats_rows(stats, _L().acimg_conv2d_fwd_split3_stats_rows(C.byref(d)), "conv2d_fwd_split3")
     plan.add("conv2d_fwd_bf16" if bf16 else "conv2d_fwd_split3", fn, C.byref(d), x, wsplit, bias, y, in_scale, in_shift,
              int(in_relu), stats)
 

@@ -58,6 +58,12 @@ def test_host_side_queries_need_no_gpu(lib):
     assert ops.conv2d_stats_rows(ops.conv_desc(32, 224, 298, 8, 8, 3, 3, 2, "SAME")) == 32 * 112 * 149 // 256
     assert ops.conv2d_stats_rows(ops.conv_desc(32, 224, 298, 8, 8, 3, 3, 1, "SAME", act=1)) == 32 * 224 * 298 // 256
     assert ops.conv2d_stats_rows(ops.conv_desc(2, 100, 100, 8, 8, 3, 3, 1, "SAME")) != 512
+    # the host wrapper refuses a statistics tensor sized from another descriptor (the C side cannot see the buffer)
+    import pytest as _pt
+    import torch as _t
+    dd = ops.conv_desc(32, 224, 298, 8, 8, 3, 3, 1, "SAME")
+    with _pt.raises(ValueError):
+        ops.conv2d_fwd(ops.Plan(_t.device("cpu")), dd, _t.zeros(1), _t.zeros(1), None, _t.zeros(1), stats=_t.zeros(100, 2, 8))
     # which layers read a producer's raw output through its batch norm (forward AND weight gradient stage through registers):
     # precision 0 = fp32-class entries (few channels), 1 = split3, 2 = bf16 (32 / 64 channels in, 32 out)
     assert ops.conv2d_affine_input_ok(ops.conv_desc(32, 224, 298, 8, 8, 3, 3, 1, "SAME"), 0)
